@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL TinyMPC reference (oracle/_ref/libtinympc_ref.so).
+
+Run in the build container (needs /root/reference to build the _ref library):
+    make -C oracle ref && python oracle/gen_golden.py
+The reference ships no tests or golden vectors; these fixtures are
+outputs of the reference itself on seeded inputs, and they are what pins both the C
+restatement (tests/test_oracle_golden.py) and the HIP path (tests/test_gpu_*.py).
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import scenarios as sc  # noqa: E402
+from cpu_solvers import RefSolver, build_ref  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def main():
+    if build_ref() is None:
+        sys.exit("oracle/_ref/libtinympc_ref.so missing and /root/reference absent")
+    os.makedirs(OUT, exist_ok=True)
+
+    # 1. cache known-answer values (tiny_api.cpp:307-381) for the four problem families
+    kat = {}
+    for name in ("codegen_random", "cartpole", "quadrotor_20hz", "rocket_landing_20hz"):
+        prob, _ = sc.load_problem(name)
+        s = sc.make_solver(RefSolver, prob, sc.default_config(prob))
+        for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "APf", "BPf", "Q", "R"):
+            kat[f"{name}.{k}"] = s[k].copy()
+        s.close()
+    np.savez_compressed(os.path.join(OUT, "cache_kat.npz"), **kat)
+
+    # 2. single-solve suites
+    suites = {
+        "hover_warm": sc.hover_suite(RefSolver),
+        "tracking_random": sc.tracking_random_suite(),
+        "rocket_random_isoc": sc.rocket_random_suite(en_state_soc=0, en_input_soc=1),
+        "rocket_random_bothsoc": sc.rocket_random_suite(B=6, en_state_soc=1, en_input_soc=1),
+        "rocket_episode_isoc": sc.rocket_episode_suite(RefSolver, 0, 1),
+        "rocket_episode_nosoc": sc.rocket_episode_suite(RefSolver, 0, 0, steps=(0, 3, 40)),
+        "cartpole_episode": sc.cartpole_suite(RefSolver),
+        "random_state_quad": sc.random_state_suite("quadrotor_20hz", B=8, seed=7),
+        "random_state_rocket_soc": sc.random_state_suite("rocket_landing_20hz", B=8, seed=11, soc=True),
+        "sweep_4_2_10": sc.sweep_suite(4, 2, 10),
+        "sweep_8_4_30": sc.sweep_suite(8, 4, 30, B=3),
+        "sweep_12_2_10": sc.sweep_suite(12, 2, 10, B=3),
+    }
+    slim = ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc")
+    for name, suite in suites.items():
+        soc = suite["config"]["en_state_soc"] or suite["config"]["en_input_soc"]
+        fields = [f for f in slim if soc or f not in ("vcnew", "zcnew", "gc", "yc")]
+        if name.startswith("random_state"):
+            fields += ["q", "r", "p", "d", "sol_x", "sol_u"]
+        out = sc.run_cases(RefSolver, suite, fields=fields)
+        sc.save_suite(os.path.join(OUT, name + ".npz"), suite, out)
+        ep = suite.get("episode")
+        print(f"{name:26s} B={len(out['iter'])} iters={out['iter'].astype(int).tolist()}"
+              + (f" episode_total={int(ep['iters'].sum())}" if ep else ""))
+
+    # 3. tracking episode summary (examples/quadrotor_tracking.cpp): per-step iterations
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    cfg = sc._hover_cfg(prob, extra)
+    s = sc.make_solver(RefSolver, prob, cfg)
+    traj = np.array(extra["y_axis_line"])
+    N, nx, nu = prob["N"], prob["nx"], prob["nu"]
+    s["Xref"] = traj[0:N].T
+    x0 = s["Xref"][:, 0].copy()
+    its, u0s = [], []
+    for k in range(301 - N):
+        s["x"][:, 0] = x0
+        s["Xref"] = traj[k:k + N].T
+        s["y"] = np.zeros((nu, N - 1))
+        s["g"] = np.zeros((nx, N))
+        s.solve()
+        its.append(int(s.get("sol_iter")))
+        u0s.append(s["u"][:, 0].copy())
+        x0 = prob["A"] @ x0 + prob["B"] @ s["u"][:, 0]
+    s.close()
+    np.savez_compressed(os.path.join(OUT, "tracking_episode.npz"), iters=np.array(its, dtype=np.int32),
+                        u0=np.array(u0s), x_final=x0)
+    print("tracking episode total", sum(its))
+
+    # 4. project_soc known answers (admm.cpp:39-60) incl. the three branches and float truncation
+    rng = np.random.default_rng(5)
+    S = rng.normal(0, 1, (64, 3))
+    S[0] = [0.3, 0.4, 10.0]      # inside cone
+    S[1] = [0.3, 0.4, -10.0]     # below cone -> origin
+    S[2] = [3.0, 4.0, 1.0]       # outside
+    S[3] = [0.0, 0.0, 0.0]
+    mus = rng.uniform(0.1, 1.5, 64)
+    mus[:4] = [0.5, 0.5, 0.25, 0.3]
+    prob, _ = sc.load_problem("codegen_random")
+    s = sc.make_solver(RefSolver, prob, sc.default_config(prob))
+    P = np.stack([s.project_soc(S[i], mus[i]) for i in range(64)])
+    s.close()
+    np.savez_compressed(os.path.join(OUT, "project_soc_kat.npz"), s=S, mu=mus, out=P)
+
+    # 5. per-phase known answers on a random workspace (every phase symbol is exported, admm.hpp:12-17)
+    suite = sc.random_state_suite("rocket_landing_20hz", B=1, seed=3, soc=True)
+    s = sc.make_solver(RefSolver, suite["problem"], suite["config"])
+    rng = np.random.default_rng(3)
+    for k in s.STATE_FIELDS + ("Xref", "Uref"):
+        s[k] = rng.normal(0, 0.5, s[k].shape)
+    ph = {"in." + k: s[k].copy() for k in s.STATE_FIELDS + ("Xref", "Uref")}
+    for name in ("update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual"):
+        s.phase(name)
+        for k in s.STATE_FIELDS:
+            ph[f"{name}.{k}"] = s[k].copy()
+    s.set("check_termination", 1)
+    ph["termination"] = np.array([s.phase("termination_condition")] + [s.get(k) for k in (
+        "primal_residual_state", "dual_residual_state", "primal_residual_input", "dual_residual_input")])
+    s.close()
+    np.savez_compressed(os.path.join(OUT, "phase_kat.npz"), **ph)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()
