@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on its quoted config: QP solves/s (+ ADMM iterations/s) for
+65 536 batched quadrotor-hover instances (nx=12, nu=4, N=10) per MI355X.
+
+A "step" = ONE batched tiny_solve over the whole per-GPU batch (one MPC step of the closed loop of
+examples/quadrotor_hovering.cpp, warm-started from the previous step, plant advanced on device).
+The timed region always starts from the cold state of tiny_setup, so K steps = the first K steps of
+the reference's 100-step episode (K = 100 -> 882 ADMM iterations per instance).
+State is resident in HBM before timing starts.  Multi-GPU: one process per GPU, batch sharded with
+no data-path collective (weak scaling: 65 536 instances per GPU); one RCCL all-reduce of the
+residual / iteration statistics closes the timed region.
+
+  python bench.py --gpus 1 --steps 100 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+         --master-port 29500 bench.py --gpus 8 --steps 100 --warmup 10
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy rate)
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (spec)
+
+
+def flops_per_iter(nx, nu, N):
+    """SURVEY.md section 8 footnote 1 (box constraints only)."""
+    S = nx * N + nu * (N - 1)
+    return (4 * S + 2 * nx * nx + 3 * nx + (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nu * nu + 2 * nu + 3 * nx)
+            + (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nx + 2 * nu) + 11 * S)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="instances PER GPU")
+    ap.add_argument("--grid-waves-per-cu", type=int, default=int(os.environ.get("TINYMPC_GRID_WAVES_PER_CU", "0")))
+    ap.add_argument("--dpp-mode", type=int, default=int(os.environ.get("TINYMPC_DPP_MODE", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # CPU baseline first (rank 0, N=1 only), before any HIP context exists in this process.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import cpu_baseline
+        cpu = cpu_baseline.run(seconds=args.cpu_seconds)
+
+    import numpy as np
+    import torch
+    import tinympc_amd as tm
+
+    if not torch.cuda.is_available() or tm.device_count() == 0:
+        sys.exit("bench.py needs an MI355X: tinympc_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+
+    prob, extra = tm.load_problem("quadrotor_20hz")
+    h = extra["hover"]
+    nx, nu, N, B = prob["nx"], prob["nu"], prob["N"], args.batch
+    s = tm.TinyBatchSolver.from_problem(prob, B, device=local_rank)
+    s.set_bound_constraints(np.full((nx, 1), h["x_min"]), np.full((nx, 1), h["x_max"]),
+                            np.full((nu, 1), h["u_min"]), np.full((nu, 1), h["u_max"]))
+    s.update_settings(max_iter=h["max_iter"])
+    s.set_option("advance_x0", 1)
+    s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
+    s.set_option("dpp_mode", args.dpp_mode)
+    stream = torch.cuda.Stream(device=local_rank)
+    s.set_stream(stream.cuda_stream)                 # kernels, events and the RCCL all-reduce share one stream
+    xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
+    x0 = np.array(h["x0"], dtype=np.float64)
+    stats = torch.zeros(10, dtype=torch.float64, device=f"cuda:{local_rank}")
+
+    def cold_start():
+        s.reset()
+        s.set_x_ref(xref, broadcast=True)
+        s.set_x0(x0, broadcast=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        cold_start()
+        for _ in range(args.warmup):
+            s.solve_async()
+        s.synchronize()
+        cold_start()
+        s.set_option("timing", args.steps)           # HIP events around every timed solve kernel, on `stream`
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s.solve_async()
+        s.reduce_stats_async(stats.data_ptr())
+        if dist is not None:                         # the one collective of the path: residual / count all-reduce
+            counts = stats[[0, 1, 2, 7, 8]].contiguous()
+            resid = stats[3:7].contiguous()
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            dist.all_reduce(resid, op=dist.ReduceOp.MAX)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        acc_iters, acc_solved = float(counts[3].item()), float(counts[4].item())
+        max_resid = [float(v) for v in resid.tolist()]
+    else:
+        st = stats.tolist()
+        acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]
+
+    kern_ms = s.timing_ms()
+    solves = float(world) * B * args.steps
+    value = solves / elapsed
+    alg_bytes = s.algorithmic_bytes(cold=False) * B            # per launch, SURVEY.md 8(d) bytes_warm
+    avg_kernel_s = float(kern_ms.mean()) * 1e-3
+    achieved_gbs = alg_bytes / avg_kernel_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch, if profiled
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    fl = flops_per_iter(nx, nu, N)
+    iters_local = acc_iters / world
+    fp64_tflops = iters_local * fl / float(kern_ms.sum() * 1e-3) / 1e12
+    if rank == 0:
+        out = {
+            "metric": "QP solves/sec (+ ADMM iters/sec), 64k-batch quadrotor hover",
+            "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "quadrotor_hovering (nx=12, nu=4, N=10), 65536 identical instances per GPU, "
+                                   "closed-loop MPC steps from a cold start (BASELINE configs[1])",
+                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}",
+                       "grid_waves_per_cu": args.grid_waves_per_cu, "dpp_mode": args.dpp_mode},
+            "admm_iters_per_s": acc_iters / elapsed,
+            "admm_iters_per_solve": acc_iters / solves,
+            "solved_fraction": acc_solved / solves,
+            "max_residuals": max_resid,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "admm_solve_kernel<12,4,10>", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "bytes_warm = 8*(nx+8S)+44 = 10124 B per solve x batch; launches of the first "
+                                 "MPC steps run 100 ADMM iterations and are FP64-issue bound, see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64-valu", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": fp64_tflops / FP64_PEAK_TFLOPS,
+                              "flops_per_admm_iter": fl},
+            "kernel_ms": {"first": float(kern_ms[0]), "last": float(kern_ms[-1]), "sum": float(kern_ms.sum()),
+                          "min": float(kern_ms.min())},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    s.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

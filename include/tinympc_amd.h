@@ -1,0 +1,271 @@
+/*
+ * tinympc_amd.h -- C ABI of the MI355X-native batched TinyMPC ADMM solver (libtinympc_amd.so).
+ *
+ * Two surfaces, both plain C (pointers and sizes only, no C++/Eigen/torch types):
+ *
+ *  (A) the BATCHED, device-resident surface (tiny_batch_*): what the throughput metric is measured
+ *      on.  It mirrors the reference's operator interface for the hot path one-for-one --
+ *      tiny_setup / tiny_set_bound_constraints / tiny_set_cone_constraints / tiny_update_settings /
+ *      tiny_set_x0 / tiny_set_x_ref / tiny_set_u_ref / tiny_solve  (src/tinympc/tiny_api.hpp:10-54)
+ *      -- but every per-instance quantity carries a leading batch axis and lives in HBM.
+ *
+ *  (B) the reference's own entry points (tiny_setup, tiny_solve, ... same names, same argument
+ *      meaning, same return codes) over plain-data mirrors of the reference structs, so existing
+ *      callers compiled against the reference's headers link against this library unchanged
+ *      (INTEGRATION.md).  tiny_solve(TinySolver*) is a batch of one on the GPU.
+ *
+ * There is NO CPU fallback: every solve runs the HIP kernels; without a GPU the calls fail with
+ * TINY_ERR_NO_DEVICE.
+ *
+ * Matrix conventions: column-major (Eigen default).  Per-instance matrices of a batch are stored
+ * back to back: Xref is [batch][N][nx] doubles (instance-major, then knot point, then row).
+ */
+#ifndef TINYMPC_AMD_H
+#define TINYMPC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* return codes: 0 / 1 keep the reference's meaning (tiny_solve: 0 = all converged, 1 = some
+ * instance hit max_iter, admm.cpp:441,454; setters: 0 = ok, 1 = dimension error).              */
+#define TINY_OK                 0
+#define TINY_ERR_DIM            1
+#define TINY_ERR_NULL          (-1)
+#define TINY_ERR_NO_DEVICE     (-2)   /* no MI355X / HIP runtime failure: there is no CPU path   */
+#define TINY_ERR_UNSUPPORTED   (-3)   /* (nx,nu,N) not instantiated, or an out-of-scope feature   */
+#define TINY_ERR_HIP           (-4)
+#define TINY_ERR_ARG           (-5)
+
+/* work->status values (admm.cpp:336,431) */
+#define TINY_STATUS_SOLVED      1
+#define TINY_STATUS_UNSOLVED   11
+
+typedef struct TinyBatch TinyBatch;   /* opaque, owns its HBM buffers */
+
+/* Per-instance fields (reference names, src/tinympc/types.hpp:88-208). State-sized = nx x N,
+ * input-sized = nu x (N-1). */
+typedef enum {
+    TINY_F_X0 = 0,      /* nx            tiny_set_x0  (x[:,0])                */
+    TINY_F_XREF,        /* nx x N        tiny_set_x_ref                        */
+    TINY_F_UREF,        /* nu x (N-1)    tiny_set_u_ref                        */
+    TINY_F_X,           /* work->x      (primal; col 0 is x0)                 */
+    TINY_F_U,           /* work->u                                             */
+    TINY_F_VNEW,        /* work->vnew   (== solution->x after a solve)         */
+    TINY_F_ZNEW,        /* work->znew   (== solution->u)                       */
+    TINY_F_G,           /* work->g                                             */
+    TINY_F_Y,           /* work->y                                             */
+    TINY_F_V,           /* work->v                                             */
+    TINY_F_Z,           /* work->z                                             */
+    TINY_F_VCNEW,       /* work->vcnew  (cone slack, only with a cone enabled) */
+    TINY_F_ZCNEW,
+    TINY_F_GC,
+    TINY_F_YC,
+    TINY_F_Q,           /* work->q / r / p / d of the last iteration: only     */
+    TINY_F_R,           /* available after tiny_batch_set_option("debug", 1)   */
+    TINY_F_P,
+    TINY_F_D,
+    TINY_F_COUNT
+} TinyField;
+
+/* flags for tiny_batch_set / tiny_batch_get */
+#define TINY_HOST        0   /* pointer is host memory, [batch] matrices back to back          */
+#define TINY_DEVICE      1   /* pointer is device (HBM) memory on the batch's GPU               */
+#define TINY_BROADCAST   2   /* (set only) ONE matrix, replicated to every instance              */
+
+/* ---- problem family ---------------------------------------------------------------------- */
+int tiny_batch_device_count(void);
+
+/* == tiny_setup (tiny_api.hpp:10-12, tiny_api.cpp:21-147) for `batch` instances sharing one
+ * (A, B, f, Q, R, rho).  Qdiag/Rdiag are the USER diagonals (the reference's callers pass
+ * Q.asDiagonal()); rho is added the way the reference does (twice on the cache path).
+ * Runs the infinite-horizon Riccati recursion on the host (tiny_api.cpp:307-381), allocates the
+ * HBM records (zero-initialised, like tiny_setup) on GPU `device`.                                */
+int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn,
+                     const double* Qdiag, const double* Rdiag, double rho,
+                     int nx, int nu, int N, int batch, int device, int verbose);
+int tiny_batch_destroy(TinyBatch* b);
+
+/* == tiny_set_bound_constraints (tiny_api.hpp:13-15): nx x N, nx x N, nu x (N-1), nu x (N-1),
+ * column-major, shared by every instance. */
+int tiny_batch_set_bound_constraints(TinyBatch* b, const double* x_min, const double* x_max,
+                                     const double* u_min, const double* u_max);
+/* == tiny_set_cone_constraints (tiny_api.cpp:176-208): STATE triple first (the definition's
+ * positional order).  Cones have dimension 3 (admm.cpp:53) and must not overlap. */
+int tiny_batch_set_cone_constraints(TinyBatch* b, int n_state_cones, const int* Acx, const int* qcx,
+                                    const double* cx, int n_input_cones, const int* Acu,
+                                    const int* qcu, const double* cu);
+/* == tiny_update_settings (tiny_api.hpp:36-42).  The linear / time-varying-linear switches must
+ * be 0 (out of the hot-path scope): non-zero -> TINY_ERR_UNSUPPORTED. */
+int tiny_batch_update_settings(TinyBatch* b, double abs_pri_tol, double abs_dua_tol, int max_iter,
+                               int check_termination, int en_state_bound, int en_input_bound,
+                               int en_state_soc, int en_input_soc, int en_state_linear,
+                               int en_input_linear, int en_tv_state_linear, int en_tv_input_linear);
+/* Read back one cache matrix (TinyCache, types.hpp:43-59) by name: "Kinf" (nu x nx), "Pinf",
+ * "Quu_inv", "AmBKt", "APf", "BPf", or "Q"/"R" (work->Q/R = user + rho).  Returns element count. */
+int tiny_batch_get_cache(TinyBatch* b, const char* name, double* out, int capacity);
+
+/* ---- per-instance data ------------------------------------------------------------------- */
+/* tiny_set_x0 / tiny_set_x_ref / tiny_set_u_ref and direct workspace pokes of the examples
+ * (work->Xref = ..., work->y = 0, examples/quadrotor_tracking.cpp:89-93). */
+int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags);
+int tiny_batch_get(TinyBatch* b, TinyField field, double* dst, int flags);
+/* zero every warm-start record (x,u,vnew,znew,v,z,g,y,vcnew,zcnew,gc,yc) = state after tiny_setup */
+int tiny_batch_reset(TinyBatch* b);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* == tiny_solve (tiny_api.hpp:34): one ADMM solve of every instance from its warm state.
+ * Synchronous; returns 0 when every instance converged, 1 otherwise (admm.cpp:441,454). */
+int tiny_batch_solve(TinyBatch* b);
+/* Same launch, asynchronous on the batch's stream; returns TINY_OK after enqueueing. */
+int tiny_batch_solve_async(TinyBatch* b);
+int tiny_batch_synchronize(TinyBatch* b);
+/* solution->iter, solution->solved, work->status, and the four residuals
+ * {primal_state, primal_input, dual_state, dual_input} ([batch][4]); any pointer may be NULL. */
+int tiny_batch_get_status(TinyBatch* b, int* iter, int* solved, int* status, double* residuals);
+/* Device-side reduction over the batch: out[0..9] = {sum iter, sum solved, batch,
+ * max primal_state, max primal_input, max dual_state, max dual_input,
+ * iterations accumulated since the last tiny_batch_reset, converged solves accumulated, 0}.
+ * host_out and/or device_out (a device pointer to 10 doubles, e.g. the buffer handed to an
+ * RCCL all-reduce) may be NULL. */
+int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
+
+/* ---- plumbing ---------------------------------------------------------------------------- */
+/* Options: "advance_x0" (1: each solve also writes x0 <- A x0 + B u[:,0] + f, the plant step of
+ * the examples' closed loop, examples/quadrotor_hovering.cpp:92), "debug" (1: keep q,r,p,d),
+ * "grid_waves_per_cu" (persistent-grid size, 0 = one wave per tile), "dpp_mode" (0 fused
+ * v_fmac_f64_dpp, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves). */
+int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
+int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
+/* kernel durations (ms) of the solves recorded since "timing" was set; returns the count */
+int tiny_batch_get_timing(TinyBatch* b, float* ms, int capacity);
+const char* tiny_batch_last_error(TinyBatch* b);
+/* registered (nx,nu,N) kernel instantiations: writes up to capacity triples, returns the count */
+int tiny_batch_supported_dims(int* triples, int capacity);
+/* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
+ * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */
+long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold);
+
+/* ------------------------------------------------------------------------------------------ */
+/* (B) Reference entry points over plain-data mirrors of the reference structs.
+ *
+ * Layout contract (x86-64, Eigen 3.4.90, measured with offsetof against the reference's own
+ * src/tinympc/types.hpp, see SURVEY.md section 8(b) and tests/test_abi_layout.py):
+ *   tinyMatrix  = {double* data; int64 rows; int64 cols}   (DenseStorage.h:453-457)
+ *   tinyVector  = {double* data; int64 rows}                (DenseStorage.h:613-616)
+ *   VectorXi    = {int* data;    int64 rows}
+ * Eigen objects passed BY VALUE through C linkage arrive, under the Itanium C++ ABI, as a
+ * pointer to a caller-owned temporary -- hence the `const Tiny*POD*` parameters below.          */
+typedef struct { double* data; int64_t rows; int64_t cols; } TinyMatrixPOD;
+typedef struct { double* data; int64_t rows; } TinyVectorPOD;
+typedef struct { int* data; int64_t rows; } TinyVectorXiPOD;
+
+typedef struct {                 /* types.hpp:32-37, 56 bytes */
+    int iter;
+    int solved;
+    TinyMatrixPOD x;
+    TinyMatrixPOD u;
+} TinySolution;
+
+typedef struct {                 /* types.hpp:43-59, 280 bytes */
+    double rho;
+    TinyMatrixPOD Kinf, Pinf, Quu_inv, AmBKt;
+    TinyVectorPOD APf, BPf;
+    TinyMatrixPOD C1, C2;
+    TinyMatrixPOD dKinf_drho, dPinf_drho, dC1_drho, dC2_drho;
+} TinyCache;
+
+typedef struct {                 /* types.hpp:63-82, 88 bytes */
+    double abs_pri_tol;
+    double abs_dua_tol;
+    int max_iter;
+    int check_termination;
+    int en_state_bound;
+    int en_input_bound;
+    int en_state_soc;
+    int en_input_soc;
+    int en_state_linear;
+    int en_input_linear;
+    int en_tv_state_linear;
+    int en_tv_input_linear;
+    int adaptive_rho;
+    double adaptive_rho_min;
+    double adaptive_rho_max;
+    int adaptive_rho_enable_clipping;
+} TinySettings;
+
+typedef struct {                 /* types.hpp:88-208, 1328 bytes */
+    int nx, nu, N;
+    TinyMatrixPOD x, u, q, r, p, d, v, vnew, z, znew, g, y;
+    TinyMatrixPOD x_min, x_max, u_min, u_max;
+    int numStateCones, numInputCones;
+    TinyVectorPOD cx, cu;
+    TinyVectorXiPOD Acx, Acu, qcx, qcu;
+    TinyMatrixPOD vc, vcnew, zc, zcnew, gc, yc;
+    int numStateLinear, numInputLinear;
+    TinyMatrixPOD Alin_x;
+    TinyVectorPOD blin_x;
+    TinyMatrixPOD Alin_u;
+    TinyVectorPOD blin_u;
+    TinyMatrixPOD vl, vlnew, zl, zlnew, gl, yl;
+    int numtvStateLinear, numtvInputLinear;
+    TinyMatrixPOD tv_Alin_x, tv_blin_x, tv_Alin_u, tv_blin_u;
+    TinyMatrixPOD vl_tv, vlnew_tv, zl_tv, zlnew_tv, gl_tv, yl_tv;
+    TinyVectorPOD Q, R;
+    TinyMatrixPOD Adyn, Bdyn;
+    TinyVectorPOD fdyn;
+    TinyMatrixPOD Xref, Uref;
+    TinyVectorPOD Qu;
+    double primal_residual_state, primal_residual_input, dual_residual_state, dual_residual_input;
+    int status;
+    int iter;
+} TinyWorkspace;
+
+typedef struct {                 /* types.hpp:213-218, 32 bytes */
+    TinySolution* solution;
+    TinySettings* settings;
+    TinyCache* cache;
+    TinyWorkspace* work;
+} TinySolver;
+
+/* tiny_api.hpp:10-12 */
+int tiny_setup(TinySolver** solverp, const TinyMatrixPOD* Adyn, const TinyMatrixPOD* Bdyn,
+               const TinyMatrixPOD* fdyn, const TinyMatrixPOD* Q, const TinyMatrixPOD* R,
+               double rho, int nx, int nu, int N, int verbose);
+/* tiny_api.hpp:13-15 */
+int tiny_set_bound_constraints(TinySolver* solver, const TinyMatrixPOD* x_min, const TinyMatrixPOD* x_max,
+                               const TinyMatrixPOD* u_min, const TinyMatrixPOD* u_max);
+/* tiny_api.hpp:16-18; positional binding of the DEFINITION (tiny_api.cpp:176-178): state first */
+int tiny_set_cone_constraints(TinySolver* solver, const TinyVectorXiPOD* Acx, const TinyVectorXiPOD* qcx,
+                              const TinyVectorPOD* cx, const TinyVectorXiPOD* Acu,
+                              const TinyVectorXiPOD* qcu, const TinyVectorPOD* cu);
+/* tiny_api.hpp:25-27 */
+int tiny_precompute_and_set_cache(TinyCache* cache, const TinyMatrixPOD* Adyn, const TinyMatrixPOD* Bdyn,
+                                  const TinyMatrixPOD* fdyn, const TinyMatrixPOD* Q, const TinyMatrixPOD* R,
+                                  int nx, int nu, double rho, int verbose);
+/* tiny_api.hpp:34, admm.hpp:9 */
+int tiny_solve(TinySolver* solver);
+int solve(TinySolver* solver);
+/* tiny_api.hpp:36-43 */
+int tiny_update_settings(TinySettings* settings, double abs_pri_tol, double abs_dua_tol, int max_iter,
+                         int check_termination, int en_state_bound, int en_input_bound,
+                         int en_state_soc, int en_input_soc, int en_state_linear, int en_input_linear,
+                         int en_tv_state_linear, int en_tv_input_linear);
+int tiny_set_default_settings(TinySettings* settings);
+/* tiny_api.hpp:45-47 */
+int tiny_set_x0(TinySolver* solver, const TinyVectorPOD* x0);
+int tiny_set_x_ref(TinySolver* solver, const TinyMatrixPOD* x_ref);
+int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref);
+/* NEW: n solvers that share one cache / settings / bounds, solved in ONE launch (gather from and
+ * scatter to ordinary TinySolver workspaces).  Returns 0 when all converged, else 1. */
+int tiny_solve_batch(TinySolver** solvers, int n);
+/* NEW: the reference has no destroy (tiny_api.cpp:25-29 leaks); this frees host + device state. */
+int tiny_destroy(TinySolver* solver);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYMPC_AMD_H */

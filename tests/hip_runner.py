@@ -1,0 +1,54 @@
+"""Run a parity suite (oracle/scenarios.py) through the product: libtinympc_amd.so via the C ABI."""
+import numpy as np
+
+import tinympc_amd as tm
+
+IN_FIELDS = ("Xref", "Uref", "vnew", "znew", "g", "y", "v", "z", "x", "u", "gc", "yc")
+OUT_FIELDS = ("x", "u", "vnew", "znew", "g", "y", "v", "z")
+SOC_OUT = ("vcnew", "zcnew", "gc", "yc")
+
+
+def make_batch(suite, batch=None, replicate=1):
+    prob, cfg = suite["problem"], suite["config"]
+    B = (batch or suite["cases"]["x0"].shape[0]) * replicate
+    s = tm.TinyBatchSolver(prob["A"], prob["B"], prob["f"], prob["Q"], prob["R"], prob["rho"], prob["nx"],
+                           prob["nu"], prob["N"], B)
+    s.set_bound_constraints(cfg["x_min"], cfg["x_max"], cfg["u_min"], cfg["u_max"])
+    sc_, ic_ = cfg.get("state_cone"), cfg.get("input_cone")
+    if sc_ is not None or ic_ is not None:
+        sc_ = sc_ or ([], [], [])
+        ic_ = ic_ or ([], [], [])
+        s.set_cone_constraints(sc_[0], sc_[1], sc_[2], ic_[0], ic_[1], ic_[2])
+    s.update_settings(cfg["abs_pri_tol"], cfg["abs_dua_tol"], cfg["max_iter"], cfg["check_termination"],
+                      cfg["en_state_bound"], cfg["en_input_bound"], cfg["en_state_soc"], cfg["en_input_soc"])
+    return s
+
+
+def run_cases_hip(suite, replicate=1, debug=False, options=None):
+    """One tiny_solve per case, all cases in ONE launch. replicate>1 tiles the cases (bigger grids)."""
+    cases = suite["cases"]
+    s = make_batch(suite, replicate=replicate)
+    for k, v in (options or {}).items():
+        s.set_option(k, v)
+    if debug:
+        s.set_option("debug", 1)
+    rep = (lambda a: np.concatenate([a] * replicate, axis=0)) if replicate > 1 else (lambda a: a)
+    s.set_x0(rep(cases["x0"]))
+    for f in IN_FIELDS:
+        if f in cases:
+            s.set(f, rep(cases[f]))
+    ret = s.solve()
+    soc = suite["config"]["en_state_soc"] or suite["config"]["en_input_soc"]
+    out = {f: s.get(f) for f in OUT_FIELDS + (SOC_OUT if soc else ())}
+    if debug:
+        for f in ("q", "r", "p", "d"):
+            out[f] = s.get(f)
+    st = s.status()
+    out.update(iter=st["iter"].astype(float), sol_iter=st["iter"].astype(float), sol_solved=st["solved"].astype(float),
+               status=st["status"].astype(float), ret=(1.0 - st["solved"]).astype(float),
+               primal_residual_state=st["primal_residual_state"], primal_residual_input=st["primal_residual_input"],
+               dual_residual_state=st["dual_residual_state"], dual_residual_input=st["dual_residual_input"])
+    out["sol_x"], out["sol_u"] = out["vnew"], out["znew"]          # solution = slack (admm.cpp:436-437)
+    out["batch_ret"] = ret
+    s.close()
+    return out

@@ -1,0 +1,299 @@
+"""tinympc_amd -- MI355X-native batched TinyMPC ADMM solver (host-side mirror of the C ABI).
+
+The product is ``libtinympc_amd.so`` (hand-written HIP for gfx950 + a C ABI, ``include/tinympc_amd.h``).
+This package is a thin ctypes mirror of the reference's operator interface for the hot path
+(``tiny_setup / tiny_set_bound_constraints / tiny_set_cone_constraints / tiny_update_settings /
+tiny_set_x0 / tiny_set_x_ref / tiny_set_u_ref / tiny_solve``, reference
+``src/tinympc/tiny_api.hpp:10-54``) with a leading batch axis.  There is no CPU fallback: if the
+shared library is missing the import fails, and without a GPU ``TinyBatchSolver`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinympc_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+
+OK, ERR_DIM, ERR_NULL, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_HIP, ERR_ARG = 0, 1, -1, -2, -3, -4, -5
+HOST, DEVICE, BROADCAST = 0, 1, 2
+
+# TinyField (include/tinympc_amd.h)
+FIELDS = ("x0", "Xref", "Uref", "x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc",
+          "q", "r", "p", "d")
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+STATE_FIELDS = {"Xref", "x", "vnew", "g", "v", "vcnew", "gc", "q", "p"}
+
+# every extern "C" symbol include/tinympc_amd.h declares (checked by tests/test_abi_symbols.py)
+BATCH_SYMBOLS = (
+    "tiny_batch_device_count", "tiny_batch_setup", "tiny_batch_destroy", "tiny_batch_set_bound_constraints",
+    "tiny_batch_set_cone_constraints", "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
+    "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
+    "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
+    "tiny_batch_get_timing", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
+REFERENCE_SYMBOLS = (
+    "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_precompute_and_set_cache",
+    "tiny_solve", "solve", "tiny_update_settings", "tiny_set_default_settings", "tiny_set_x0", "tiny_set_x_ref",
+    "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy")
+
+
+class TinyMPCError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libtinympc_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or `make -C tinympc_amd/csrc`). tinympc_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.tiny_batch_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int]
+        L.tiny_batch_destroy.argtypes = [C.c_void_p]
+        L.tiny_batch_set_bound_constraints.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.tiny_batch_set_cone_constraints.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp]
+        L.tiny_batch_update_settings.argtypes = [C.c_void_p, C.c_double, C.c_double] + [C.c_int] * 10
+        L.tiny_batch_get_cache.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+        L.tiny_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.tiny_batch_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.tiny_batch_reset.argtypes = [C.c_void_p]
+        L.tiny_batch_solve.argtypes = [C.c_void_p]
+        L.tiny_batch_solve_async.argtypes = [C.c_void_p]
+        L.tiny_batch_synchronize.argtypes = [C.c_void_p]
+        L.tiny_batch_get_status.argtypes = [C.c_void_p, _ip, _ip, _ip, _dp]
+        L.tiny_batch_reduce_stats.argtypes = [C.c_void_p, _dp, C.c_void_p]
+        L.tiny_batch_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.tiny_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.tiny_batch_get_timing.argtypes = [C.c_void_p, _fp, C.c_int]
+        L.tiny_batch_last_error.argtypes = [C.c_void_p]
+        L.tiny_batch_last_error.restype = C.c_char_p
+        L.tiny_batch_supported_dims.argtypes = [_ip, C.c_int]
+        L.tiny_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.tiny_batch_algorithmic_bytes.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().tiny_batch_device_count())
+
+
+def supported_dims():
+    buf = (C.c_int * (3 * 256))()
+    n = lib().tiny_batch_supported_dims(buf, 256)
+    return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _colmajor(a, shape):
+    """numpy (rows, cols) -> flat column-major doubles."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    a = np.broadcast_to(a, shape)
+    return np.ascontiguousarray(a.T).ravel()
+
+
+class TinyBatchSolver:
+    """``batch`` independent MPC QPs sharing one (A, B, f, Q, R, rho): device-resident state, one
+    HIP launch per ``solve()``.  Method names / argument meaning follow ``tiny_api.hpp``."""
+
+    def __init__(self, A, B, f, Q, R, rho, nx, nu, N, batch, device=0, verbose=0):
+        self._h = C.c_void_p()
+        self.nx, self.nu, self.N, self.batch = int(nx), int(nu), int(N), int(batch)
+        A = _colmajor(A, (nx, nx))
+        Bm = _colmajor(B, (nx, nu))
+        fv = _f64(np.zeros(nx) if f is None else f).ravel()
+        Q = _f64(Q)
+        R = _f64(R)
+        Qd = (np.diag(Q) if Q.ndim == 2 else Q).copy()      # callers pass Q.asDiagonal() (dense) or the diagonal
+        Rd = (np.diag(R) if R.ndim == 2 else R).copy()
+        rc = lib().tiny_batch_setup(C.byref(self._h), A.ctypes.data_as(_dp), Bm.ctypes.data_as(_dp),
+                                    fv.ctypes.data_as(_dp), Qd.ctypes.data_as(_dp), Rd.ctypes.data_as(_dp),
+                                    float(rho), nx, nu, N, batch, device, verbose)
+        if rc != OK:
+            self._h = C.c_void_p()
+            msg = {ERR_NO_DEVICE: "no MI355X / HIP device available (there is no CPU fallback)",
+                   ERR_UNSUPPORTED: f"(nx,nu,N)=({nx},{nu},{N}) has no compiled kernel; have {supported_dims()}",
+                   ERR_DIM: "bad dimensions"}.get(rc, f"error {rc}")
+            raise TinyMPCError(f"tiny_batch_setup failed: {msg}")
+
+    @classmethod
+    def from_problem(cls, prob, batch, device=0):
+        return cls(prob["A"], prob["B"], prob.get("f"), prob["Q"], prob["R"], prob["rho"], prob["nx"], prob["nu"],
+                   prob["N"], batch, device)
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tiny_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc not in (OK,):
+            raise TinyMPCError(f"{what} failed ({rc}): {lib().tiny_batch_last_error(self._h).decode()}")
+
+    # ---- problem family (tiny_api.hpp:13-18, 36-43)
+    def set_bound_constraints(self, x_min, x_max, u_min, u_max):
+        nx, nu, N = self.nx, self.nu, self.N
+        a = [_colmajor(x_min, (nx, N)), _colmajor(x_max, (nx, N)), _colmajor(u_min, (nu, N - 1)),
+             _colmajor(u_max, (nu, N - 1))]
+        self._check(lib().tiny_batch_set_bound_constraints(self._h, *[v.ctypes.data_as(_dp) for v in a]),
+                    "set_bound_constraints")
+
+    def set_cone_constraints(self, Acx, qcx, cx, Acu, qcu, cu):
+        """STATE triple first (the positional order of the reference's definition, tiny_api.cpp:176-178)."""
+        ia = [np.ascontiguousarray(np.asarray(v, dtype=np.int32).ravel()) for v in (Acx, qcx, Acu, qcu)]
+        da = [_f64(v).ravel() for v in (cx, cu)]
+        self._check(lib().tiny_batch_set_cone_constraints(
+            self._h, len(ia[0]), ia[0].ctypes.data_as(_ip), ia[1].ctypes.data_as(_ip), da[0].ctypes.data_as(_dp),
+            len(ia[2]), ia[2].ctypes.data_as(_ip), ia[3].ctypes.data_as(_ip), da[1].ctypes.data_as(_dp)),
+            "set_cone_constraints")
+
+    def update_settings(self, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=1000, check_termination=1,
+                        en_state_bound=1, en_input_bound=1, en_state_soc=0, en_input_soc=0, en_state_linear=0,
+                        en_input_linear=0, en_tv_state_linear=0, en_tv_input_linear=0):
+        self._check(lib().tiny_batch_update_settings(
+            self._h, abs_pri_tol, abs_dua_tol, int(max_iter), int(check_termination), int(en_state_bound),
+            int(en_input_bound), int(en_state_soc), int(en_input_soc), int(en_state_linear), int(en_input_linear),
+            int(en_tv_state_linear), int(en_tv_input_linear)), "update_settings")
+
+    def cache(self, name):
+        shapes = {"Kinf": (self.nu, self.nx), "Pinf": (self.nx, self.nx), "Quu_inv": (self.nu, self.nu),
+                  "AmBKt": (self.nx, self.nx), "APf": (self.nx, 1), "BPf": (self.nu, 1), "Q": (self.nx, 1),
+                  "R": (self.nu, 1)}
+        r, c = shapes[name]
+        out = np.zeros(r * c)
+        n = lib().tiny_batch_get_cache(self._h, name.encode(), out.ctypes.data_as(_dp), r * c)
+        assert n == r * c
+        return out.reshape((r, c), order="F")
+
+    # ---- per-instance data
+    def _shape(self, name):
+        if name == "x0":
+            return (self.nx, 1)
+        return (self.nx, self.N) if name in STATE_FIELDS else (self.nu, self.N - 1)
+
+    def set(self, name, value, broadcast=False):
+        """value: [batch, rows, cols] (or [rows, cols] with broadcast=True); x0: [batch, nx]."""
+        r, c = self._shape(name)
+        a = np.asarray(value, dtype=np.float64)
+        if broadcast:
+            flat = np.ascontiguousarray(a.reshape(r, c).T).ravel()
+        else:
+            flat = np.ascontiguousarray(a.reshape(self.batch, r, c).transpose(0, 2, 1)).ravel()
+        self._check(lib().tiny_batch_set(self._h, FIELD_ID[name], flat.ctypes.data_as(C.c_void_p),
+                                         HOST | (BROADCAST if broadcast else 0)), f"set({name})")
+
+    def get(self, name):
+        r, c = self._shape(name)
+        out = np.zeros((self.batch, c, r))
+        self._check(lib().tiny_batch_get(self._h, FIELD_ID[name], out.ctypes.data_as(C.c_void_p), HOST), f"get({name})")
+        out = out.transpose(0, 2, 1)
+        return out[:, :, 0] if name == "x0" else out
+
+    def set_device(self, name, ptr, broadcast=False):
+        """ptr: device pointer (int) to [batch][cols][rows] doubles already resident in HBM."""
+        self._check(lib().tiny_batch_set(self._h, FIELD_ID[name], C.c_void_p(ptr),
+                                         DEVICE | (BROADCAST if broadcast else 0)), f"set_device({name})")
+
+    def set_x0(self, x0, broadcast=False):          # tiny_set_x0
+        self.set("x0", x0, broadcast)
+
+    def set_x_ref(self, x_ref, broadcast=False):    # tiny_set_x_ref
+        self.set("Xref", x_ref, broadcast)
+
+    def set_u_ref(self, u_ref, broadcast=False):    # tiny_set_u_ref
+        self.set("Uref", u_ref, broadcast)
+
+    def reset(self):
+        self._check(lib().tiny_batch_reset(self._h), "reset")
+
+    # ---- hot path
+    def solve(self) -> int:
+        rc = lib().tiny_batch_solve(self._h)
+        if rc not in (0, 1):
+            self._check(rc, "solve")
+        return rc
+
+    def solve_async(self):
+        self._check(lib().tiny_batch_solve_async(self._h), "solve_async")
+
+    def synchronize(self):
+        self._check(lib().tiny_batch_synchronize(self._h), "synchronize")
+
+    def status(self):
+        B = self.batch
+        it, so, st = (np.zeros(B, dtype=np.int32) for _ in range(3))
+        res = np.zeros((B, 4))
+        self._check(lib().tiny_batch_get_status(self._h, it.ctypes.data_as(_ip), so.ctypes.data_as(_ip),
+                                                st.ctypes.data_as(_ip), res.ctypes.data_as(_dp)), "get_status")
+        return dict(iter=it, solved=so, status=st, primal_residual_state=res[:, 0], primal_residual_input=res[:, 1],
+                    dual_residual_state=res[:, 2], dual_residual_input=res[:, 3])
+
+    def reduce_stats(self, device_out=None):
+        """[sum_iter, sum_solved, batch, max residual x4, accumulated iters, accumulated solved, 0];
+        device_out: optional device pointer (int) receiving the same 10 doubles (e.g. the buffer of an
+        RCCL all-reduce)."""
+        out = np.zeros(10)
+        self._check(lib().tiny_batch_reduce_stats(self._h, out.ctypes.data_as(_dp),
+                                                  C.c_void_p(device_out) if device_out else None), "reduce_stats")
+        return out
+
+    def reduce_stats_async(self, device_out):
+        self._check(lib().tiny_batch_reduce_stats(self._h, None, C.c_void_p(device_out)), "reduce_stats")
+
+    def set_option(self, name, value):
+        self._check(lib().tiny_batch_set_option(self._h, name.encode(), int(value)), f"set_option({name})")
+
+    def set_stream(self, stream_ptr):
+        self._check(lib().tiny_batch_set_stream(self._h, C.c_void_p(stream_ptr)), "set_stream")
+
+    def timing_ms(self, capacity=4096):
+        buf = np.zeros(capacity, dtype=np.float32)
+        n = lib().tiny_batch_get_timing(self._h, buf.ctypes.data_as(_fp), capacity)
+        return buf[:max(n, 0)].astype(np.float64)
+
+    def algorithmic_bytes(self, cold=False) -> int:
+        return int(lib().tiny_batch_algorithmic_bytes(self._h, 1 if cold else 0))
+
+
+def load_problem(name):
+    """Problem families of the reference examples (numbers extracted by oracle/extract_problem_data.py)."""
+    import json
+    p = json.load(open(os.path.join(_HERE, "data", "problems.json")))[name]
+    prob = dict(nx=p["nx"], nu=p["nu"], N=p["N"], rho=float(p["rho"]), A=np.array(p["A"], dtype=np.float64),
+                B=np.array(p["B"], dtype=np.float64), f=np.array(p["f"], dtype=np.float64),
+                Q=np.array(p["Q"], dtype=np.float64), R=np.array(p["R"], dtype=np.float64))
+    extra = {k: v for k, v in p.items() if k not in prob and k != "source"}
+    return prob, extra

@@ -1,0 +1,390 @@
+// admm_kernel.hip.h -- the MI355X (gfx950 / CDNA4) ADMM solve kernel.
+//
+// What it computes: one tiny_solve() (reference src/tinympc/admm.cpp:331-455) for each of
+// `batch` independent MPC QPs that share one TinyCache (Kinf, Pinf, Quu_inv, AmBKt, APf, BPf)
+// and one set of bounds / cones / settings.  Per ADMM iteration, in the reference's order:
+//   update_linear_cost (admm.cpp:262-297) -> backward_pass_grad (:13-20) -> forward_pass (:25-32)
+//   -> update_slack (:81-135, box + second-order cone) -> update_dual (:219-235)
+//   -> termination_condition (:310-328) -> v = vnew, z = znew (:445-446).
+//
+// Mapping (designed for CDNA4, not translated from anything):
+//   * A 16-lane DPP row of a wave64 owns ONE problem instance; a wavefront carries 4.
+//     Lane j of the row owns ROW j of the stacked knot vector [x_i ; u_i] (j < nx: state row j,
+//     nx <= j < nx+nu: input row j-nx) for EVERY knot point i.  All per-element ADMM state
+//     (x/u, vnew/znew, v/z, g/y, the reference-cost term) therefore lives in that lane's
+//     registers as N-long arrays, and every element-wise phase (linear cost, slack projection,
+//     dual update, residuals) is lane-local: no LDS, no shuffles.
+//   * The Riccati sweeps need y = M * w with M a shared <=16x16 matrix and w spread one entry
+//     per lane.  Lane j keeps row j of M in registers and the row-broadcast of w_k comes for free
+//     from the DPP `row_newbcast:k` modifier folded into the FMA:
+//         v_fmac_f64_dpp acc, w, M[j][k] row_newbcast:k       (gfx90a+ "DP-ALU DPP")
+//     i.e. one FP64 FMA issue slot per matrix column, no LDS traffic, no cross-lane reduction.
+//     (A broadcast-through-LDS formulation is LDS-bandwidth bound at 2x the FMA time on CDNA4:
+//     8 B of LDS read per FMA vs 256 B/clk/CU LDS and 64 FP64 FMA/clk/CU.)
+//   * No MFMA: FP64 MFMA on MI355X runs at the vector FP64 rate and the path is bounded by HBM
+//     (few-iteration warm solves) or FP64 VALU issue (cold solves), never by matrix throughput.
+//   * HBM layout = "knot-point interleaved" records, [instance][knot i][row j] with row stride
+//     nx+nu, so a DPP row reads/writes one contiguous (nx+nu)*8-byte segment per knot point
+//     (128 B for the quadrotor) and consecutive instances are contiguous: every byte of every
+//     touched cache line is used.
+//   * One workgroup = one wavefront (no __syncthreads anywhere); waves are persistent and walk
+//     tiles of 4 instances with a grid stride, so the per-wave table prologue amortises.
+//     Groups that converge early are masked off by EXEC (per-row exit), the wave leaves the
+//     iteration loop when its last row has converged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tinympc_amd {
+
+// ---- table layout shared with the host (batch_api.cpp builds it) --------------------------
+// All lane tables are [column k][lane j] with 16 lanes, doubles.
+enum : int {
+    TAB_MB = 0,          // backward:  cols k<nx multiply p_{i+1}[k], cols nx.. multiply r_i[k-nx]
+    TAB_MF1 = 256,       // forward 1: cols k<nx multiply x_i[k]   (state lanes: A, input lanes: -Kinf)
+    TAB_MF2 = 512,       // forward 2: cols nx.. multiply u_i[k-nx] (state lanes: B)
+    TAB_PT = 768,        // terminal:  cols k<nx multiply Xref[k, N-1] (state lanes: Pinf[k][j])
+    TAB_VEC = 1024,      // 16-entry lane vectors, see VEC_* below
+    TAB_BOUNDS = 1024 + 16 * 16,
+};
+enum : int {
+    VEC_CB = 0,          // backward constant: APf (state lanes), Quu_inv*BPf (input lanes)
+    VEC_CF = 1,          // forward constant: fdyn (state lanes)
+    VEC_QR = 2,          // work->Q / work->R (user diagonal + rho)
+    VEC_SMASK = 3,       // 1.0 on state lanes else 0
+    VEC_NIM = 4,         // -1.0 on input lanes else 0
+    VEC_SOCFLAG = 5,     // 1.0 when this lane's cone slack is enabled (admm.cpp:102-109)
+    VEC_CONE_BASE = 6,   // first lane of the cone this lane belongs to, or -1
+    VEC_CONE_MU = 7,     // cone coefficient (double; truncated to float as admm.cpp:39 does)
+    VEC_COUNT = 16,
+};
+static inline int tab_doubles(int N) { return TAB_BOUNDS + 2 * N * 16; }
+
+struct SolveArgs {
+    const double* tab;        // tab_doubles(N) doubles
+    const double* x0;         // [batch][nx]
+    const double* ref;        // KPI: Xref/Uref
+    double* prim;             // KPI: x/u        (out; also in when a cone is enabled, admm.cpp:352-357)
+    double* slack;            // KPI: vnew/znew  (in/out)
+    double* dual;             // KPI: g/y        (in/out)
+    double* slack_prev;       // KPI: v/z        (in/out)
+    double* cslack;           // KPI: vcnew/zcnew (out, SOC only)
+    double* cdual;            // KPI: gc/yc      (in/out, SOC only)
+    int4* status;             // [batch] {iter, solved, status (1 | 11), checked}
+    double* resid;            // [batch][4] {pri_state, pri_input, dua_state, dua_input}
+    double* x0_next;          // optional [batch][nx]: plant step x1 = A x0 + B u0 + f (may alias x0)
+    double* dbg_qr;           // optional KPI: q/r of the last iteration (work->q, work->r)
+    double* dbg_pd;           // optional KPI: p/d of the last iteration (work->p, work->d)
+    uint2* accum;             // optional [batch] {iterations, solves converged} accumulated over successive solves
+    double rho, tol_pri, tol_dua;
+    int batch, max_iter, check_termination;
+};
+
+// ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
+// One asm statement per block so that the two wait states a DPP read needs after a VALU write of
+// its source (CDNA ISA "VALU writes VGPR -> DPP reads that VGPR") are paid once (the leading
+// s_nop 1), and no compiler-inserted copy can land between the FMAs.  The accumulators are
+// EARLY-CLOBBER ("+&v"): they are written while src / m[] are still being read, so they must never
+// share a register with an input (without it hipcc happily aliases b0 with src when b0 == src).
+#define TF_(acc, mi, k) "v_fmac_f64_dpp %" #acc ", %2, %" #mi " row_newbcast:%3+" #k " row_mask:0xf bank_mask:0xf\n\t"
+#define TB1 TF_(0, 4, 0)
+#define TB2 TB1 TF_(1, 5, 1)
+#define TB3 TB2 TF_(0, 6, 2)
+#define TB4 TB3 TF_(1, 7, 3)
+#define TB5 TB4 TF_(0, 8, 4)
+#define TB6 TB5 TF_(1, 9, 5)
+#define TB7 TB6 TF_(0, 10, 6)
+#define TB8 TB7 TF_(1, 11, 7)
+#define TB9 TB8 TF_(0, 12, 8)
+#define TB10 TB9 TF_(1, 13, 9)
+#define TB11 TB10 TF_(0, 14, 10)
+#define TB12 TB11 TF_(1, 15, 11)
+#define TB13 TB12 TF_(0, 16, 12)
+#define TB14 TB13 TF_(1, 17, 13)
+#define TB15 TB14 TF_(0, 18, 14)
+#define TB16 TB15 TF_(1, 19, 15)
+#define TM1 "v"(m[0])
+#define TM2 TM1, "v"(m[1])
+#define TM3 TM2, "v"(m[2])
+#define TM4 TM3, "v"(m[3])
+#define TM5 TM4, "v"(m[4])
+#define TM6 TM5, "v"(m[5])
+#define TM7 TM6, "v"(m[6])
+#define TM8 TM7, "v"(m[7])
+#define TM9 TM8, "v"(m[8])
+#define TM10 TM9, "v"(m[9])
+#define TM11 TM10, "v"(m[10])
+#define TM12 TM11, "v"(m[11])
+#define TM13 TM12, "v"(m[12])
+#define TM14 TM13, "v"(m[13])
+#define TM15 TM14, "v"(m[14])
+#define TM16 TM15, "v"(m[15])
+#define RING_CASE(K)                                                                        \
+    if constexpr (NCOL == K) {                                                              \
+        asm("s_nop 1\n\t" TB##K : "+&v"(a0), "+&v"(a1) : "v"(src), "i"(COL0), TM##K);        \
+    }
+
+template <int C>
+__device__ __forceinline__ double row_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + C, 0xf, 0xf, false);   // DPP_ROW_NEWBCAST0 + C
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int COL0, int NCOL, int K>
+struct RingB {
+    static __device__ __forceinline__ void run(double& a0, double& a1, double src, const double* m) {
+        if constexpr (K < NCOL) {
+            if constexpr ((K & 1) == 0) a0 = fma(row_bcast<COL0 + K>(src), m[K], a0);
+            else a1 = fma(row_bcast<COL0 + K>(src), m[K], a1);
+            RingB<COL0, NCOL, K + 1>::run(a0, a1, src, m);
+        }
+    }
+};
+
+// acc{0,1} += sum_{k<NCOL} bcast(src, lane COL0+k) * m[k]   (even k -> a0, odd k -> a1)
+// MODE 0: fused v_fmac_f64_dpp (1 issue slot / column); MODE 1: v_mov_b32_dpp x2 + v_fma_f64.
+template <int MODE, int COL0, int NCOL>
+__device__ __forceinline__ void ring(double& a0, double& a1, double src, const double* m) {
+    static_assert(NCOL >= 1 && NCOL <= 16 && COL0 + NCOL <= 16, "one DPP row");
+    if constexpr (MODE == 0) {
+        RING_CASE(1) RING_CASE(2) RING_CASE(3) RING_CASE(4) RING_CASE(5) RING_CASE(6) RING_CASE(7) RING_CASE(8)
+        RING_CASE(9) RING_CASE(10) RING_CASE(11) RING_CASE(12) RING_CASE(13) RING_CASE(14) RING_CASE(15) RING_CASE(16)
+    } else {
+        RingB<COL0, NCOL, 0>::run(a0, a1, src, m);
+    }
+}
+
+__device__ __forceinline__ double grp_max16(double v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 16));
+    return v;
+}
+
+// project_soc (admm.cpp:39-60) for one component of a 3-cone; s0,s1,s2 = the cone's vector,
+// c = which component this lane owns.  mu and the norm are float, a/mu is a float division.
+__device__ __forceinline__ double soc_component(double s0, double s1, double s2, int c, double mu_d) {
+    const float mu = (float)mu_d;
+    const double u0 = s2 * (double)mu;                                  // :40
+    const float a = (float)sqrt(__dadd_rn(__dmul_rn(s0, s0), __dmul_rn(s1, s1)));   // :42
+    const double mine = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
+    if ((double)a <= -u0) return 0.0;                                   // :46
+    if ((double)a <= u0) return mine;                                   // :49
+    if ((double)a >= fabs(u0)) {                                        // :52
+        const double scale = 0.5 * (1.0 + u0 / (double)a);
+        const double last = (double)(a / mu);
+        return scale * ((c == 2) ? last : mine);
+    }
+    return 0.0;
+}
+
+// ---- the kernel -------------------------------------------------------------------------------
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE>
+__global__ __launch_bounds__(64) void admm_solve_kernel(const SolveArgs P) {
+    constexpr int NZ = NX + NU;
+    static_assert(NZ <= 16, "one instance per 16-lane DPP row");
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int grp = lane >> 4;
+    const bool is_state = j < NX;
+    const bool is_input = (j >= NX) && (j < NZ);
+    const bool used = j < NZ;
+
+    // per-wave LDS copies of the tables that are read with a dynamic index or only once per solve
+    __shared__ double sPt[NX * 16];
+    __shared__ double sLo[N * 16];
+    __shared__ double sHi[N * 16];
+    for (int e = lane; e < NX * 16; e += 64) sPt[e] = P.tab[TAB_PT + e];
+    for (int e = lane; e < N * 16; e += 64) {
+        sLo[e] = P.tab[TAB_BOUNDS + e];
+        sHi[e] = P.tab[TAB_BOUNDS + N * 16 + e];
+    }
+    // this lane's matrix rows
+    double mb[NZ], mf1[NX], mf2[NU];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) mb[k] = P.tab[TAB_MB + k * 16 + j];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) mf1[k] = P.tab[TAB_MF1 + k * 16 + j];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) mf2[k] = P.tab[TAB_MF2 + (NX + k) * 16 + j];
+    const double cb = P.tab[TAB_VEC + VEC_CB * 16 + j];
+    const double cf = P.tab[TAB_VEC + VEC_CF * 16 + j];
+    const double qr = P.tab[TAB_VEC + VEC_QR * 16 + j];
+    const double smask = P.tab[TAB_VEC + VEC_SMASK * 16 + j];
+    const double nim = P.tab[TAB_VEC + VEC_NIM * 16 + j];
+    bool soc_lane = false;
+    int cone_base = -1, cone_c = 0;
+    double cone_mu = 0.0;
+    if constexpr (SOC) {
+        soc_lane = P.tab[TAB_VEC + VEC_SOCFLAG * 16 + j] != 0.0;
+        cone_base = (int)P.tab[TAB_VEC + VEC_CONE_BASE * 16 + j];
+        cone_mu = P.tab[TAB_VEC + VEC_CONE_MU * 16 + j];
+        cone_c = (cone_base >= 0) ? (j - cone_base) : 0;
+    }
+    const double rho = P.rho;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
+
+    const int ntiles = (P.batch + 3) >> 2;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile * 4 + grp;
+        if (b < P.batch) {
+            const size_t rec = (size_t)b * (N * NZ);
+            double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
+            double VC[SOC ? N : 1], GC[SOC ? N : 1];
+            double Qd[DBG ? N : 1], Pd[DBG ? N : 1];
+            double ref_last = 0.0, qx_last_plain = 0.0;
+            // ---- load the instance record (coalesced: one contiguous NZ*8-byte segment per knot)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool valid = used && (is_state || i < N - 1);
+                const size_t off = rec + i * NZ + j;
+                const double r = valid ? P.ref[off] : 0.0;
+                VN[i] = valid ? P.slack[off] : 0.0;
+                G[i] = valid ? P.dual[off] : 0.0;
+                VP[i] = valid ? P.slack_prev[off] : 0.0;
+                QX[i] = -(r * qr);                           // admm.cpp:266 / :279
+                X[i] = 0.0;
+                if (i == N - 1) ref_last = r;
+                if constexpr (SOC) {
+                    VC[i] = (valid && soc_lane) ? P.prim[off] : 0.0;        // admm.cpp:352-357
+                    GC[i] = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                }
+            }
+            const double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;     // tiny_set_x0
+            X[0] = x0v;
+            if constexpr (SOC) { if (is_state && soc_lane) VC[0] = x0v; }
+            {   // terminal cost  -(Xref[:,N-1]^T Pinf)   (admm.cpp:292)
+                double pt[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) pt[k] = sPt[k * 16 + j];
+                double a0 = 0.0, a1 = 0.0;
+                ring<MODE, 0, NX>(a0, a1, ref_last, pt);
+                qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
+                QX[N - 1] = is_state ? -(a0 + a1) : QX[N - 1];
+            }
+
+            int iter = 0, solved = 0, checked = 0;
+            int countdown = P.check_termination;
+            double rp = 0.0, rd = 0.0;
+            for (int it = 0; it < P.max_iter; ++it) {
+                // ---- update_linear_cost (lane-local) fused into the backward sweep
+                double pcur;
+                {
+                    double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293
+                    if constexpr (SOC) t = fma(-rho, VC[N - 1] - GC[N - 1], t); // :295
+                    pcur = t;
+                    if constexpr (DBG) {
+                        double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
+                        if constexpr (SOC) ql = fma(-rho, VC[N - 1] - GC[N - 1], ql);
+                        Qd[N - 1] = ql;
+                        Pd[N - 1] = t;
+                    }
+                }
+                // ---- backward_pass_grad, admm.cpp:13-20
+#pragma unroll
+                for (int i = N - 2; i >= 0; --i) {
+                    double qi = fma(-rho, VN[i] - G[i], QX[i]);                 // :267 / :280
+                    if constexpr (SOC) qi = fma(-rho, VC[i] - GC[i], qi);       // :269 / :282
+                    double a0 = 0.0, a1 = 0.0;
+                    ring<MODE, 0, NX>(a0, a1, pcur, mb);                        // AmBKt p | (Quu_inv B') p
+                    ring<MODE, NX, NU>(a0, a1, qi, mb + NX);                    // -Kinf' r | Quu_inv r
+                    double res = (a0 + a1) + cb;
+                    res = fma(qi, smask, res);                                  // + q_i on state lanes
+                    pcur = res;                                                 // p_i | d_i
+                    Dn[i] = res * nim;                                          // -d_i on input lanes, 0 elsewhere
+                    if constexpr (DBG) { Qd[i] = qi; Pd[i] = res; }
+                }
+                // ---- forward_pass, admm.cpp:25-32
+#pragma unroll
+                for (int i = 0; i < N - 1; ++i) {
+                    double a0 = Dn[i], a1 = 0.0;
+                    ring<MODE, 0, NX>(a0, a1, X[i], mf1);                       // A x_i | -Kinf x_i - d_i
+                    const double t = a0 + a1;
+                    X[i] = is_input ? t : X[i];                                 // u_i
+                    double b0 = t, b1 = 0.0;
+                    ring<MODE, NX, NU>(b0, b1, t, mf2);                         // + B u_i
+                    const double xn = (b0 + b1) + cf;                           // + f
+                    X[i + 1] = (i == N - 2 && !is_state) ? 0.0 : xn;            // x_{i+1} (input lanes: rewritten next step)
+                }
+                // ---- update_slack + update_dual + residuals (lane-local), admm.cpp:81-135, 219-235, 314-317
+                double pmax = 0.0, dmax = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double xi = X[i];
+                    const double t = xi + G[i];                                 // :85 / :88
+                    const double vn = fmin(sHi[i * 16 + j], fmax(sLo[i * 16 + j], t));   // :91-98
+                    pmax = fmax(pmax, fabs(xi - vn));
+                    dmax = fmax(dmax, fabs(VP[i] - vn));
+                    G[i] = (G[i] + xi) - vn;                                    // :222 / :225
+                    VN[i] = vn;
+                    if constexpr (SOC) {
+                        double vc = soc_lane ? (xi + GC[i]) : 0.0;              // :102-109
+                        const int base = (cone_base >= 0) ? cone_base : j;
+                        const double s0 = __shfl(vc, base, 16);
+                        const double s1 = __shfl(vc, base + 1, 16);
+                        const double s2 = __shfl(vc, base + 2, 16);
+                        const bool knot_ok = is_state || (i < N - 1);
+                        if (cone_base >= 0 && soc_lane && knot_ok) vc = soc_component(s0, s1, s2, cone_c, cone_mu);
+                        GC[i] = soc_lane ? ((GC[i] + xi) - vc) : 0.0;           // :229 / :234
+                        VC[i] = vc;
+                    }
+                }
+                iter += 1;                                                      // :394
+                // ---- termination_condition, admm.cpp:310-328
+                bool conv = false;
+                if (countdown > 0 && --countdown == 0) {
+                    countdown = P.check_termination;
+                    checked = 1;
+                    rp = pmax;
+                    rd = dmax * rho;
+                    const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
+                    const unsigned long long bal = __ballot(ok);
+                    conv = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
+                }
+                if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)
+#pragma unroll
+                for (int i = 0; i < N; ++i) VP[i] = VN[i];                      // :445-446
+            }
+
+            // ---- write back (coalesced) -------------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool valid = used && (is_state || i < N - 1);
+                const size_t off = rec + i * NZ + j;
+                if (valid) {
+                    P.prim[off] = X[i];
+                    P.slack[off] = VN[i];
+                    P.dual[off] = G[i];
+                    P.slack_prev[off] = VP[i];
+                    if constexpr (SOC) {
+                        P.cslack[off] = VC[i];
+                        P.cdual[off] = GC[i];
+                    }
+                    if constexpr (DBG) {
+                        if (P.dbg_qr) {
+                            P.dbg_qr[off] = Qd[i];     // work->q | work->r
+                            P.dbg_pd[off] = Pd[i];     // work->p | work->d
+                        }
+                    }
+                }
+            }
+            if (P.x0_next && is_state) P.x0_next[(size_t)b * NX + j] = X[1];     // x1 = A x0 + B u0 + f
+            const double ps = grp_max16(is_state ? rp : 0.0), pi = grp_max16(is_input ? rp : 0.0);
+            const double ds = grp_max16(is_state ? rd : 0.0), di = grp_max16(is_input ? rd : 0.0);
+            if (j == 0) {
+                P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
+                double4 rr = make_double4(ps, pi, ds, di);
+                *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = rr;
+                if (P.accum) {
+                    uint2 ac = P.accum[b];
+                    ac.x += (unsigned)iter;
+                    ac.y += (unsigned)solved;
+                    P.accum[b] = ac;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace tinympc_amd

@@ -1,0 +1,597 @@
+// batch_api.hip -- host side of the batched, device-resident C ABI (include/tinympc_amd.h, part A).
+//
+// Mirrors the reference operator interface for the hot path (src/tinympc/tiny_api.cpp:21-147
+// setup, :149-208 constraint setters, :388-411 settings, :443-477 x0/xref/uref, :384-386 solve)
+// with a leading batch axis; the ADMM iteration itself is admm_kernel.hip.h.  No CPU fallback.
+#include "batch_impl.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+namespace tinympc_amd {
+
+// ---- small device kernels (layout conversion, reductions) ------------------------------------
+// Reference layout  : state-sized  [batch][N][nx]     input-sized [batch][N-1][nu]   (column-major matrices)
+// Device KPI layout : [batch][N][nx+nu]  (knot-point interleaved, see admm_kernel.hip.h)
+__global__ void pack_kpi_kernel(double* __restrict__ kpi, const double* __restrict__ src, int batch, int N,
+                                int nz, int rows, int row_off, int cols, int broadcast) {
+    const size_t total = (size_t)batch * cols * rows;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % rows);
+        const int i = (int)((e / rows) % cols);
+        const size_t b = e / ((size_t)rows * cols);
+        const size_t s = broadcast ? ((size_t)i * rows + r) : e;
+        kpi[(b * N + i) * nz + row_off + r] = src[s];
+    }
+}
+__global__ void unpack_kpi_kernel(const double* __restrict__ kpi, double* __restrict__ dst, int batch, int N,
+                                  int nz, int rows, int row_off, int cols) {
+    const size_t total = (size_t)batch * cols * rows;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % rows);
+        const int i = (int)((e / rows) % cols);
+        const size_t b = e / ((size_t)rows * cols);
+        dst[e] = kpi[(b * N + i) * nz + row_off + r];
+    }
+}
+__global__ void broadcast_rows_kernel(double* __restrict__ dst, const double* __restrict__ src, int batch, int n) {
+    const size_t total = (size_t)batch * n;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+        dst[e] = src[e % n];
+}
+// out[10] = {sum iter, sum solved, batch, max pri_s, max pri_i, max dua_s, max dua_i,
+//            accumulated iterations, accumulated converged solves, 0}; out must be zeroed before the launch
+// (non-negative doubles order like their bit patterns, so the maxima use integer atomicMax).
+__global__ __launch_bounds__(256) void reduce_stats_kernel(const int4* __restrict__ status,
+                                                           const double* __restrict__ resid,
+                                                           const uint2* __restrict__ accum, int batch,
+                                                           double* __restrict__ out) {
+    double si = 0, ss = 0, ai = 0, as = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += gridDim.x * blockDim.x) {
+        const int4 st = status[b];
+        si += st.x;
+        ss += st.y;
+        const uint2 ac = accum[b];
+        ai += ac.x;
+        as += ac.y;
+        const double4 r = *reinterpret_cast<const double4*>(resid + (size_t)b * 4);
+        m0 = fmax(m0, r.x); m1 = fmax(m1, r.y); m2 = fmax(m2, r.z); m3 = fmax(m3, r.w);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        si += __shfl_xor(si, off); ss += __shfl_xor(ss, off);
+        ai += __shfl_xor(ai, off); as += __shfl_xor(as, off);
+        m0 = fmax(m0, __shfl_xor(m0, off)); m1 = fmax(m1, __shfl_xor(m1, off));
+        m2 = fmax(m2, __shfl_xor(m2, off)); m3 = fmax(m3, __shfl_xor(m3, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 0, si); atomicAdd(out + 1, ss); atomicAdd(out + 7, ai); atomicAdd(out + 8, as);
+        unsigned long long* mo = reinterpret_cast<unsigned long long*>(out);
+        atomicMax(mo + 3, (unsigned long long)__double_as_longlong(m0));
+        atomicMax(mo + 4, (unsigned long long)__double_as_longlong(m1));
+        atomicMax(mo + 5, (unsigned long long)__double_as_longlong(m2));
+        atomicMax(mo + 6, (unsigned long long)__double_as_longlong(m3));
+        if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = (double)batch;
+    }
+}
+
+// ---- kernel registry: (nx, nu, N) instantiations ---------------------------------------------
+typedef void (*SolveKernel)(const SolveArgs);
+struct KernelEntry {
+    int nx, nu, N;
+    SolveKernel k[2][2][2];   // [soc][dbg][dpp_mode]
+};
+#define KERNELS_FOR(NX, NU, NN)                                                                   \
+    { NX, NU, NN, { { { admm_solve_kernel<NX, NU, NN, false, false, 0>,                           \
+                        admm_solve_kernel<NX, NU, NN, false, false, 1> },                         \
+                      { admm_solve_kernel<NX, NU, NN, false, true, 0>,                            \
+                        admm_solve_kernel<NX, NU, NN, false, true, 1> } },                        \
+                    { { admm_solve_kernel<NX, NU, NN, true, false, 0>,                            \
+                        admm_solve_kernel<NX, NU, NN, true, false, 1> },                          \
+                      { admm_solve_kernel<NX, NU, NN, true, true, 0>,                             \
+                        admm_solve_kernel<NX, NU, NN, true, true, 1> } } } }
+static const KernelEntry g_kernels[] = {
+#include "kernel_dims.inc"
+};
+static const int g_nkernels = (int)(sizeof(g_kernels) / sizeof(g_kernels[0]));
+
+static const KernelEntry* find_kernel(int nx, int nu, int N) {
+    for (int i = 0; i < g_nkernels; ++i)
+        if (g_kernels[i].nx == nx && g_kernels[i].nu == nu && g_kernels[i].N == N) return &g_kernels[i];
+    return nullptr;
+}
+
+int fail(TinyBatch* b, int code, const char* fmt, ...) {
+    if (b) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(b->err, sizeof(b->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+#define HIP_TRY(b, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(b, TINY_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Lane tables for the kernel (layout in admm_kernel.hip.h).  Rebuilt whenever cache, bounds, cones or
+// the enable switches change.
+static void build_tables(TinyBatch* b) {
+    const int nx = b->nx, nu = b->nu, N = b->N;
+    const Cache& c = b->cache;
+    std::vector<double>& t = b->h_tab;
+    t.assign(tab_doubles(N), 0.0);
+    // Quu_inv * B'  and  Quu_inv * BPf : the input rows of the fused backward step
+    //   d_i = Quu_inv (B' p_{i+1} + r_i + BPf)            (admm.cpp:17)
+    Mat QBt = c.Quu_inv * transpose(b->B);
+    Mat QBPf = c.Quu_inv * c.BPf;
+    for (int j = 0; j < nx; ++j) {                 // state lanes
+        for (int k = 0; k < nx; ++k) {
+            t[TAB_MB + k * 16 + j] = c.AmBKt(j, k);           // p_i += AmBKt p_{i+1}     (admm.cpp:18)
+            t[TAB_MF1 + k * 16 + j] = b->A(j, k);             // x_{i+1} = A x_i ...      (admm.cpp:30)
+            t[TAB_PT + k * 16 + j] = c.Pinf(k, j);            // (Xref' Pinf)[j]          (admm.cpp:292)
+        }
+        for (int m = 0; m < nu; ++m) {
+            t[TAB_MB + (nx + m) * 16 + j] = -c.Kinf(m, j);    // - Kinf' r_i
+            t[TAB_MF2 + (nx + m) * 16 + j] = b->B(j, m);      // + B u_i
+        }
+        t[TAB_VEC + VEC_CB * 16 + j] = c.APf(j, 0);
+        t[TAB_VEC + VEC_CF * 16 + j] = b->f(j, 0);
+        t[TAB_VEC + VEC_QR * 16 + j] = b->Qw[j];
+        t[TAB_VEC + VEC_SMASK * 16 + j] = 1.0;
+    }
+    for (int a = 0; a < nu; ++a) {                 // input lanes
+        const int j = nx + a;
+        for (int k = 0; k < nx; ++k) {
+            t[TAB_MB + k * 16 + j] = QBt(a, k);
+            t[TAB_MF1 + k * 16 + j] = -c.Kinf(a, k);          // u_i = -Kinf x_i - d_i     (admm.cpp:29)
+        }
+        for (int m = 0; m < nu; ++m) t[TAB_MB + (nx + m) * 16 + j] = c.Quu_inv(a, m);
+        t[TAB_VEC + VEC_CB * 16 + j] = QBPf(a, 0);
+        t[TAB_VEC + VEC_QR * 16 + j] = b->Rw[a];
+        t[TAB_VEC + VEC_NIM * 16 + j] = -1.0;
+    }
+    // cones (admm.cpp:102-135): lane flags
+    for (int j = 0; j < 16; ++j) t[TAB_VEC + VEC_CONE_BASE * 16 + j] = -1.0;
+    const bool s_on = b->set.en_state_soc && !b->Acx.empty();
+    const bool i_on = b->set.en_input_soc && !b->Acu.empty();
+    for (int j = 0; j < nx; ++j) t[TAB_VEC + VEC_SOCFLAG * 16 + j] = s_on ? 1.0 : 0.0;
+    for (int a = 0; a < nu; ++a) t[TAB_VEC + VEC_SOCFLAG * 16 + nx + a] = i_on ? 1.0 : 0.0;
+    if (b->set.en_state_soc)
+        for (size_t k = 0; k < b->Acx.size(); ++k)
+            for (int c3 = 0; c3 < 3; ++c3) {
+                t[TAB_VEC + VEC_CONE_BASE * 16 + b->Acx[k] + c3] = b->Acx[k];
+                t[TAB_VEC + VEC_CONE_MU * 16 + b->Acx[k] + c3] = b->cx[k];
+            }
+    if (b->set.en_input_soc)
+        for (size_t k = 0; k < b->Acu.size(); ++k)
+            for (int c3 = 0; c3 < 3; ++c3) {
+                t[TAB_VEC + VEC_CONE_BASE * 16 + nx + b->Acu[k] + c3] = nx + b->Acu[k];
+                t[TAB_VEC + VEC_CONE_MU * 16 + nx + b->Acu[k] + c3] = b->cu[k];
+            }
+    // bounds (admm.cpp:91-98): a disabled or never-set box is (-inf, +inf)
+    const double inf = std::numeric_limits<double>::infinity();
+    double* lo = &t[TAB_BOUNDS];
+    double* hi = &t[TAB_BOUNDS + N * 16];
+    for (int e = 0; e < N * 16; ++e) { lo[e] = -inf; hi[e] = inf; }
+    if (b->set.en_state_bound && b->have_bounds)
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < nx; ++j) {
+                lo[i * 16 + j] = b->x_min[(size_t)i * nx + j];
+                hi[i * 16 + j] = b->x_max[(size_t)i * nx + j];
+            }
+    if (b->set.en_input_bound && b->have_bounds)
+        for (int i = 0; i < N - 1; ++i)
+            for (int a = 0; a < nu; ++a) {
+                lo[i * 16 + nx + a] = b->u_min[(size_t)i * nu + a];
+                hi[i * 16 + nx + a] = b->u_max[(size_t)i * nu + a];
+            }
+}
+
+static int upload_tables(TinyBatch* b) {
+    if (!b->tab_dirty) return TINY_OK;
+    build_tables(b);
+    HIP_TRY(b, hipMemcpyAsync(b->d_tab, b->h_tab.data(), b->h_tab.size() * sizeof(double), hipMemcpyHostToDevice,
+                              b->stream));
+    // h_tab is pageable: the copy above is staged synchronously, so reusing h_tab later is safe
+    b->tab_dirty = false;
+    return TINY_OK;
+}
+
+static bool soc_active(const TinyBatch* b) {
+    return (b->set.en_state_soc && !b->Acx.empty()) || (b->set.en_input_soc && !b->Acu.empty());
+}
+
+int launch_solve(TinyBatch* b) {
+    if (int rc = upload_tables(b)) return rc;
+    const bool soc = soc_active(b);
+    SolveArgs a;
+    a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
+    a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
+    a.status = b->d_status; a.resid = b->d_resid;
+    a.x0_next = b->advance_x0 ? b->d_x0 : nullptr;
+    a.dbg_qr = b->debug ? b->d_dbg_qr : nullptr;
+    a.dbg_pd = b->debug ? b->d_dbg_pd : nullptr;
+    a.accum = b->d_accum;
+    a.rho = b->cache.rho; a.tol_pri = b->set.abs_pri_tol; a.tol_dua = b->set.abs_dua_tol;
+    a.batch = b->batch; a.max_iter = b->set.max_iter; a.check_termination = b->set.check_termination;
+    const int tiles = (b->batch + 3) / 4;
+    int grid = tiles;
+    if (b->grid_waves_per_cu > 0) {
+        const long cap = (long)b->num_cus * b->grid_waves_per_cu;
+        if (cap < grid) grid = (int)cap;
+    }
+    SolveKernel k = b->kernel->k[soc ? 1 : 0][b->debug ? 1 : 0][b->dpp_mode ? 1 : 0];
+    const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
+    if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, b->stream, a);
+    HIP_TRY(b, hipGetLastError());
+    if (timed) {
+        HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream));
+        b->timing_n++;
+        b->timing_left--;
+    }
+    return TINY_OK;
+}
+
+static int field_geometry(const TinyBatch* b, TinyField f, double** kpi, int* rows, int* row_off, int* cols) {
+    const int nx = b->nx, nu = b->nu, N = b->N;
+    const bool st = (f == TINY_F_XREF || f == TINY_F_X || f == TINY_F_VNEW || f == TINY_F_G || f == TINY_F_V ||
+                     f == TINY_F_VCNEW || f == TINY_F_GC || f == TINY_F_Q || f == TINY_F_P);
+    *rows = st ? nx : nu; *row_off = st ? 0 : nx; *cols = st ? N : N - 1;
+    switch (f) {
+        case TINY_F_XREF: case TINY_F_UREF: *kpi = b->d_ref; break;
+        case TINY_F_X: case TINY_F_U: *kpi = b->d_prim; break;
+        case TINY_F_VNEW: case TINY_F_ZNEW: *kpi = b->d_slack; break;
+        case TINY_F_G: case TINY_F_Y: *kpi = b->d_dual; break;
+        case TINY_F_V: case TINY_F_Z: *kpi = b->d_slack_prev; break;
+        case TINY_F_VCNEW: case TINY_F_ZCNEW: *kpi = b->d_cslack; break;
+        case TINY_F_GC: case TINY_F_YC: *kpi = b->d_cdual; break;
+        case TINY_F_Q: case TINY_F_R: *kpi = b->d_dbg_qr; break;
+        case TINY_F_P: case TINY_F_D: *kpi = b->d_dbg_pd; break;
+        default: return TINY_ERR_ARG;
+    }
+    return TINY_OK;
+}
+
+static int ensure_debug_buffers(TinyBatch* b) {
+    if (b->d_dbg_qr) return TINY_OK;
+    const size_t kpi_bytes = (size_t)b->batch * b->N * (b->nx + b->nu) * sizeof(double);
+    HIP_TRY(b, hipMalloc(&b->d_dbg_qr, kpi_bytes));
+    HIP_TRY(b, hipMalloc(&b->d_dbg_pd, kpi_bytes));
+    HIP_TRY(b, hipMemsetAsync(b->d_dbg_qr, 0, kpi_bytes, b->stream));
+    HIP_TRY(b, hipMemsetAsync(b->d_dbg_pd, 0, kpi_bytes, b->stream));
+    return TINY_OK;
+}
+
+}  // namespace tinympc_amd
+
+using namespace tinympc_amd;
+
+extern "C" {
+
+int tiny_batch_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tiny_batch_supported_dims(int* triples, int capacity) {
+    for (int i = 0; i < g_nkernels && i < capacity; ++i) {
+        triples[3 * i] = g_kernels[i].nx; triples[3 * i + 1] = g_kernels[i].nu; triples[3 * i + 2] = g_kernels[i].N;
+    }
+    return g_nkernels;
+}
+
+int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn,
+                     const double* Qdiag, const double* Rdiag, double rho, int nx, int nu, int N, int batch,
+                     int device, int verbose) {
+    if (!out || !Adyn || !Bdyn || !Qdiag || !Rdiag) return TINY_ERR_NULL;
+    *out = nullptr;
+    if (nx <= 0 || nu <= 0 || N < 2 || batch <= 0) return TINY_ERR_DIM;
+    const KernelEntry* ke = find_kernel(nx, nu, N);
+    if (!ke) {
+        if (verbose) fprintf(stderr, "tinympc_amd: no kernel instantiated for (nx,nu,N)=(%d,%d,%d)\n", nx, nu, N);
+        return TINY_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+        if (verbose) fprintf(stderr, "tinympc_amd: no usable HIP device (this library has no CPU path)\n");
+        return TINY_ERR_NO_DEVICE;
+    }
+    TinyBatch* b = new TinyBatch();
+    b->nx = nx; b->nu = nu; b->N = N; b->batch = batch; b->device = device; b->kernel = ke;
+    b->A = Mat(nx, nx, Adyn); b->B = Mat(nx, nu, Bdyn);
+    b->f = fdyn ? Mat(nx, 1, fdyn) : Mat(nx, 1);
+    b->Qw.assign(Qdiag, Qdiag + nx); b->Rw.assign(Rdiag, Rdiag + nu);
+    for (double& v : b->Qw) v += rho;                 // work->Q = diag(Q) + rho   (tiny_api.cpp:117)
+    for (double& v : b->Rw) v += rho;                 // work->R = diag(R) + rho   (tiny_api.cpp:118)
+    if (!precompute_cache(b->A, b->B, b->f, Mat::diag(b->Qw), Mat::diag(b->Rw), rho, &b->cache)) {   // tiny_api.cpp:136
+        delete b;
+        return TINY_ERR_ARG;
+    }
+    if (verbose && b->cache.riccati_converged) printf("Kinf converged after %d iterations\n", b->cache.riccati_iters);
+    // tiny_set_default_settings, tiny_api.cpp:413-441
+    b->set = Settings();
+    auto bail = [&](int code) { tiny_batch_destroy(b); return code; };
+    if (hipSetDevice(device) != hipSuccess) return bail(TINY_ERR_NO_DEVICE);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(TINY_ERR_HIP);
+    b->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return bail(TINY_ERR_HIP);
+    b->own_stream = true;
+    const int nz = nx + nu;
+    const size_t kpi_bytes = (size_t)batch * N * nz * sizeof(double);
+    double** kpis[] = {&b->d_ref, &b->d_prim, &b->d_slack, &b->d_dual, &b->d_slack_prev, &b->d_cslack, &b->d_cdual};
+    for (double** p : kpis) {
+        if (hipMalloc(p, kpi_bytes) != hipSuccess) return bail(TINY_ERR_HIP);
+        if (hipMemsetAsync(*p, 0, kpi_bytes, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    }
+    b->stage_doubles = (size_t)batch * nx * N;
+    if (hipMalloc(&b->d_x0, (size_t)batch * nx * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_x0, 0, (size_t)batch * nx * sizeof(double), b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_stage, b->stage_doubles * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_status, (size_t)batch * sizeof(int4)) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_status, 0, (size_t)batch * sizeof(int4), b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_resid, (size_t)batch * 4 * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_resid, 0, (size_t)batch * 4 * sizeof(double), b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_stats, 10 * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_accum, (size_t)batch * sizeof(uint2)) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_accum, 0, (size_t)batch * sizeof(uint2), b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_tab, tab_doubles(N) * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
+    b->tab_dirty = true;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    *out = b;
+    return TINY_OK;
+}
+
+int tiny_batch_destroy(TinyBatch* b) {
+    if (!b) return TINY_ERR_NULL;
+    hipSetDevice(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    void* bufs[] = {b->d_ref, b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual, b->d_x0,
+                    b->d_stage, b->d_status, b->d_resid, b->d_stats, b->d_tab, b->d_dbg_qr, b->d_dbg_pd, b->d_accum};
+    for (void* p : bufs)
+        if (p) hipFree(p);
+    for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_stop) hipEventDestroy(e);
+    if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+    delete b;
+    return TINY_OK;
+}
+
+const char* tiny_batch_last_error(TinyBatch* b) { return b ? b->err : "null batch"; }
+
+int tiny_batch_set_bound_constraints(TinyBatch* b, const double* x_min, const double* x_max, const double* u_min,
+                                     const double* u_max) {
+    if (!b) { printf("Error in tiny_set_bound_constraints: solver is nullptr\n"); return 1; }   // tiny_api.cpp:152-155
+    if (!x_min || !x_max || !u_min || !u_max) return fail(b, TINY_ERR_NULL, "null bound pointer");
+    const size_t ns = (size_t)b->nx * b->N, ni = (size_t)b->nu * (b->N - 1);
+    b->x_min.assign(x_min, x_min + ns); b->x_max.assign(x_max, x_max + ns);
+    b->u_min.assign(u_min, u_min + ni); b->u_max.assign(u_max, u_max + ni);
+    b->have_bounds = true;
+    b->tab_dirty = true;
+    return TINY_OK;
+}
+
+int tiny_batch_set_cone_constraints(TinyBatch* b, int nsc, const int* Acx, const int* qcx, const double* cx,
+                                    int nic, const int* Acu, const int* qcu, const double* cu) {
+    if (!b) { printf("Error in tiny_set_cone_constraints: solver is nullptr\n"); return 1; }     // tiny_api.cpp:179-182
+    if (nsc < 0 || nic < 0) return fail(b, TINY_ERR_DIM, "negative cone count");
+    std::vector<int> used(16, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int n = pass ? nic : nsc;
+        const int* A = pass ? Acu : Acx;
+        const int* q = pass ? qcu : qcx;
+        const int dim = pass ? b->nu : b->nx, off = pass ? b->nx : 0;
+        for (int k = 0; k < n; ++k) {
+            if (q[k] != 3) return fail(b, TINY_ERR_UNSUPPORTED, "cone dimension %d: the reference's project_soc only handles 3 (admm.cpp:53)", q[k]);
+            if (A[k] < 0 || A[k] + 3 > dim) return fail(b, TINY_ERR_DIM, "cone %d out of range", k);
+            for (int c3 = 0; c3 < 3; ++c3)
+                if (used[off + A[k] + c3]++) return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones");
+        }
+    }
+    b->Acx.assign(Acx, Acx + nsc); b->qcx.assign(qcx, qcx + nsc); b->cx.assign(cx, cx + nsc);
+    b->Acu.assign(Acu, Acu + nic); b->qcu.assign(qcu, qcu + nic); b->cu.assign(cu, cu + nic);
+    b->tab_dirty = true;
+    return TINY_OK;
+}
+
+int tiny_batch_update_settings(TinyBatch* b, double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                               int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
+                               int en_state_linear, int en_input_linear, int en_tv_state_linear,
+                               int en_tv_input_linear) {
+    if (!b) { printf("Error in tiny_update_settings: settings is nullptr\n"); return 1; }        // tiny_api.cpp:393-396
+    if (en_state_linear || en_input_linear || en_tv_state_linear || en_tv_input_linear)
+        return fail(b, TINY_ERR_UNSUPPORTED, "linear constraints are outside the accelerated hot path (SURVEY.md 8(f))");
+    b->set.abs_pri_tol = abs_pri_tol; b->set.abs_dua_tol = abs_dua_tol; b->set.max_iter = max_iter;
+    b->set.check_termination = check_termination; b->set.en_state_bound = en_state_bound;
+    b->set.en_input_bound = en_input_bound; b->set.en_state_soc = en_state_soc; b->set.en_input_soc = en_input_soc;
+    b->tab_dirty = true;
+    return TINY_OK;
+}
+
+int tiny_batch_get_cache(TinyBatch* b, const char* name, double* out, int capacity) {
+    if (!b || !name) return TINY_ERR_NULL;
+    const std::vector<double>* v = nullptr;
+    if (!strcmp(name, "Kinf")) v = &b->cache.Kinf.a;
+    else if (!strcmp(name, "Pinf")) v = &b->cache.Pinf.a;
+    else if (!strcmp(name, "Quu_inv")) v = &b->cache.Quu_inv.a;
+    else if (!strcmp(name, "AmBKt")) v = &b->cache.AmBKt.a;
+    else if (!strcmp(name, "APf")) v = &b->cache.APf.a;
+    else if (!strcmp(name, "BPf")) v = &b->cache.BPf.a;
+    else if (!strcmp(name, "Q")) v = &b->Qw;
+    else if (!strcmp(name, "R")) v = &b->Rw;
+    else return fail(b, TINY_ERR_ARG, "unknown cache member %s", name);
+    if (out && capacity >= (int)v->size()) memcpy(out, v->data(), v->size() * sizeof(double));
+    return (int)v->size();
+}
+
+int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags) {
+    if (!b || !src) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    const bool dev = flags & TINY_DEVICE, bc = flags & TINY_BROADCAST;
+    const int nx = b->nx;
+    if (field == TINY_F_X0) {
+        const size_t n = (size_t)(bc ? 1 : b->batch) * nx;
+        if (!bc) {
+            HIP_TRY(b, hipMemcpyAsync(b->d_x0, src, n * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->stream));
+        } else {
+            const double* s = src;
+            if (!dev) { HIP_TRY(b, hipMemcpyAsync(b->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream)); s = b->d_stage; }
+            hipLaunchKernelGGL(broadcast_rows_kernel, dim3(1024), dim3(256), 0, b->stream, b->d_x0, s, b->batch, nx);
+        }
+        if (!dev) HIP_TRY(b, hipStreamSynchronize(b->stream));
+        return TINY_OK;
+    }
+    if (field >= TINY_F_Q) return fail(b, TINY_ERR_ARG, "q/r/p/d are outputs");
+    double* kpi; int rows, row_off, cols;
+    if (field_geometry(b, field, &kpi, &rows, &row_off, &cols)) return fail(b, TINY_ERR_ARG, "bad field %d", (int)field);
+    const size_t n = (size_t)(bc ? 1 : b->batch) * rows * cols;
+    const double* s = src;
+    if (!dev) { HIP_TRY(b, hipMemcpyAsync(b->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream)); s = b->d_stage; }
+    hipLaunchKernelGGL(pack_kpi_kernel, dim3(2048), dim3(256), 0, b->stream, kpi, s, b->batch, b->N, b->nx + b->nu, rows,
+                       row_off, cols, bc ? 1 : 0);
+    HIP_TRY(b, hipGetLastError());
+    if (!dev) HIP_TRY(b, hipStreamSynchronize(b->stream));   // the staging buffer is reused by the next call
+    return TINY_OK;
+}
+
+int tiny_batch_get(TinyBatch* b, TinyField field, double* dst, int flags) {
+    if (!b || !dst) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    const bool dev = flags & TINY_DEVICE;
+    if (field == TINY_F_X0) {
+        HIP_TRY(b, hipMemcpyAsync(dst, b->d_x0, (size_t)b->batch * b->nx * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, b->stream));
+        if (!dev) HIP_TRY(b, hipStreamSynchronize(b->stream));
+        return TINY_OK;
+    }
+    if (field >= TINY_F_Q && !b->debug) return fail(b, TINY_ERR_ARG, "q/r/p/d need set_option(\"debug\", 1) before the solve");
+    double* kpi; int rows, row_off, cols;
+    if (field_geometry(b, field, &kpi, &rows, &row_off, &cols)) return fail(b, TINY_ERR_ARG, "bad field %d", (int)field);
+    const size_t n = (size_t)b->batch * rows * cols;
+    double* d = dev ? dst : b->d_stage;
+    hipLaunchKernelGGL(unpack_kpi_kernel, dim3(2048), dim3(256), 0, b->stream, kpi, d, b->batch, b->N, b->nx + b->nu, rows,
+                       row_off, cols);
+    HIP_TRY(b, hipGetLastError());
+    if (!dev) {
+        HIP_TRY(b, hipMemcpyAsync(dst, b->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(b, hipStreamSynchronize(b->stream));
+    }
+    return TINY_OK;
+}
+
+int tiny_batch_reset(TinyBatch* b) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    const size_t kpi_bytes = (size_t)b->batch * b->N * (b->nx + b->nu) * sizeof(double);
+    double* z[] = {b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual};
+    for (double* p : z) HIP_TRY(b, hipMemsetAsync(p, 0, kpi_bytes, b->stream));
+    HIP_TRY(b, hipMemsetAsync(b->d_accum, 0, (size_t)b->batch * sizeof(uint2), b->stream));
+    return TINY_OK;
+}
+
+int tiny_batch_solve_async(TinyBatch* b) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    return launch_solve(b);
+}
+
+int tiny_batch_synchronize(TinyBatch* b) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    return TINY_OK;
+}
+
+int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    double* dst = device_out ? (double*)device_out : b->d_stats;
+    HIP_TRY(b, hipMemsetAsync(dst, 0, 10 * sizeof(double), b->stream));
+    int blocks = (b->batch + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(blocks), dim3(256), 0, b->stream, b->d_status, b->d_resid, b->d_accum,
+                       b->batch, dst);
+    HIP_TRY(b, hipGetLastError());
+    if (host_out) {
+        HIP_TRY(b, hipMemcpyAsync(host_out, dst, 10 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(b, hipStreamSynchronize(b->stream));
+    }
+    return TINY_OK;
+}
+
+int tiny_batch_solve(TinyBatch* b) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    if (int rc = launch_solve(b)) return rc;
+    double st[10];
+    if (int rc = tiny_batch_reduce_stats(b, st, nullptr)) return rc;
+    return (st[1] == (double)b->batch) ? 0 : 1;          // tiny_solve: 0 converged, 1 max_iter reached
+}
+
+int tiny_batch_get_status(TinyBatch* b, int* iter, int* solved, int* status, double* residuals) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    std::vector<int4> st(b->batch);
+    HIP_TRY(b, hipMemcpyAsync(st.data(), b->d_status, (size_t)b->batch * sizeof(int4), hipMemcpyDeviceToHost, b->stream));
+    if (residuals)
+        HIP_TRY(b, hipMemcpyAsync(residuals, b->d_resid, (size_t)b->batch * 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    for (int i = 0; i < b->batch; ++i) {
+        if (iter) iter[i] = st[i].x;
+        if (solved) solved[i] = st[i].y;
+        if (status) status[i] = st[i].z;
+    }
+    return TINY_OK;
+}
+
+int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
+    if (!b || !name) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    if (!strcmp(name, "advance_x0")) b->advance_x0 = value != 0;
+    else if (!strcmp(name, "debug")) {
+        b->debug = value != 0;
+        if (b->debug) { if (int rc = ensure_debug_buffers(b)) return rc; }
+    } else if (!strcmp(name, "grid_waves_per_cu")) b->grid_waves_per_cu = (int)value;
+    else if (!strcmp(name, "dpp_mode")) b->dpp_mode = (int)value;
+    else if (!strcmp(name, "timing")) {
+        HIP_TRY(b, hipStreamSynchronize(b->stream));
+        while ((long)b->ev_start.size() < value) {
+            hipEvent_t s, e;
+            HIP_TRY(b, hipEventCreate(&s));
+            HIP_TRY(b, hipEventCreate(&e));
+            b->ev_start.push_back(s); b->ev_stop.push_back(e);
+        }
+        b->timing_n = 0;
+        b->timing_left = (int)value;
+    } else return fail(b, TINY_ERR_ARG, "unknown option %s", name);
+    return TINY_OK;
+}
+
+int tiny_batch_set_stream(TinyBatch* b, void* hip_stream) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+    b->stream = (hipStream_t)hip_stream;
+    b->own_stream = false;
+    return TINY_OK;
+}
+
+int tiny_batch_get_timing(TinyBatch* b, float* ms, int capacity) {
+    if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    for (int i = 0; i < b->timing_n && i < capacity; ++i)
+        HIP_TRY(b, hipEventElapsedTime(&ms[i], b->ev_start[i], b->ev_stop[i]));
+    return b->timing_n;
+}
+
+long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold) {
+    if (!b) return 0;
+    const long S = (long)b->nx * b->N + (long)b->nu * (b->N - 1);
+    return 8 * (b->nx + (cold ? 2 : 8) * S) + 44;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// batch_impl.hpp -- the opaque TinyBatch behind include/tinympc_amd.h (shared by batch_api.hip and
+// compat_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/tinympc_amd.h"
+#include "admm_kernel.hip.h"
+#include "cache.hpp"
+
+namespace tinympc_amd {
+
+struct KernelEntry;
+
+struct Settings {              // TinySettings (types.hpp:63-82) hot-path subset; defaults tiny_api.cpp:413-441
+    double abs_pri_tol = 1e-3, abs_dua_tol = 1e-3;
+    int max_iter = 1000, check_termination = 1;
+    int en_state_bound = 1, en_input_bound = 1, en_state_soc = 0, en_input_soc = 0;
+};
+
+}  // namespace tinympc_amd
+
+struct TinyBatch {
+    int nx = 0, nu = 0, N = 0, batch = 0, device = 0, num_cus = 256;
+    const tinympc_amd::KernelEntry* kernel = nullptr;
+    // host copies of the problem family
+    tinympc_amd::Mat A, B, f;
+    std::vector<double> Qw, Rw;                    // work->Q, work->R (user + rho)
+    tinympc_amd::Cache cache;
+    tinympc_amd::Settings set;
+    bool have_bounds = false;
+    std::vector<double> x_min, x_max, u_min, u_max;
+    std::vector<int> Acx, qcx, Acu, qcu;
+    std::vector<double> cx, cu;
+    // device state (KPI records, see admm_kernel.hip.h)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double *d_tab = nullptr, *d_x0 = nullptr, *d_ref = nullptr, *d_prim = nullptr, *d_slack = nullptr,
+           *d_dual = nullptr, *d_slack_prev = nullptr, *d_cslack = nullptr, *d_cdual = nullptr, *d_resid = nullptr,
+           *d_stage = nullptr, *d_stats = nullptr, *d_dbg_qr = nullptr, *d_dbg_pd = nullptr;
+    int4* d_status = nullptr;
+    uint2* d_accum = nullptr;
+    size_t stage_doubles = 0;
+    std::vector<double> h_tab;
+    bool tab_dirty = true;
+    // options
+    bool advance_x0 = false, debug = false;
+    int grid_waves_per_cu = 0, dpp_mode = 0;
+    // timing
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int timing_n = 0, timing_left = 0;
+    char err[256] = {0};
+};
+
+namespace tinympc_amd {
+int fail(TinyBatch* b, int code, const char* fmt, ...);
+int launch_solve(TinyBatch* b);
+}  // namespace tinympc_amd

@@ -1,0 +1,474 @@
+// compat_api.hip -- the reference's own entry points (include/tinympc_amd.h, part B) over plain-data
+// mirrors of TinySolver / TinyCache / TinyWorkspace / TinySettings / TinySolution
+// (reference src/tinympc/types.hpp:32-218), so a caller compiled against the reference's headers can
+// link this library instead of libtinympcstatic.a.
+//
+// tiny_solve(TinySolver*) == a batch of ONE on the GPU: the workspace is gathered into the
+// device records, the same admm_solve_kernel runs, and every workspace field the reference's
+// solve() touches (x,u,q,r,p,d,v,vnew,z,znew,g,y,vcnew,zcnew,gc,yc, residuals, status, iter,
+// solution) is scattered back.  It is a latency-bound convenience/parity path; throughput users
+// call tiny_batch_* directly.  There is no CPU solve in here.
+#include "batch_impl.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+
+using namespace tinympc_amd;
+
+namespace {
+
+// ---- Eigen-compatible storage: with default x86-64 flags Eigen allocates with plain malloc/free
+// (EIGEN_MALLOC_ALREADY_ALIGNED, Eigen/src/Core/util/Memory.h:23-57), so buffers made here can be
+// resized / freed by Eigen-side callers and vice versa.
+void mat_alloc(TinyMatrixPOD* m, int64_t r, int64_t c) {
+    m->data = (r * c) ? (double*)calloc((size_t)(r * c), sizeof(double)) : nullptr;
+    m->rows = r; m->cols = c;
+}
+void vec_alloc(TinyVectorPOD* v, int64_t r) {
+    v->data = r ? (double*)calloc((size_t)r, sizeof(double)) : nullptr;
+    v->rows = r;
+}
+void mat_assign(TinyMatrixPOD* m, const double* src, int64_t r, int64_t c) {   // Eigen operator= semantics
+    if (m->rows * m->cols != r * c) {
+        free(m->data);
+        m->data = (r * c) ? (double*)malloc((size_t)(r * c) * sizeof(double)) : nullptr;
+    }
+    m->rows = r; m->cols = c;
+    if (r * c) memcpy(m->data, src, (size_t)(r * c) * sizeof(double));
+}
+void vec_assign(TinyVectorPOD* v, const double* src, int64_t r) {
+    if (v->rows != r) { free(v->data); v->data = r ? (double*)malloc((size_t)r * sizeof(double)) : nullptr; }
+    v->rows = r;
+    if (r) memcpy(v->data, src, (size_t)r * sizeof(double));
+}
+void ivec_assign(TinyVectorXiPOD* v, const int* src, int64_t r) {
+    if (v->rows != r) { free(v->data); v->data = r ? (int*)malloc((size_t)r * sizeof(int)) : nullptr; }
+    v->rows = r;
+    if (r) memcpy(v->data, src, (size_t)r * sizeof(int));
+}
+void mat_from(TinyMatrixPOD* m, const Mat& s) { mat_assign(m, s.a.data(), s.r, s.c); }
+
+int check_dimension(const char* name, const char* what, long actual, long expected) {   // tiny_api.cpp:13-19
+    if (actual != expected) {
+        std::cout << name << " has " << actual << " " << what << ". Expected " << expected << "." << std::endl;
+        return 1;
+    }
+    return 0;
+}
+
+// Eigen's operator<< with IOFormat(4, 0, ", ", "\n", "[", "]") (tiny_api.cpp:11): every coefficient
+// printed at precision 4, right-aligned to the widest one, rows wrapped in [ ].
+std::string fmt_matrix(const double* d, int64_t rows, int64_t cols) {
+    std::vector<std::string> cell((size_t)(rows * cols));
+    size_t width = 0;
+    for (int64_t j = 0; j < cols; ++j)
+        for (int64_t i = 0; i < rows; ++i) {
+            std::ostringstream os;
+            os.precision(4);
+            os << d[j * rows + i];
+            cell[(size_t)(j * rows + i)] = os.str();
+            width = std::max(width, os.str().size());
+        }
+    std::ostringstream out;
+    for (int64_t i = 0; i < rows; ++i) {
+        if (i) out << "\n";
+        out << "[";
+        for (int64_t j = 0; j < cols; ++j) {
+            if (j) out << ", ";
+            out << std::setw((int)width) << cell[(size_t)(j * rows + i)];
+        }
+        out << "]";
+    }
+    return out.str();
+}
+std::string fmt(const Mat& m) { return fmt_matrix(m.a.data(), m.r, m.c); }
+
+Mat to_mat(const TinyMatrixPOD* m) { return Mat((int)m->rows, (int)m->cols, m->data); }
+
+// ---- device contexts for the struct-level solve --------------------------------------------
+struct Ctx { TinyBatch* b = nullptr; int n = 0; };
+std::map<TinySolver*, Ctx> g_ctx;
+std::mutex g_mu;
+
+int raw_batch(TinyBatch** out, int nx, int nu, int N, int n) {
+    // a TinyBatch whose cache is filled from the caller's TinyCache at every solve
+    std::vector<double> A((size_t)nx * nx, 0.0), B((size_t)nx * nu, 0.0), Q(nx, 1.0), R(nu, 1.0);
+    for (int i = 0; i < nx; ++i) A[(size_t)i * nx + i] = 0.5;
+    return tiny_batch_setup(out, A.data(), B.data(), nullptr, Q.data(), R.data(), 1.0, nx, nu, N, n, 0, 0);
+}
+
+bool shaped(const TinyMatrixPOD& m, int64_t r, int64_t c) { return m.data && m.rows == r && m.cols == c; }
+
+// copy the problem family (cache, dynamics, costs, bounds, cones, settings) of `s` into the batch
+int sync_family(TinyBatch* b, const TinySolver* s) {
+    const TinyWorkspace* w = s->work;
+    const TinyCache* c = s->cache;
+    const TinySettings* st = s->settings;
+    const int nx = w->nx, nu = w->nu, N = w->N;
+    if (st->en_state_linear || st->en_input_linear || st->en_tv_state_linear || st->en_tv_input_linear || st->adaptive_rho)
+        return fail(b, TINY_ERR_UNSUPPORTED, "linear constraints / adaptive rho are outside the accelerated hot path");
+    if (!shaped(c->Kinf, nu, nx) || !shaped(c->Pinf, nx, nx) || !shaped(c->Quu_inv, nu, nu) || !shaped(c->AmBKt, nx, nx) ||
+        c->APf.rows != nx || c->BPf.rows != nu || !shaped(w->Adyn, nx, nx) || !shaped(w->Bdyn, nx, nu))
+        return fail(b, TINY_ERR_DIM, "cache / dynamics have unexpected shapes");
+    b->cache.rho = c->rho;
+    b->cache.Kinf = to_mat(&c->Kinf); b->cache.Pinf = to_mat(&c->Pinf);
+    b->cache.Quu_inv = to_mat(&c->Quu_inv); b->cache.AmBKt = to_mat(&c->AmBKt);
+    b->cache.APf = Mat(nx, 1, c->APf.data); b->cache.BPf = Mat(nu, 1, c->BPf.data);
+    b->A = to_mat(&w->Adyn); b->B = to_mat(&w->Bdyn);
+    b->f = (w->fdyn.rows == nx) ? Mat(nx, 1, w->fdyn.data) : Mat(nx, 1);
+    b->Qw.assign(w->Q.data, w->Q.data + nx); b->Rw.assign(w->R.data, w->R.data + nu);
+    b->set.abs_pri_tol = st->abs_pri_tol; b->set.abs_dua_tol = st->abs_dua_tol; b->set.max_iter = st->max_iter;
+    b->set.check_termination = st->check_termination; b->set.en_state_bound = st->en_state_bound;
+    b->set.en_input_bound = st->en_input_bound; b->set.en_state_soc = st->en_state_soc; b->set.en_input_soc = st->en_input_soc;
+    b->have_bounds = false;
+    if (st->en_state_bound || st->en_input_bound) {
+        if (!shaped(w->x_min, nx, N) || !shaped(w->x_max, nx, N) || !shaped(w->u_min, nu, N - 1) || !shaped(w->u_max, nu, N - 1))
+            return fail(b, TINY_ERR_DIM, "bounds enabled but x_min/x_max/u_min/u_max are not set (tiny_set_bound_constraints)");
+        b->x_min.assign(w->x_min.data, w->x_min.data + (size_t)nx * N);
+        b->x_max.assign(w->x_max.data, w->x_max.data + (size_t)nx * N);
+        b->u_min.assign(w->u_min.data, w->u_min.data + (size_t)nu * (N - 1));
+        b->u_max.assign(w->u_max.data, w->u_max.data + (size_t)nu * (N - 1));
+        b->have_bounds = true;
+    }
+    b->tab_dirty = true;
+    const int nsc = w->numStateCones, nic = w->numInputCones;
+    return tiny_batch_set_cone_constraints(b, nsc, w->Acx.data, w->qcx.data, w->cx.data, nic, w->Acu.data, w->qcu.data, w->cu.data);
+}
+
+struct FieldMap { TinyField f; TinyMatrixPOD TinyWorkspace::*m; };
+const FieldMap kIn[] = {{TINY_F_XREF, &TinyWorkspace::Xref}, {TINY_F_UREF, &TinyWorkspace::Uref},
+                        {TINY_F_VNEW, &TinyWorkspace::vnew}, {TINY_F_ZNEW, &TinyWorkspace::znew},
+                        {TINY_F_G, &TinyWorkspace::g}, {TINY_F_Y, &TinyWorkspace::y},
+                        {TINY_F_V, &TinyWorkspace::v}, {TINY_F_Z, &TinyWorkspace::z}};
+const FieldMap kInSoc[] = {{TINY_F_X, &TinyWorkspace::x}, {TINY_F_U, &TinyWorkspace::u},
+                           {TINY_F_GC, &TinyWorkspace::gc}, {TINY_F_YC, &TinyWorkspace::yc}};
+const FieldMap kOut[] = {{TINY_F_X, &TinyWorkspace::x}, {TINY_F_U, &TinyWorkspace::u},
+                         {TINY_F_VNEW, &TinyWorkspace::vnew}, {TINY_F_ZNEW, &TinyWorkspace::znew},
+                         {TINY_F_G, &TinyWorkspace::g}, {TINY_F_Y, &TinyWorkspace::y},
+                         {TINY_F_V, &TinyWorkspace::v}, {TINY_F_Z, &TinyWorkspace::z},
+                         {TINY_F_Q, &TinyWorkspace::q}, {TINY_F_R, &TinyWorkspace::r},
+                         {TINY_F_P, &TinyWorkspace::p}, {TINY_F_D, &TinyWorkspace::d}};
+const FieldMap kOutSocS[] = {{TINY_F_VCNEW, &TinyWorkspace::vcnew}, {TINY_F_GC, &TinyWorkspace::gc}};
+const FieldMap kOutSocI[] = {{TINY_F_ZCNEW, &TinyWorkspace::zcnew}, {TINY_F_YC, &TinyWorkspace::yc}};
+
+bool is_state_field(TinyField f) {
+    return f == TINY_F_XREF || f == TINY_F_X || f == TINY_F_VNEW || f == TINY_F_G || f == TINY_F_V || f == TINY_F_VCNEW ||
+           f == TINY_F_GC || f == TINY_F_Q || f == TINY_F_P;
+}
+
+int solve_group(TinySolver** solvers, int n) {
+    if (!solvers || n <= 0 || !solvers[0]) return TINY_ERR_NULL;
+    TinySolver* s0 = solvers[0];
+    const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx& ctx = g_ctx[s0];
+    if (ctx.b && ctx.n != n) { tiny_batch_destroy(ctx.b); ctx.b = nullptr; }
+    if (!ctx.b) {
+        int rc = raw_batch(&ctx.b, nx, nu, N, n);
+        if (rc) {
+            fprintf(stderr, "tiny_solve: cannot create the device context for (nx,nu,N)=(%d,%d,%d): error %d "
+                            "(libtinympc_amd has no CPU path)\n", nx, nu, N, rc);
+            g_ctx.erase(s0);
+            return rc;
+        }
+        ctx.n = n;
+        tiny_batch_set_option(ctx.b, "debug", 1);
+    }
+    TinyBatch* b = ctx.b;
+    if (int rc = sync_family(b, s0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    const size_t ns = (size_t)nx * N, ni = (size_t)nu * (N - 1);
+    std::vector<double> buf((size_t)n * ns);
+    const bool s_soc = s0->settings->en_state_soc && s0->work->numStateCones > 0;
+    const bool i_soc = s0->settings->en_input_soc && s0->work->numInputCones > 0;
+    auto gather = [&](const FieldMap& fm) -> int {
+        const size_t sz = is_state_field(fm.f) ? ns : ni;
+        for (int k = 0; k < n; ++k) {
+            const TinyMatrixPOD& m = solvers[k]->work->*(fm.m);
+            if ((size_t)(m.rows * m.cols) != sz) return fail(b, TINY_ERR_DIM, "workspace field %d of solver %d has the wrong size", (int)fm.f, k);
+            memcpy(&buf[k * sz], m.data, sz * sizeof(double));
+        }
+        return tiny_batch_set(b, fm.f, buf.data(), TINY_HOST);
+    };
+    for (const FieldMap& fm : kIn) if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    if (s_soc || i_soc)
+        for (const FieldMap& fm : kInSoc) if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    for (int k = 0; k < n; ++k) memcpy(&buf[(size_t)k * nx], solvers[k]->work->x.data, nx * sizeof(double));   // x[:,0] = x0
+    if (int rc = tiny_batch_set(b, TINY_F_X0, buf.data(), TINY_HOST)) return rc;
+
+    if (int rc = launch_solve(b)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+
+    auto scatter = [&](const FieldMap& fm) -> int {
+        if (int rc = tiny_batch_get(b, fm.f, buf.data(), TINY_HOST)) return rc;
+        const size_t sz = is_state_field(fm.f) ? ns : ni;
+        for (int k = 0; k < n; ++k) {
+            TinyMatrixPOD& m = solvers[k]->work->*(fm.m);
+            if ((size_t)(m.rows * m.cols) == sz) memcpy(m.data, &buf[k * sz], sz * sizeof(double));
+        }
+        return TINY_OK;
+    };
+    for (const FieldMap& fm : kOut) if (int rc = scatter(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    if (s_soc) for (const FieldMap& fm : kOutSocS) if (int rc = scatter(fm)) return rc;
+    if (i_soc) for (const FieldMap& fm : kOutSocI) if (int rc = scatter(fm)) return rc;
+    std::vector<int4> st(n);
+    std::vector<double> res((size_t)n * 4);
+    if (hipMemcpyAsync(st.data(), b->d_status, n * sizeof(int4), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    if (hipMemcpyAsync(res.data(), b->d_resid, n * 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return TINY_ERR_HIP;
+    int all = 0;
+    for (int k = 0; k < n; ++k) {
+        TinySolver* s = solvers[k];
+        TinyWorkspace* w = s->work;
+        w->iter = st[k].x;                                   // admm.cpp:337,394
+        w->status = st[k].z;                                 // admm.cpp:336,431
+        if (st[k].w) {                                       // residuals are only written by a check (admm.cpp:312-317)
+            w->primal_residual_state = res[4 * k + 0]; w->primal_residual_input = res[4 * k + 1];
+            w->dual_residual_state = res[4 * k + 2]; w->dual_residual_input = res[4 * k + 3];
+        }
+        s->solution->iter = st[k].x;                         // admm.cpp:434-437 / :450-453
+        s->solution->solved = st[k].y;
+        mat_assign(&s->solution->x, w->vnew.data, w->vnew.rows, w->vnew.cols);
+        mat_assign(&s->solution->u, w->znew.data, w->znew.rows, w->znew.cols);
+        if (st[k].y) std::cout << "Solver converged in " << w->iter << " iterations" << std::endl;   // admm.cpp:439
+        else all = 1;
+    }
+    return all;                                              // 0 converged / 1 max_iter (admm.cpp:441,454)
+}
+
+}  // namespace
+
+extern "C" {
+
+int tiny_set_default_settings(TinySettings* settings) {           // tiny_api.cpp:413-441
+    if (!settings) { std::cout << "Error in tiny_set_default_settings: settings is nullptr" << std::endl; return 1; }
+    settings->abs_pri_tol = 1e-3; settings->abs_dua_tol = 1e-3;
+    settings->max_iter = 1000; settings->check_termination = 1;
+    settings->en_state_bound = 1; settings->en_input_bound = 1;
+    settings->en_state_soc = 0; settings->en_input_soc = 0;
+    settings->en_state_linear = 0; settings->en_input_linear = 0;
+    settings->en_tv_state_linear = 0; settings->en_tv_input_linear = 0;
+    settings->adaptive_rho = 0; settings->adaptive_rho_min = 1.0; settings->adaptive_rho_max = 100.0;
+    settings->adaptive_rho_enable_clipping = 1;
+    return 0;
+}
+
+int tiny_update_settings(TinySettings* settings, double abs_pri_tol, double abs_dua_tol, int max_iter,
+                         int check_termination, int en_state_bound, int en_input_bound, int en_state_soc,
+                         int en_input_soc, int en_state_linear, int en_input_linear, int en_tv_state_linear,
+                         int en_tv_input_linear) {                 // tiny_api.cpp:388-411
+    if (!settings) { std::cout << "Error in tiny_update_settings: settings is nullptr" << std::endl; return 1; }
+    settings->abs_pri_tol = abs_pri_tol; settings->abs_dua_tol = abs_dua_tol;
+    settings->max_iter = max_iter; settings->check_termination = check_termination;
+    settings->en_state_bound = en_state_bound; settings->en_input_bound = en_input_bound;
+    settings->en_state_soc = en_state_soc; settings->en_input_soc = en_input_soc;
+    settings->en_state_linear = en_state_linear; settings->en_input_linear = en_input_linear;
+    settings->en_tv_state_linear = en_tv_state_linear; settings->en_tv_input_linear = en_tv_input_linear;
+    return 0;
+}
+
+int tiny_precompute_and_set_cache(TinyCache* cache, const TinyMatrixPOD* Adyn, const TinyMatrixPOD* Bdyn,
+                                  const TinyMatrixPOD* fdyn, const TinyMatrixPOD* Q, const TinyMatrixPOD* R, int nx,
+                                  int nu, double rho, int verbose) {   // tiny_api.cpp:307-381
+    if (!cache) { std::cout << "Error in tiny_precompute_and_set_cache: cache is nullptr" << std::endl; return 1; }
+    const Mat A = to_mat(Adyn), B = to_mat(Bdyn), f = to_mat(fdyn), Qm = to_mat(Q), Rm = to_mat(R);
+    if (A.r != nx || A.c != nx || B.r != nx || B.c != nu || Qm.r != nx || Qm.c != nx || Rm.r != nu || Rm.c != nu ||
+        f.r != nx || f.c != 1)
+        return 1;
+    if (verbose) {
+        Mat Q1 = Qm, R1 = Rm;
+        for (int i = 0; i < nx; ++i) Q1(i, i) += rho;
+        for (int i = 0; i < nu; ++i) R1(i, i) += rho;
+        std::cout << "A = " << fmt(A) << std::endl;
+        std::cout << "B = " << fmt(B) << std::endl;
+        std::cout << "Q = " << fmt(Q1) << std::endl;
+        std::cout << "R = " << fmt(R1) << std::endl;
+        std::cout << "rho = " << rho << std::endl;
+    }
+    Cache c;
+    if (!precompute_cache(A, B, f, Qm, Rm, rho, &c)) return 1;
+    if (verbose) {
+        if (c.riccati_converged)      // printed only when the recursion converged (tiny_api.cpp:342-344)
+            std::cout << "Kinf converged after " << c.riccati_iters << " iterations" << std::endl;
+        std::cout << "Kinf = " << fmt(c.Kinf) << std::endl;
+        std::cout << "Pinf = " << fmt(c.Pinf) << std::endl;
+        std::cout << "Quu_inv = " << fmt(c.Quu_inv) << std::endl;
+        std::cout << "AmBKt = " << fmt(c.AmBKt) << std::endl;
+        std::cout << "APf = " << fmt(c.APf) << std::endl;
+        std::cout << "BPf = " << fmt(c.BPf) << std::endl;
+        std::cout << "\nPrecomputation finished!\n" << std::endl;
+    }
+    cache->rho = rho;
+    mat_from(&cache->Kinf, c.Kinf); mat_from(&cache->Pinf, c.Pinf);
+    mat_from(&cache->Quu_inv, c.Quu_inv); mat_from(&cache->AmBKt, c.AmBKt);
+    mat_from(&cache->C1, c.Quu_inv); mat_from(&cache->C2, c.AmBKt);        // tiny_api.cpp:375-376
+    vec_assign(&cache->APf, c.APf.a.data(), nx); vec_assign(&cache->BPf, c.BPf.a.data(), nu);
+    return 0;
+}
+
+int tiny_setup(TinySolver** solverp, const TinyMatrixPOD* Adyn, const TinyMatrixPOD* Bdyn, const TinyMatrixPOD* fdyn,
+               const TinyMatrixPOD* Q, const TinyMatrixPOD* R, double rho, int nx, int nu, int N, int verbose) {
+    // tiny_api.cpp:21-147
+    TinySolution* solution = (TinySolution*)calloc(1, sizeof(TinySolution));
+    TinyCache* cache = (TinyCache*)calloc(1, sizeof(TinyCache));
+    TinySettings* settings = (TinySettings*)calloc(1, sizeof(TinySettings));
+    TinyWorkspace* work = (TinyWorkspace*)calloc(1, sizeof(TinyWorkspace));
+    TinySolver* solver = (TinySolver*)calloc(1, sizeof(TinySolver));
+    solver->solution = solution; solver->cache = cache; solver->settings = settings; solver->work = work;
+    *solverp = solver;
+    solution->iter = 0; solution->solved = 0;
+    mat_alloc(&solution->x, nx, N); mat_alloc(&solution->u, nu, N - 1);
+    tiny_set_default_settings(settings);
+    work->nx = nx; work->nu = nu; work->N = N;
+    int status = 0;
+    status |= check_dimension("State transition matrix (A)", "rows", Adyn->rows, nx);
+    status |= check_dimension("State transition matrix (A)", "columns", Adyn->cols, nx);
+    status |= check_dimension("Input matrix (B)", "rows", Bdyn->rows, nx);
+    status |= check_dimension("Input matrix (B)", "columns", Bdyn->cols, nu);
+    status |= check_dimension("Affine vector (f)", "rows", fdyn->rows, nx);
+    status |= check_dimension("Affine vector (f)", "columns", fdyn->cols, 1);
+    status |= check_dimension("State stage cost (Q)", "rows", Q->rows, nx);
+    status |= check_dimension("State stage cost (Q)", "columns", Q->cols, nx);
+    status |= check_dimension("State input cost (R)", "rows", R->rows, nu);
+    status |= check_dimension("State input cost (R)", "columns", R->cols, nu);
+    if (status) return status;
+    TinyMatrixPOD* st[] = {&work->x, &work->q, &work->p, &work->v, &work->vnew, &work->g, &work->vc, &work->vcnew,
+                           &work->gc, &work->vl, &work->vlnew, &work->gl, &work->vl_tv, &work->vlnew_tv, &work->gl_tv,
+                           &work->Xref};
+    TinyMatrixPOD* in[] = {&work->u, &work->r, &work->d, &work->z, &work->znew, &work->y, &work->zc, &work->zcnew,
+                           &work->yc, &work->zl, &work->zlnew, &work->yl, &work->zl_tv, &work->zlnew_tv, &work->yl_tv,
+                           &work->Uref};
+    for (TinyMatrixPOD* m : st) mat_alloc(m, nx, N);
+    for (TinyMatrixPOD* m : in) mat_alloc(m, nu, N - 1);
+    vec_alloc(&work->Q, nx); vec_alloc(&work->R, nu);
+    for (int i = 0; i < nx; ++i) work->Q.data[i] = Q->data[(size_t)i * nx + i] + rho;     // :117
+    for (int i = 0; i < nu; ++i) work->R.data[i] = R->data[(size_t)i * nu + i] + rho;     // :118
+    mat_assign(&work->Adyn, Adyn->data, nx, nx);
+    mat_assign(&work->Bdyn, Bdyn->data, nx, nu);
+    vec_assign(&work->fdyn, fdyn->data, nx);
+    vec_alloc(&work->Qu, nu);
+    work->status = 0; work->iter = 0;
+    // :136 -- the cache sees diag(work->Q), diag(work->R), i.e. rho a second time
+    Mat Qd(nx, nx), Rd(nu, nu);
+    for (int i = 0; i < nx; ++i) Qd(i, i) = work->Q.data[i];
+    for (int i = 0; i < nu; ++i) Rd(i, i) = work->R.data[i];
+    TinyMatrixPOD Qp{Qd.a.data(), nx, nx}, Rp{Rd.a.data(), nu, nu};
+    TinyMatrixPOD fp{work->fdyn.data, nx, 1};
+    status = tiny_precompute_and_set_cache(cache, &work->Adyn, &work->Bdyn, &fp, &Qp, &Rp, nx, nu, rho, verbose);
+    return status;
+}
+
+int tiny_set_bound_constraints(TinySolver* solver, const TinyMatrixPOD* x_min, const TinyMatrixPOD* x_max,
+                               const TinyMatrixPOD* u_min, const TinyMatrixPOD* u_max) {   // tiny_api.cpp:149-174
+    if (!solver) { std::cout << "Error in tiny_set_bound_constraints: solver is nullptr" << std::endl; return 1; }
+    TinyWorkspace* w = solver->work;
+    int status = 0;
+    status |= check_dimension("Lower state bounds (x_min)", "rows", x_min->rows, w->nx);
+    status |= check_dimension("Lower state bounds (x_min)", "cols", x_min->cols, w->N);
+    status |= check_dimension("Lower state bounds (x_max)", "rows", x_max->rows, w->nx);
+    status |= check_dimension("Lower state bounds (x_max)", "cols", x_max->cols, w->N);
+    status |= check_dimension("Lower input bounds (u_min)", "rows", u_min->rows, w->nu);
+    status |= check_dimension("Lower input bounds (u_min)", "cols", u_min->cols, w->N - 1);
+    status |= check_dimension("Lower input bounds (u_max)", "rows", u_max->rows, w->nu);
+    status |= check_dimension("Lower input bounds (u_max)", "cols", u_max->cols, w->N - 1);
+    mat_assign(&w->x_min, x_min->data, x_min->rows, x_min->cols);
+    mat_assign(&w->x_max, x_max->data, x_max->rows, x_max->cols);
+    mat_assign(&w->u_min, u_min->data, u_min->rows, u_min->cols);
+    mat_assign(&w->u_max, u_max->data, u_max->rows, u_max->cols);
+    return 0;                                                    // the reference ignores `status` here (:173)
+}
+
+int tiny_set_cone_constraints(TinySolver* solver, const TinyVectorXiPOD* Acx, const TinyVectorXiPOD* qcx,
+                              const TinyVectorPOD* cx, const TinyVectorXiPOD* Acu, const TinyVectorXiPOD* qcu,
+                              const TinyVectorPOD* cu) {           // tiny_api.cpp:176-208
+    if (!solver) { std::cout << "Error in tiny_set_cone_constraints: solver is nullptr" << std::endl; return 1; }
+    const int nsc = (int)Acx->rows, nic = (int)Acu->rows;
+    int status = 0;
+    status |= check_dimension("Cone state size (qcx)", "rows", qcx->rows, nsc);
+    status |= check_dimension("Cone mu value for state (cx)", "rows", cx->rows, nsc);
+    status |= check_dimension("Cone input size (qcu)", "rows", qcu->rows, nic);
+    status |= check_dimension("Cone mu value for input (cu)", "rows", cu->rows, nic);
+    if (status) return status;
+    TinyWorkspace* w = solver->work;
+    w->numStateCones = nsc; w->numInputCones = nic;
+    ivec_assign(&w->Acx, Acx->data, nsc); ivec_assign(&w->qcx, qcx->data, nsc); vec_assign(&w->cx, cx->data, nsc);
+    ivec_assign(&w->Acu, Acu->data, nic); ivec_assign(&w->qcu, qcu->data, nic); vec_assign(&w->cu, cu->data, nic);
+    return 0;
+}
+
+int tiny_set_x0(TinySolver* solver, const TinyVectorPOD* x0) {     // tiny_api.cpp:443-453
+    if (!solver) { std::cout << "Error in tiny_set_x0: solver is nullptr" << std::endl; return 1; }
+    if (x0->rows != solver->work->nx) { perror("Error in tiny_set_x0: x0 is not the correct length"); return 0; }
+    memcpy(solver->work->x.data, x0->data, (size_t)x0->rows * sizeof(double));   // x.col(0) = x0
+    return 0;
+}
+
+int tiny_set_x_ref(TinySolver* solver, const TinyMatrixPOD* x_ref) {   // tiny_api.cpp:455-465
+    if (!solver) { std::cout << "Error in tiny_set_x_ref: solver is nullptr" << std::endl; return 1; }
+    check_dimension("State reference trajectory (x_ref)", "rows", x_ref->rows, solver->work->nx);
+    check_dimension("State reference trajectory (x_ref)", "columns", x_ref->cols, solver->work->N);
+    mat_assign(&solver->work->Xref, x_ref->data, x_ref->rows, x_ref->cols);
+    return 0;
+}
+
+int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref) {   // tiny_api.cpp:467-477
+    if (!solver) { std::cout << "Error in tiny_set_u_ref: solver is nullptr" << std::endl; return 1; }
+    check_dimension("Control/input reference trajectory (u_ref)", "rows", u_ref->rows, solver->work->nu);
+    check_dimension("Control/input reference trajectory (u_ref)", "columns", u_ref->cols, solver->work->N - 1);
+    mat_assign(&solver->work->Uref, u_ref->data, u_ref->rows, u_ref->cols);
+    return 0;
+}
+
+int solve(TinySolver* solver) { return solve_group(&solver, 1); }          // admm.cpp:331
+int tiny_solve(TinySolver* solver) { return solve(solver); }               // tiny_api.cpp:384-386
+int tiny_solve_batch(TinySolver** solvers, int n) { return solve_group(solvers, n); }
+
+int tiny_destroy(TinySolver* solver) {
+    if (!solver) return TINY_ERR_NULL;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(solver);
+        if (it != g_ctx.end()) { if (it->second.b) tiny_batch_destroy(it->second.b); g_ctx.erase(it); }
+    }
+    // every matrix member is {data*, ...}: walk the structs as arrays of words would be fragile; free by name
+    TinyWorkspace* w = solver->work;
+    TinyMatrixPOD* ms[] = {&w->x, &w->u, &w->q, &w->r, &w->p, &w->d, &w->v, &w->vnew, &w->z, &w->znew, &w->g, &w->y,
+                           &w->x_min, &w->x_max, &w->u_min, &w->u_max, &w->vc, &w->vcnew, &w->zc, &w->zcnew, &w->gc,
+                           &w->yc, &w->Alin_x, &w->Alin_u, &w->vl, &w->vlnew, &w->zl, &w->zlnew, &w->gl, &w->yl,
+                           &w->tv_Alin_x, &w->tv_blin_x, &w->tv_Alin_u, &w->tv_blin_u, &w->vl_tv, &w->vlnew_tv,
+                           &w->zl_tv, &w->zlnew_tv, &w->gl_tv, &w->yl_tv, &w->Adyn, &w->Bdyn, &w->Xref, &w->Uref,
+                           &solver->solution->x, &solver->solution->u, &solver->cache->Kinf, &solver->cache->Pinf,
+                           &solver->cache->Quu_inv, &solver->cache->AmBKt, &solver->cache->C1, &solver->cache->C2,
+                           &solver->cache->dKinf_drho, &solver->cache->dPinf_drho, &solver->cache->dC1_drho,
+                           &solver->cache->dC2_drho};
+    for (TinyMatrixPOD* m : ms) free(m->data);
+    TinyVectorPOD* vs[] = {&w->cx, &w->cu, &w->blin_x, &w->blin_u, &w->Q, &w->R, &w->fdyn, &w->Qu, &solver->cache->APf,
+                           &solver->cache->BPf};
+    for (TinyVectorPOD* v : vs) free(v->data);
+    free(w->Acx.data); free(w->Acu.data); free(w->qcx.data); free(w->qcu.data);
+    free(solver->solution); free(solver->cache); free(solver->settings); free(solver->work); free(solver);
+    return 0;
+}
+
+}  // extern "C"
+
+// layout contract with the reference (measured with offsetof on its types.hpp)
+static_assert(sizeof(TinyMatrixPOD) == 24 && sizeof(TinyVectorPOD) == 16 && sizeof(TinyVectorXiPOD) == 16, "Eigen DenseStorage");
+static_assert(sizeof(TinySolution) == 56 && offsetof(TinySolution, x) == 8 && offsetof(TinySolution, u) == 32, "TinySolution");
+static_assert(sizeof(TinyCache) == 280 && offsetof(TinyCache, Kinf) == 8 && offsetof(TinyCache, APf) == 104 &&
+              offsetof(TinyCache, BPf) == 120 && offsetof(TinyCache, C1) == 136 && offsetof(TinyCache, dC2_drho) == 256, "TinyCache");
+static_assert(sizeof(TinySettings) == 88 && offsetof(TinySettings, max_iter) == 16 && offsetof(TinySettings, adaptive_rho) == 56 &&
+              offsetof(TinySettings, adaptive_rho_min) == 64 && offsetof(TinySettings, adaptive_rho_enable_clipping) == 80, "TinySettings");
+static_assert(sizeof(TinyWorkspace) == 1328 && offsetof(TinyWorkspace, x) == 16 && offsetof(TinyWorkspace, x_min) == 304 &&
+              offsetof(TinyWorkspace, numStateCones) == 400 && offsetof(TinyWorkspace, cx) == 408 && offsetof(TinyWorkspace, vc) == 504 &&
+              offsetof(TinyWorkspace, numStateLinear) == 648 && offsetof(TinyWorkspace, Alin_x) == 656 && offsetof(TinyWorkspace, vl) == 736 &&
+              offsetof(TinyWorkspace, numtvStateLinear) == 880 && offsetof(TinyWorkspace, vl_tv) == 984 && offsetof(TinyWorkspace, Q) == 1128 &&
+              offsetof(TinyWorkspace, Adyn) == 1160 && offsetof(TinyWorkspace, Xref) == 1224 && offsetof(TinyWorkspace, Qu) == 1272 &&
+              offsetof(TinyWorkspace, primal_residual_state) == 1288 && offsetof(TinyWorkspace, status) == 1320 &&
+              offsetof(TinyWorkspace, iter) == 1324, "TinyWorkspace");
+static_assert(sizeof(TinySolver) == 32 && offsetof(TinySolver, work) == 24, "TinySolver");
