@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances PER GPU")
     ap.add_argument("--grid-waves-per-cu", type=int, default=int(os.environ.get("TINYMPC_GRID_WAVES_PER_CU", "0")))
     ap.add_argument("--dpp-mode", type=int, default=int(os.environ.get("TINYMPC_DPP_MODE", "0")))
+    ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("TINYMPC_STEPS_PER_LAUNCH", "1")),
+                    help="closed-loop MPC steps fused into one kernel launch (state stays in registers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -84,6 +86,10 @@ def main():
     s.set_option("advance_x0", 1)
     s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
     s.set_option("dpp_mode", args.dpp_mode)
+    T = max(1, args.steps_per_launch)
+    if args.steps % T or (args.warmup % T and args.warmup):
+        sys.exit("--steps and --warmup must be multiples of --steps-per-launch")
+    s.set_option("steps_per_launch", T)
     stream = torch.cuda.Stream(device=local_rank)
     s.set_stream(stream.cuda_stream)                 # kernels, events and the RCCL all-reduce share one stream
     xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
@@ -103,14 +109,14 @@ def main():
 
     with torch.cuda.stream(stream):
         cold_start()
-        for _ in range(args.warmup):
+        for _ in range(args.warmup // T):
             s.solve_async()
         s.synchronize()
         cold_start()
-        s.set_option("timing", args.steps)           # HIP events around every timed solve kernel, on `stream`
+        s.set_option("timing", args.steps // T)      # HIP events around every timed solve kernel, on `stream`
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // T):
             s.solve_async()
         s.reduce_stats_async(stats.data_ptr())
         if dist is not None:                         # the one collective of the path: residual / count all-reduce
@@ -133,7 +139,7 @@ def main():
     kern_ms = s.timing_ms()
     solves = float(world) * B * args.steps
     value = solves / elapsed
-    alg_bytes = s.algorithmic_bytes(cold=False) * B            # per launch, SURVEY.md 8(d) bytes_warm
+    alg_bytes = s.algorithmic_bytes(cold=False) * B * T        # per launch: SURVEY.md 8(d) bytes_warm x solves per launch
     avg_kernel_s = float(kern_ms.mean()) * 1e-3
     achieved_gbs = alg_bytes / avg_kernel_s / 1e9
     traffic = None
@@ -155,7 +161,8 @@ def main():
             "config": {"workload": "quadrotor_hovering (nx=12, nu=4, N=10), 65536 identical instances per GPU, "
                                    "closed-loop MPC steps from a cold start (BASELINE configs[1])",
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}",
-                       "grid_waves_per_cu": args.grid_waves_per_cu, "dpp_mode": args.dpp_mode},
+                       "grid_waves_per_cu": args.grid_waves_per_cu, "dpp_mode": args.dpp_mode,
+                       "mpc_steps_per_launch": T},
             "admm_iters_per_s": acc_iters / elapsed,
             "admm_iters_per_solve": acc_iters / solves,
             "solved_fraction": acc_solved / solves,
@@ -164,8 +171,11 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "admm_solve_kernel<12,4,10>", "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "bytes_warm = 8*(nx+8S)+44 = 10124 B per solve x batch; launches of the first "
-                                 "MPC steps run 100 ADMM iterations and are FP64-issue bound, see roofline_fp64"},
+                         "launches": args.steps // T,
+                         "note": "bytes_warm = 8*(nx+8S)+44 = 10124 B per solve x solves per launch; the launches "
+                                 "that hold the first MPC steps (100 ADMM iterations each) are FP64-issue bound, "
+                                 "see roofline_fp64; with mpc_steps_per_launch > 1 the state stays in registers "
+                                 "between fused steps, so real HBM traffic is below the algorithmic figure"},
             "roofline_fp64": {"bound": "fp64-valu", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": fp64_tflops / FP64_PEAK_TFLOPS,
                               "flops_per_admm_iter": fl},

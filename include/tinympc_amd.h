@@ -137,9 +137,15 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
 /* Options: "advance_x0" (1: each solve also writes x0 <- A x0 + B u[:,0] + f, the plant step of
  * the examples' closed loop, examples/quadrotor_hovering.cpp:92), "debug" (1: keep q,r,p,d),
  * "grid_waves_per_cu" (persistent-grid size, 0 = one wave per tile), "dpp_mode" (0 fused
- * v_fmac_f64_dpp, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves). */
+ * v_fmac_f64_dpp, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves),
+ * "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
+ * x0 <- A x0 + B u[:,0] + f, solve, ... -- inside ONE launch with the ADMM state held in registers;
+ * references stay fixed during the launch), "step_log" (1: keep per-step iteration counts / u0). */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
+/* After a launch with "steps_per_launch" = T > 1 and "step_log" = 1: per fused MPC step and instance,
+ * iters[T][batch] (negative = that solve hit max_iter) and the applied control u0[T][batch][nu]. */
+int tiny_batch_get_step_log(TinyBatch* b, int* iters, double* u0, int steps);
 /* kernel durations (ms) of the solves recorded since "timing" was set; returns the count */
 int tiny_batch_get_timing(TinyBatch* b, float* ms, int capacity);
 const char* tiny_batch_last_error(TinyBatch* b);

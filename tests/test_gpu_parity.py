@@ -61,9 +61,10 @@ def test_hip_matches_reference_golden(name):
     assert worst <= CONTRACT_RTOL
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_dpp_modes_agree_with_golden(mode):
-    """dpp_mode 0 = fused v_fmac_f64_dpp row_newbcast, 1 = v_mov_b32_dpp + v_fma_f64: same results."""
+    """dpp_mode 0 = fused v_fmac_f64_dpp row_newbcast (two accumulator chains), 2 = one chain,
+    1 = compiler-scheduled v_mov_b32_dpp + v_fma_f64: same results."""
     suite, ref = sc.load_suite(os.path.join(GOLDEN, "random_state_quad.npz"))
     out = run_cases_hip(suite, options={"dpp_mode": mode})
     assert_match(out, ref, RTOL, f"dpp_mode={mode}")
@@ -147,6 +148,52 @@ def test_hover_closed_loop_full_batch():
         total += gold[k]
     assert total == 882
     s.close()
+
+
+@pytest.mark.parametrize("T", [100, 10])
+def test_fused_closed_loop_steps(T):
+    """steps_per_launch = T: T closed-loop MPC steps (solve, plant step, solve, ...) inside ONE launch
+    with the ADMM state held in registers.  Must reproduce the reference's per-step iteration
+    sequence (100 100 100 100 100 58 43 14 7 ... total 882) and applied controls, and leave the same
+    warm state behind as 100 separate launches."""
+    suite, _ = sc.load_suite(os.path.join(GOLDEN, "hover_warm.npz"))
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    B = 1000                      # not a multiple of 4*anything special: ragged last wave
+    xref = np.tile(np.array(extra["hover"]["xref"], dtype=float).reshape(-1, 1), (1, prob["N"]))
+    x0 = np.array(extra["hover"]["x0"], dtype=float)
+    gold = suite["episode"]
+    # reference run: one launch per step
+    a = make_batch(suite, batch=B)
+    a.set_option("advance_x0", 1)
+    a.set_x_ref(xref, broadcast=True)
+    a.set_x0(x0, broadcast=True)
+    for _ in range(100):
+        a.solve_async()
+    fa = {k: a.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "x0")}
+    sa = a.reduce_stats()
+    a.close()
+    f = make_batch(suite, batch=B)
+    f.set_option("steps_per_launch", T)
+    f.set_option("step_log", 1)
+    f.set_x_ref(xref, broadcast=True)
+    f.set_x0(x0, broadcast=True)
+    its, u0s = [], []
+    for _ in range(100 // T):
+        f.solve_async()
+        it, u0 = f.step_log(T)
+        its.append(it)
+        u0s.append(u0)
+    its, u0s = np.concatenate(its), np.concatenate(u0s)
+    assert np.array_equal(np.abs(its[:, 0]), gold["iters"]) and np.abs(its[:, 0]).sum() == 882
+    assert np.all(its == its[:, :1])                                   # every instance identical
+    assert np.array_equal(its[:, 0] < 0, gold["iters"] == 100)         # first five solves hit max_iter
+    assert rel_err(u0s[:10, 0], gold["u0"][:10]) < RTOL and rel_err(u0s[:, 0], gold["u0"]) < 1e-6
+    ff = {k: f.get(k) for k in fa}
+    sf = f.reduce_stats()
+    f.close()
+    for k in fa:
+        assert np.array_equal(ff[k], fa[k]), f"fused launch left a different {k}"
+    assert sf[7] == sa[7] == 882.0 * B and sf[8] == sa[8] == 95.0 * B
 
 
 def test_tracking_full_batch_properties():

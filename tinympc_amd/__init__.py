@@ -38,7 +38,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_set_cone_constraints", "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
-    "tiny_batch_get_timing", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
+    "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
 REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_precompute_and_set_cache",
     "tiny_solve", "solve", "tiny_update_settings", "tiny_set_default_settings", "tiny_set_x0", "tiny_set_x_ref",
@@ -86,6 +86,7 @@ def lib():
         L.tiny_batch_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.tiny_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_get_timing.argtypes = [C.c_void_p, _fp, C.c_int]
+        L.tiny_batch_get_step_log.argtypes = [C.c_void_p, _ip, _dp, C.c_int]
         L.tiny_batch_last_error.argtypes = [C.c_void_p]
         L.tiny_batch_last_error.restype = C.c_char_p
         L.tiny_batch_supported_dims.argtypes = [_ip, C.c_int]
@@ -283,6 +284,14 @@ class TinyBatchSolver:
         buf = np.zeros(capacity, dtype=np.float32)
         n = lib().tiny_batch_get_timing(self._h, buf.ctypes.data_as(_fp), capacity)
         return buf[:max(n, 0)].astype(np.float64)
+
+    def step_log(self, steps):
+        """(iters[steps, batch] (negative: hit max_iter), u0[steps, batch, nu]) of the last fused launch."""
+        it = np.zeros((steps, self.batch), dtype=np.int32)
+        u0 = np.zeros((steps, self.batch, self.nu))
+        self._check(lib().tiny_batch_get_step_log(self._h, it.ctypes.data_as(_ip), u0.ctypes.data_as(_dp), steps),
+                    "get_step_log")
+        return it, u0
 
     def algorithmic_bytes(self, cold=False) -> int:
         return int(lib().tiny_batch_algorithmic_bytes(self._h, 1 if cold else 0))

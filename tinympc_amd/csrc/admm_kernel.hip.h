@@ -76,17 +76,23 @@ struct SolveArgs {
     double* dbg_qr;           // optional KPI: q/r of the last iteration (work->q, work->r)
     double* dbg_pd;           // optional KPI: p/d of the last iteration (work->p, work->d)
     uint2* accum;             // optional [batch] {iterations, solves converged} accumulated over successive solves
+    int* iter_log;            // optional [steps][batch]: per-MPC-step iteration count (negative: not converged), steps > 1
+    double* u0_log;           // optional [steps][batch][nu]: the applied control u[:,0] of every fused MPC step
     double rho, tol_pri, tol_dua;
     int batch, max_iter, check_termination;
+    int steps;                // closed-loop MPC steps fused into this launch (>= 1; > 1 implies the plant step)
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
 // One asm statement per block so that the two wait states a DPP read needs after a VALU write of
 // its source (CDNA ISA "VALU writes VGPR -> DPP reads that VGPR") are paid once (the leading
 // s_nop 1), and no compiler-inserted copy can land between the FMAs.  The accumulators are
-// EARLY-CLOBBER ("+&v"): they are written while src / m[] are still being read, so they must never
-// share a register with an input (without it hipcc happily aliases b0 with src when b0 == src).
+// EARLY-CLOBBER ("&"): they are written while src / m[] are still being read, so they must never
+// share a register with an input (without it hipcc happily aliases an accumulator with src).
+//
+//   TF_  : v_fmac_f64_dpp acc, src, m[k] row_newbcast:COL0+k      acc += bcast(src, lane COL0+k) * m[k]
 #define TF_(acc, mi, k) "v_fmac_f64_dpp %" #acc ", %2, %" #mi " row_newbcast:%3+" #k " row_mask:0xf bank_mask:0xf\n\t"
+// two-accumulator chains, every column an fmac (both accumulators carry a value in)
 #define TB1 TF_(0, 4, 0)
 #define TB2 TB1 TF_(1, 5, 1)
 #define TB3 TB2 TF_(0, 6, 2)
@@ -103,6 +109,24 @@ struct SolveArgs {
 #define TB14 TB13 TF_(1, 17, 13)
 #define TB15 TB14 TF_(0, 18, 14)
 #define TB16 TB15 TF_(1, 19, 15)
+// single-accumulator chain (operand numbering: %0 acc, %1 src, %2 COL0, %3.. m[k])
+#define TS_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:%2+" #k " row_mask:0xf bank_mask:0xf\n\t"
+#define TS1 TS_(3, 0)
+#define TS2 TS1 TS_(4, 1)
+#define TS3 TS2 TS_(5, 2)
+#define TS4 TS3 TS_(6, 3)
+#define TS5 TS4 TS_(7, 4)
+#define TS6 TS5 TS_(8, 5)
+#define TS7 TS6 TS_(9, 6)
+#define TS8 TS7 TS_(10, 7)
+#define TS9 TS8 TS_(11, 8)
+#define TS10 TS9 TS_(12, 9)
+#define TS11 TS10 TS_(13, 10)
+#define TS12 TS11 TS_(14, 11)
+#define TS13 TS12 TS_(15, 12)
+#define TS14 TS13 TS_(16, 13)
+#define TS15 TS14 TS_(17, 14)
+#define TS16 TS15 TS_(18, 15)
 #define TM1 "v"(m[0])
 #define TM2 TM1, "v"(m[1])
 #define TM3 TM2, "v"(m[2])
@@ -123,6 +147,10 @@ struct SolveArgs {
     if constexpr (NCOL == K) {                                                              \
         asm("s_nop 1\n\t" TB##K : "+&v"(a0), "+&v"(a1) : "v"(src), "i"(COL0), TM##K);        \
     }
+#define RING1_CASE(K)                                                                       \
+    if constexpr (NCOL == K) {                                                              \
+        asm("s_nop 1\n\t" TS##K : "+&v"(a0) : "v"(src), "i"(COL0), TM##K);                   \
+    }
 
 template <int C>
 __device__ __forceinline__ double row_bcast(double v) {
@@ -142,7 +170,7 @@ struct RingB {
     }
 };
 
-// acc{0,1} += sum_{k<NCOL} bcast(src, lane COL0+k) * m[k]   (even k -> a0, odd k -> a1)
+// a{0,1} += sum_{k<NCOL} bcast(src, lane COL0+k) * m[k]   (even k -> a0, odd k -> a1)
 // MODE 0: fused v_fmac_f64_dpp (1 issue slot / column); MODE 1: v_mov_b32_dpp x2 + v_fma_f64.
 template <int MODE, int COL0, int NCOL>
 __device__ __forceinline__ void ring(double& a0, double& a1, double src, const double* m) {
@@ -153,6 +181,60 @@ __device__ __forceinline__ void ring(double& a0, double& a1, double src, const d
     } else {
         RingB<COL0, NCOL, 0>::run(a0, a1, src, m);
     }
+}
+// single accumulator chain: a0 += sum_k bcast(src, COL0+k) * m[k]
+template <int COL0, int NCOL>
+__device__ __forceinline__ void ring1(double& a0, double src, const double* m) {
+    static_assert(NCOL >= 1 && NCOL <= 16 && COL0 + NCOL <= 16, "one DPP row");
+    RING1_CASE(1) RING1_CASE(2) RING1_CASE(3) RING1_CASE(4) RING1_CASE(5) RING1_CASE(6) RING1_CASE(7) RING1_CASE(8)
+    RING1_CASE(9) RING1_CASE(10) RING1_CASE(11) RING1_CASE(12) RING1_CASE(13) RING1_CASE(14) RING1_CASE(15) RING1_CASE(16)
+}
+// init + sum_{k<NA} bcast(srcA, k) mA[k] + sum_{k<NB} bcast(srcB, NA+k) mB[k]
+//   MODE 0: two accumulator chains (fused DPP FMA);  MODE 2: one chain;  MODE 1: compiler-scheduled mov_dpp + fma
+template <int MODE, int NA, int NB>
+__device__ __forceinline__ double ring_sum2(double init, double srcA, const double* mA, double srcB, const double* mB) {
+    if constexpr (MODE == 2) {
+        double a0 = init;
+        ring1<0, NA>(a0, srcA, mA);
+        ring1<NA, NB>(a0, srcB, mB);
+        return a0;
+    } else {
+        double a0 = init, a1 = 0.0;
+        ring<MODE, 0, NA>(a0, a1, srcA, mA);
+        ring<MODE, NA, NB>(a0, a1, srcB, mB);
+        return a0 + a1;
+    }
+}
+template <int MODE, int COL0, int NCOL>
+__device__ __forceinline__ double ring_sum(double init, double src, const double* m) {
+    if constexpr (MODE == 2) {
+        double a0 = init;
+        ring1<COL0, NCOL>(a0, src, m);
+        return a0;
+    } else {
+        double a0 = init, a1 = 0.0;
+        ring<MODE, COL0, NCOL>(a0, a1, src, m);
+        return a0 + a1;
+    }
+}
+// short blocks (the forward pass' B u_i): always one chain when fused
+template <int MODE, int COL0, int NCOL>
+__device__ __forceinline__ double ring_short(double init, double src, const double* m) {
+    if constexpr (MODE == 1) return ring_sum<1, COL0, NCOL>(init, src, m);
+    else { double a0 = init; ring1<COL0, NCOL>(a0, src, m); return a0; }
+}
+
+// v_max_f64 / v_min_f64 without the canonicalising `v_max x, x` hipcc puts in front of fmax/fmin
+// operands that come from memory (the box bounds): the hardware quiets NaNs by itself.
+__device__ __forceinline__ double vmax64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmin64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ double grp_max16(double v) {
@@ -179,8 +261,12 @@ __device__ __forceinline__ double soc_component(double s0, double s1, double s2,
 }
 
 // ---- the kernel -------------------------------------------------------------------------------
+// Slot convention: lane j keeps N-long register arrays indexed by "slot" s.  State lanes (j < NX):
+// slot s = knot s.  Input lanes: slot s = knot s-1 (slot 0 is a neutral dummy), because the forward
+// step i produces x_{i+1} on the state lanes and u_i on the input lanes in the SAME instruction
+// stream -- storing both at slot i+1 needs no per-lane select.
 template <int NX, int NU, int N, bool SOC, bool DBG, int MODE>
-__global__ __launch_bounds__(64) void admm_solve_kernel(const SolveArgs P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void admm_solve_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
     const int lane = threadIdx.x & 63;
@@ -188,7 +274,6 @@ __global__ __launch_bounds__(64) void admm_solve_kernel(const SolveArgs P) {
     const int grp = lane >> 4;
     const bool is_state = j < NX;
     const bool is_input = (j >= NX) && (j < NZ);
-    const bool used = j < NZ;
 
     // per-wave LDS copies of the tables that are read with a dynamic index or only once per solve
     __shared__ double sPt[NX * 16];
@@ -229,142 +314,166 @@ __global__ __launch_bounds__(64) void admm_solve_kernel(const SolveArgs P) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile * 4 + grp;
         if (b < P.batch) {
-            const size_t rec = (size_t)b * (N * NZ);
+            // record base of this lane: input lanes read knot s-1 at slot s
+            const size_t lbase = (size_t)b * (N * NZ) + j - (is_input ? NZ : 0);
             double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
             double VC[SOC ? N : 1], GC[SOC ? N : 1];
-            double Qd[DBG ? N : 1], Pd[DBG ? N : 1];
+            double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
             double ref_last = 0.0, qx_last_plain = 0.0;
-            // ---- load the instance record (coalesced: one contiguous NZ*8-byte segment per knot)
+            // ---- load the instance record (coalesced: contiguous NZ*8-byte knot segments)
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const bool valid = used && (is_state || i < N - 1);
-                const size_t off = rec + i * NZ + j;
+            for (int s = 0; s < N; ++s) {
+                const bool valid = is_state || (is_input && s >= 1);
+                const size_t off = lbase + s * NZ;
                 const double r = valid ? P.ref[off] : 0.0;
-                VN[i] = valid ? P.slack[off] : 0.0;
-                G[i] = valid ? P.dual[off] : 0.0;
-                VP[i] = valid ? P.slack_prev[off] : 0.0;
-                QX[i] = -(r * qr);                           // admm.cpp:266 / :279
-                X[i] = 0.0;
-                if (i == N - 1) ref_last = r;
+                VN[s] = valid ? P.slack[off] : 0.0;
+                G[s] = valid ? P.dual[off] : 0.0;
+                VP[s] = valid ? P.slack_prev[off] : 0.0;
+                QX[s] = -(r * qr);                           // admm.cpp:266 / :279
+                X[s] = 0.0;
+                if (s == N - 1) ref_last = r;
                 if constexpr (SOC) {
-                    VC[i] = (valid && soc_lane) ? P.prim[off] : 0.0;        // admm.cpp:352-357
-                    GC[i] = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                    VC[s] = (valid && soc_lane) ? P.prim[off] : 0.0;        // admm.cpp:352-357
+                    GC[s] = (valid && soc_lane) ? P.cdual[off] : 0.0;
                 }
+                if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
-            const double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;     // tiny_set_x0
-            X[0] = x0v;
-            if constexpr (SOC) { if (is_state && soc_lane) VC[0] = x0v; }
-            {   // terminal cost  -(Xref[:,N-1]^T Pinf)   (admm.cpp:292)
+            double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;           // tiny_set_x0
+            {   // terminal cost  -(Xref[:,N-1]^T Pinf)   (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
                 for (int k = 0; k < NX; ++k) pt[k] = sPt[k * 16 + j];
-                double a0 = 0.0, a1 = 0.0;
-                ring<MODE, 0, NX>(a0, a1, ref_last, pt);
+                const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
-                QX[N - 1] = is_state ? -(a0 + a1) : QX[N - 1];
+                QX[N - 1] = is_state ? -xp : QX[N - 1];
             }
 
             int iter = 0, solved = 0, checked = 0;
-            int countdown = P.check_termination;
+            unsigned acc_iter = 0, acc_solved = 0;
             double rp = 0.0, rd = 0.0;
-            for (int it = 0; it < P.max_iter; ++it) {
-                // ---- update_linear_cost (lane-local) fused into the backward sweep
-                double pcur;
-                {
-                    double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293
-                    if constexpr (SOC) t = fma(-rho, VC[N - 1] - GC[N - 1], t); // :295
-                    pcur = t;
-                    if constexpr (DBG) {
-                        double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
-                        if constexpr (SOC) ql = fma(-rho, VC[N - 1] - GC[N - 1], ql);
-                        Qd[N - 1] = ql;
-                        Pd[N - 1] = t;
+            const int nsteps = P.steps > 1 ? P.steps : 1;
+            for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch
+                X[0] = x0v;                                    // work->x.col(0) = x0
+                if constexpr (SOC) {
+                    if (step > 0) {                            // vcnew = x, zcnew = u of the previous solve (admm.cpp:352-357)
+#pragma unroll
+                        for (int s = 0; s < N; ++s) VC[s] = soc_lane ? X[s] : 0.0;
+                    } else if (is_state && soc_lane) {
+                        VC[0] = x0v;
                     }
                 }
-                // ---- backward_pass_grad, admm.cpp:13-20
-#pragma unroll
-                for (int i = N - 2; i >= 0; --i) {
-                    double qi = fma(-rho, VN[i] - G[i], QX[i]);                 // :267 / :280
-                    if constexpr (SOC) qi = fma(-rho, VC[i] - GC[i], qi);       // :269 / :282
-                    double a0 = 0.0, a1 = 0.0;
-                    ring<MODE, 0, NX>(a0, a1, pcur, mb);                        // AmBKt p | (Quu_inv B') p
-                    ring<MODE, NX, NU>(a0, a1, qi, mb + NX);                    // -Kinf' r | Quu_inv r
-                    double res = (a0 + a1) + cb;
-                    res = fma(qi, smask, res);                                  // + q_i on state lanes
-                    pcur = res;                                                 // p_i | d_i
-                    Dn[i] = res * nim;                                          // -d_i on input lanes, 0 elsewhere
-                    if constexpr (DBG) { Qd[i] = qi; Pd[i] = res; }
-                }
-                // ---- forward_pass, admm.cpp:25-32
-#pragma unroll
-                for (int i = 0; i < N - 1; ++i) {
-                    double a0 = Dn[i], a1 = 0.0;
-                    ring<MODE, 0, NX>(a0, a1, X[i], mf1);                       // A x_i | -Kinf x_i - d_i
-                    const double t = a0 + a1;
-                    X[i] = is_input ? t : X[i];                                 // u_i
-                    double b0 = t, b1 = 0.0;
-                    ring<MODE, NX, NU>(b0, b1, t, mf2);                         // + B u_i
-                    const double xn = (b0 + b1) + cf;                           // + f
-                    X[i + 1] = (i == N - 2 && !is_state) ? 0.0 : xn;            // x_{i+1} (input lanes: rewritten next step)
-                }
-                // ---- update_slack + update_dual + residuals (lane-local), admm.cpp:81-135, 219-235, 314-317
-                double pmax = 0.0, dmax = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const double xi = X[i];
-                    const double t = xi + G[i];                                 // :85 / :88
-                    const double vn = fmin(sHi[i * 16 + j], fmax(sLo[i * 16 + j], t));   // :91-98
-                    pmax = fmax(pmax, fabs(xi - vn));
-                    dmax = fmax(dmax, fabs(VP[i] - vn));
-                    G[i] = (G[i] + xi) - vn;                                    // :222 / :225
-                    VN[i] = vn;
-                    if constexpr (SOC) {
-                        double vc = soc_lane ? (xi + GC[i]) : 0.0;              // :102-109
-                        const int base = (cone_base >= 0) ? cone_base : j;
-                        const double s0 = __shfl(vc, base, 16);
-                        const double s1 = __shfl(vc, base + 1, 16);
-                        const double s2 = __shfl(vc, base + 2, 16);
-                        const bool knot_ok = is_state || (i < N - 1);
-                        if (cone_base >= 0 && soc_lane && knot_ok) vc = soc_component(s0, s1, s2, cone_c, cone_mu);
-                        GC[i] = soc_lane ? ((GC[i] + xi) - vc) : 0.0;           // :229 / :234
-                        VC[i] = vc;
+                iter = 0; solved = 0;
+                int countdown = P.check_termination;
+                for (int it = 0; it < P.max_iter; ++it) {
+                    // ---- update_linear_cost (lane-local) fused into the backward sweep.
+                    // qv(s): state lanes q_s (s = N-1: the terminal p), input lanes r_{s-1}.
+                    double qhi;
+                    {
+                        double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293 | :280
+                        if constexpr (SOC) t = fma(-rho, VC[N - 1] - GC[N - 1], t); // :295 | :282
+                        qhi = t;
+                        if constexpr (DBG) {
+                            double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
+                            if constexpr (SOC) ql = fma(-rho, VC[N - 1] - GC[N - 1], ql);
+                            Qd[N - 1] = is_state ? ql : t;
+                            Pd[N - 1] = t;
+                        }
                     }
-                }
-                iter += 1;                                                      // :394
-                // ---- termination_condition, admm.cpp:310-328
-                bool conv = false;
-                if (countdown > 0 && --countdown == 0) {
-                    countdown = P.check_termination;
-                    checked = 1;
-                    rp = pmax;
-                    rd = dmax * rho;
-                    const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
-                    const unsigned long long bal = __ballot(ok);
-                    conv = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
-                }
-                if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)
+                    double pcur = qhi;                         // p_{N-1} on state lanes
+                    // ---- backward_pass_grad, admm.cpp:13-20
 #pragma unroll
-                for (int i = 0; i < N; ++i) VP[i] = VN[i];                      // :445-446
+                    for (int i = N - 2; i >= 0; --i) {
+                        double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
+                        if constexpr (SOC) qlo = fma(-rho, VC[i] - GC[i], qlo);     // :269 | :282
+                        // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
+                        const double res = ring_sum2<MODE, NX, NU>(fma(qlo, smask, cb), pcur, mb, qhi, mb + NX);
+                        pcur = res;                                                 // p_i | d_i
+                        Dn[i] = res * nim;                                          // -d_i on input lanes, 0 elsewhere
+                        if constexpr (DBG) { Qd[i] = qlo; Pd[i] = res; Dd[i + 1] = res; }
+                        qhi = qlo;
+                    }
+                    // ---- forward_pass (admm.cpp:25-32) with update_slack + update_dual + the residual maxima
+                    // (admm.cpp:81-135, 219-235, 314-317) of slot i+1 issued right behind the step that produced it:
+                    // the lane-local element-wise work (and its LDS bound reads) fills the dependency stalls of
+                    // the next step's FMA chain instead of forming a separate, latency-exposed phase.
+                    double pmax = 0.0, dmax = 0.0;
+                    auto slot_update = [&](const int s, const double lo, const double hi) {
+                        const double xi = X[s];
+                        const double t = xi + G[s];                                 // :85 / :88
+                        const double vn = vmin64(hi, vmax64(lo, t));                // :91-98
+                        pmax = fmax(pmax, fabs(xi - vn));
+                        dmax = fmax(dmax, fabs(VP[s] - vn));
+                        G[s] = (G[s] + xi) - vn;                                    // :222 / :225
+                        VN[s] = vn;
+                        if constexpr (SOC) {
+                            double vc = soc_lane ? (xi + GC[s]) : 0.0;              // :102-109
+                            const int base = (cone_base >= 0) ? cone_base : j;
+                            const double s0 = __shfl(vc, base, 16);
+                            const double s1 = __shfl(vc, base + 1, 16);
+                            const double s2 = __shfl(vc, base + 2, 16);
+                            const bool knot_ok = is_state || (s >= 1);
+                            if (cone_base >= 0 && soc_lane && knot_ok) vc = soc_component(s0, s1, s2, cone_c, cone_mu);
+                            GC[s] = soc_lane ? ((GC[s] + xi) - vc) : 0.0;           // :229 / :234
+                            VC[s] = vc;
+                        }
+                    };
+                    // Software pipeline: the box bounds of slot i+1 are read from LDS one whole step before
+                    // they are used (sched_barrier pins the reads above the step), and slot i's update is
+                    // scheduled together with the FMA chain of step i -- both only need x_i.
+                    double lo_c = sLo[j], hi_c = sHi[j];
+#pragma unroll
+                    for (int i = 0; i < N - 1; ++i) {
+                        const double lo_n = sLo[(i + 1) * 16 + j], hi_n = sHi[(i + 1) * 16 + j];
+                        __builtin_amdgcn_sched_barrier(0);
+                        const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // A x_i | u_i = -Kinf x_i - d_i
+                        X[i + 1] = ring_short<MODE, NX, NU>(t + cf, t, mf2);        // x_{i+1} = A x_i + f + B u_i | u_i (slot i+1)
+                        slot_update(i, lo_c, hi_c);
+                        lo_c = lo_n; hi_c = hi_n;
+                    }
+                    slot_update(N - 1, lo_c, hi_c);
+                    iter += 1;                                                      // :394
+                    // ---- termination_condition, admm.cpp:310-328
+                    bool conv = false;
+                    if (countdown > 0 && --countdown == 0) {
+                        countdown = P.check_termination;
+                        checked = 1;
+                        rp = pmax;
+                        rd = dmax * rho;
+                        const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
+                        const unsigned long long bal = __ballot(ok);
+                        conv = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
+                    }
+                    if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)
+#pragma unroll
+                    for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446
+                }
+                acc_iter += (unsigned)iter;
+                acc_solved += (unsigned)solved;
+                if (nsteps > 1) {
+                    if (P.iter_log && j == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
+                    if (P.u0_log && is_input) P.u0_log[((size_t)step * P.batch + b) * NU + (j - NX)] = X[1];
+                    x0v = X[1];                               // plant step x0 <- A x0 + B u_0 + f  (== forward_pass x_1)
+                }
             }
 
             // ---- write back (coalesced) -------------------------------------------------------
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const bool valid = used && (is_state || i < N - 1);
-                const size_t off = rec + i * NZ + j;
+            for (int s = 0; s < N; ++s) {
+                const bool valid = is_state || (is_input && s >= 1);
+                const size_t off = lbase + s * NZ;
                 if (valid) {
-                    P.prim[off] = X[i];
-                    P.slack[off] = VN[i];
-                    P.dual[off] = G[i];
-                    P.slack_prev[off] = VP[i];
+                    P.prim[off] = X[s];
+                    P.slack[off] = VN[s];
+                    P.dual[off] = G[s];
+                    P.slack_prev[off] = VP[s];
                     if constexpr (SOC) {
-                        P.cslack[off] = VC[i];
-                        P.cdual[off] = GC[i];
+                        P.cslack[off] = VC[s];
+                        P.cdual[off] = GC[s];
                     }
                     if constexpr (DBG) {
                         if (P.dbg_qr) {
-                            P.dbg_qr[off] = Qd[i];     // work->q | work->r
-                            P.dbg_pd[off] = Pd[i];     // work->p | work->d
+                            P.dbg_qr[off] = Qd[s];                          // work->q | work->r
+                            P.dbg_pd[off] = is_state ? Pd[s] : Dd[s];       // work->p | work->d
                         }
                     }
                 }
@@ -378,8 +487,8 @@ __global__ __launch_bounds__(64) void admm_solve_kernel(const SolveArgs P) {
                 *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = rr;
                 if (P.accum) {
                     uint2 ac = P.accum[b];
-                    ac.x += (unsigned)iter;
-                    ac.y += (unsigned)solved;
+                    ac.x += acc_iter;
+                    ac.y += acc_solved;
                     P.accum[b] = ac;
                 }
             }

@@ -80,17 +80,14 @@ __global__ __launch_bounds__(256) void reduce_stats_kernel(const int4* __restric
 typedef void (*SolveKernel)(const SolveArgs);
 struct KernelEntry {
     int nx, nu, N;
-    SolveKernel k[2][2][2];   // [soc][dbg][dpp_mode]
+    SolveKernel k[2][2][3];   // [soc][dbg][dpp_mode]
 };
+#define KERNELS_MODES(NX, NU, NN, S, D)                                                          \
+    { admm_solve_kernel<NX, NU, NN, S, D, 0>, admm_solve_kernel<NX, NU, NN, S, D, 1>,              \
+      admm_solve_kernel<NX, NU, NN, S, D, 2> }
 #define KERNELS_FOR(NX, NU, NN)                                                                   \
-    { NX, NU, NN, { { { admm_solve_kernel<NX, NU, NN, false, false, 0>,                           \
-                        admm_solve_kernel<NX, NU, NN, false, false, 1> },                         \
-                      { admm_solve_kernel<NX, NU, NN, false, true, 0>,                            \
-                        admm_solve_kernel<NX, NU, NN, false, true, 1> } },                        \
-                    { { admm_solve_kernel<NX, NU, NN, true, false, 0>,                            \
-                        admm_solve_kernel<NX, NU, NN, true, false, 1> },                          \
-                      { admm_solve_kernel<NX, NU, NN, true, true, 0>,                             \
-                        admm_solve_kernel<NX, NU, NN, true, true, 1> } } } }
+    { NX, NU, NN, { { KERNELS_MODES(NX, NU, NN, false, false), KERNELS_MODES(NX, NU, NN, false, true) },   \
+                    { KERNELS_MODES(NX, NU, NN, true, false), KERNELS_MODES(NX, NU, NN, true, true) } } }
 static const KernelEntry g_kernels[] = {
 #include "kernel_dims.inc"
 };
@@ -183,11 +180,11 @@ static void build_tables(TinyBatch* b) {
                 lo[i * 16 + j] = b->x_min[(size_t)i * nx + j];
                 hi[i * 16 + j] = b->x_max[(size_t)i * nx + j];
             }
-    if (b->set.en_input_bound && b->have_bounds)
+    if (b->set.en_input_bound && b->have_bounds)     // input lanes keep knot i in slot i+1 (admm_kernel.hip.h)
         for (int i = 0; i < N - 1; ++i)
             for (int a = 0; a < nu; ++a) {
-                lo[i * 16 + nx + a] = b->u_min[(size_t)i * nu + a];
-                hi[i * 16 + nx + a] = b->u_max[(size_t)i * nu + a];
+                lo[(i + 1) * 16 + nx + a] = b->u_min[(size_t)i * nu + a];
+                hi[(i + 1) * 16 + nx + a] = b->u_max[(size_t)i * nu + a];
             }
 }
 
@@ -212,7 +209,20 @@ int launch_solve(TinyBatch* b) {
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
     a.status = b->d_status; a.resid = b->d_resid;
-    a.x0_next = b->advance_x0 ? b->d_x0 : nullptr;
+    const int steps = b->steps_per_launch > 1 ? b->steps_per_launch : 1;
+    a.steps = steps;
+    a.x0_next = (b->advance_x0 || steps > 1) ? b->d_x0 : nullptr;     // fused steps imply the plant step
+    a.iter_log = nullptr; a.u0_log = nullptr;
+    if (steps > 1 && b->step_log) {
+        if (b->log_steps < steps) {
+            if (b->d_iter_log) hipFree(b->d_iter_log);
+            if (b->d_u0_log) hipFree(b->d_u0_log);
+            HIP_TRY(b, hipMalloc(&b->d_iter_log, (size_t)steps * b->batch * sizeof(int)));
+            HIP_TRY(b, hipMalloc(&b->d_u0_log, (size_t)steps * b->batch * b->nu * sizeof(double)));
+            b->log_steps = steps;
+        }
+        a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
+    }
     a.dbg_qr = b->debug ? b->d_dbg_qr : nullptr;
     a.dbg_pd = b->debug ? b->d_dbg_pd : nullptr;
     a.accum = b->d_accum;
@@ -224,7 +234,7 @@ int launch_solve(TinyBatch* b) {
         const long cap = (long)b->num_cus * b->grid_waves_per_cu;
         if (cap < grid) grid = (int)cap;
     }
-    SolveKernel k = b->kernel->k[soc ? 1 : 0][b->debug ? 1 : 0][b->dpp_mode ? 1 : 0];
+    SolveKernel k = b->kernel->k[soc ? 1 : 0][b->debug ? 1 : 0][(b->dpp_mode >= 0 && b->dpp_mode <= 2) ? b->dpp_mode : 0];
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, b->stream, a);
@@ -353,7 +363,8 @@ int tiny_batch_destroy(TinyBatch* b) {
     hipSetDevice(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
     void* bufs[] = {b->d_ref, b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual, b->d_x0,
-                    b->d_stage, b->d_status, b->d_resid, b->d_stats, b->d_tab, b->d_dbg_qr, b->d_dbg_pd, b->d_accum};
+                    b->d_stage, b->d_status, b->d_resid, b->d_stats, b->d_tab, b->d_dbg_qr, b->d_dbg_pd, b->d_accum,
+                    b->d_iter_log, b->d_u0_log};
     for (void* p : bufs)
         if (p) hipFree(p);
     for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
@@ -557,6 +568,8 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
         if (b->debug) { if (int rc = ensure_debug_buffers(b)) return rc; }
     } else if (!strcmp(name, "grid_waves_per_cu")) b->grid_waves_per_cu = (int)value;
     else if (!strcmp(name, "dpp_mode")) b->dpp_mode = (int)value;
+    else if (!strcmp(name, "steps_per_launch")) b->steps_per_launch = (int)value;
+    else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "timing")) {
         HIP_TRY(b, hipStreamSynchronize(b->stream));
         while ((long)b->ev_start.size() < value) {
@@ -586,6 +599,16 @@ int tiny_batch_get_timing(TinyBatch* b, float* ms, int capacity) {
     for (int i = 0; i < b->timing_n && i < capacity; ++i)
         HIP_TRY(b, hipEventElapsedTime(&ms[i], b->ev_start[i], b->ev_stop[i]));
     return b->timing_n;
+}
+
+int tiny_batch_get_step_log(TinyBatch* b, int* iters, double* u0, int steps) {
+    if (!b) return TINY_ERR_NULL;
+    if (steps > b->log_steps || !b->d_iter_log) return fail(b, TINY_ERR_ARG, "no step log recorded (set_option step_log/steps_per_launch)");
+    HIP_TRY(b, hipSetDevice(b->device));
+    if (iters) HIP_TRY(b, hipMemcpyAsync(iters, b->d_iter_log, (size_t)steps * b->batch * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    if (u0) HIP_TRY(b, hipMemcpyAsync(u0, b->d_u0_log, (size_t)steps * b->batch * b->nu * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    return TINY_OK;
 }
 
 long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold) {

@@ -41,12 +41,16 @@ struct TinyBatch {
            *d_stage = nullptr, *d_stats = nullptr, *d_dbg_qr = nullptr, *d_dbg_pd = nullptr;
     int4* d_status = nullptr;
     uint2* d_accum = nullptr;
+    int* d_iter_log = nullptr;
+    double* d_u0_log = nullptr;
+    int log_steps = 0;
     size_t stage_doubles = 0;
     std::vector<double> h_tab;
     bool tab_dirty = true;
     // options
     bool advance_x0 = false, debug = false;
-    int grid_waves_per_cu = 0, dpp_mode = 0;
+    int grid_waves_per_cu = 0, dpp_mode = 0, steps_per_launch = 1;
+    bool step_log = false;
     // timing
     std::vector<hipEvent_t> ev_start, ev_stop;
     int timing_n = 0, timing_left = 0;
