@@ -40,12 +40,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=65536, help="instances PER GPU")
     ap.add_argument("--grid-waves-per-cu", type=int, default=int(os.environ.get("TINYMPC_GRID_WAVES_PER_CU", "0")))
-    ap.add_argument("--dpp-mode", type=int, default=int(os.environ.get("TINYMPC_DPP_MODE", "0")))
-    ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("TINYMPC_STEPS_PER_LAUNCH", "1")),
-                    help="closed-loop MPC steps fused into one kernel launch (state stays in registers)")
+    ap.add_argument("--dpp-mode", type=int, default=int(os.environ.get("TINYMPC_DPP_MODE", "2")))
+    ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("TINYMPC_STEPS_PER_LAUNCH", "0")),
+                    help="closed-loop MPC steps fused into one kernel launch (ADMM state stays in registers); "
+                         "0 = auto: the largest divisor of --steps and --warmup that is <= 100; 1 = one launch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -67,12 +68,13 @@ def main():
     import numpy as np
     import torch
     import tinympc_amd as tm
+    from tinympc_amd.distributed import allreduce_stats
 
     if not torch.cuda.is_available() or tm.device_count() == 0:
         sys.exit("bench.py needs an MI355X: tinympc_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TINYMPC_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
@@ -86,7 +88,13 @@ def main():
     s.set_option("advance_x0", 1)
     s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
     s.set_option("dpp_mode", args.dpp_mode)
-    T = max(1, args.steps_per_launch)
+    T = args.steps_per_launch
+    if T <= 0:
+        import math
+        T = math.gcd(args.steps, args.warmup) if args.warmup else args.steps
+        while T > 100:                          # keep launches at <= 100 MPC steps (the reference episode length)
+            T = next(d for d in range(T // 2, 0, -1) if T % d == 0)
+    T = max(1, T)
     if args.steps % T or (args.warmup % T and args.warmup):
         sys.exit("--steps and --warmup must be multiples of --steps-per-launch")
     s.set_option("steps_per_launch", T)
@@ -120,21 +128,15 @@ def main():
             s.solve_async()
         s.reduce_stats_async(stats.data_ptr())
         if dist is not None:                         # the one collective of the path: residual / count all-reduce
-            counts = stats[[0, 1, 2, 7, 8]].contiguous()
-            resid = stats[3:7].contiguous()
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-            dist.all_reduce(resid, op=dist.ReduceOp.MAX)
+            stats = allreduce_stats(stats, dist)     # RCCL over xGMI: SUM of counts, MAX of residuals
         barrier()
         elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        acc_iters, acc_solved = float(counts[3].item()), float(counts[4].item())
-        max_resid = [float(v) for v in resid.tolist()]
-    else:
-        st = stats.tolist()
-        acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]
+    st = stats.tolist()
+    acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]
 
     kern_ms = s.timing_ms()
     solves = float(world) * B * args.steps

@@ -136,8 +136,8 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
 /* ---- plumbing ---------------------------------------------------------------------------- */
 /* Options: "advance_x0" (1: each solve also writes x0 <- A x0 + B u[:,0] + f, the plant step of
  * the examples' closed loop, examples/quadrotor_hovering.cpp:92), "debug" (1: keep q,r,p,d),
- * "grid_waves_per_cu" (persistent-grid size, 0 = one wave per tile), "dpp_mode" (0 fused
- * v_fmac_f64_dpp, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves),
+ * "grid_waves_per_cu" (persistent-grid size, 0 = one wave per tile), "dpp_mode" (2 [default] fused
+ * v_fmac_f64_dpp on one accumulator chain, 0 the same on two chains, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves),
  * "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
  * x0 <- A x0 + B u[:,0] + f, solve, ... -- inside ONE launch with the ADMM state held in registers;
  * references stay fixed during the launch), "step_log" (1: keep per-step iteration counts / u0). */

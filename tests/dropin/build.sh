@@ -1,0 +1,31 @@
+#!/bin/bash
+# Drop-in boundary check: compile the REFERENCE's own example mains
+# (by path, nothing copied) against the REFERENCE's headers, but link them against
+# libtinympc_amd.so instead of libtinympcstatic.a.  Needs /root/reference, so it only runs in the
+# build container; the binaries land in tests/dropin/_build/ (git-ignored, travel to the GPU box).
+#   build.sh           -> tests/dropin/_build/<example>          (linked against OUR library)
+#   build.sh --golden  -> also builds each example against the real reference sources and records
+#                         its stdout in tests/golden/stdout_<example>.txt
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
+REF=${TINYMPC_REFERENCE:-/root/reference}
+[ -d "$REF/examples" ] || { echo "no $REF: keeping prebuilt binaries"; exit 0; }
+OUT=$HERE/_build; mkdir -p "$OUT"
+INC="-I$REF/src -I$REF/include/Eigen -I$REF/include -I$REF/examples"
+# default alignment flags on purpose: Eigen must use plain malloc/free (SURVEY.md 8(b) ownership row)
+CXXFLAGS="-O2 -DNDEBUG -std=c++17 -w"
+EXAMPLES="cartpole_example quadrotor_hovering quadrotor_tracking rocket_landing_mpc"
+for ex in $EXAMPLES; do
+  g++ $CXXFLAGS $INC -o "$OUT/$ex" "$REF/examples/$ex.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
+      -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
+done
+wait
+if [ "$1" = "--golden" ]; then
+  for ex in $EXAMPLES; do
+    g++ $CXXFLAGS $INC -o "$OUT/ref_$ex" "$REF/examples/$ex.cpp" "$REF/src/tinympc/admm.cpp" \
+        "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp" &
+  done
+  wait
+  for ex in $EXAMPLES; do (cd "$OUT" && ./ref_$ex > "$ROOT/tests/golden/stdout_$ex.txt"); rm -f "$OUT/ref_$ex"; done
+fi
+ls -la "$OUT"

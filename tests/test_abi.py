@@ -1,0 +1,155 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/tinympc_amd.h
+declares, fails loudly without a GPU, and its HOST logic (tiny_setup / cache precompute / setters over the
+plain-data struct mirrors) reproduces the reference.  No compute calls that need a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import pod
+import scenarios as sc
+import tinympc_amd as tm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HEADER = os.path.join(ROOT, "include", "tinympc_amd.h")
+REF = "/root/reference"
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:tiny_\w+)|solve)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 34, names
+    L = tm.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/tinympc_amd.h but not exported by libtinympc_amd.so"
+    assert set(tm.BATCH_SYMBOLS) | set(tm.REFERENCE_SYMBOLS) == set(names)
+
+
+def test_struct_sizes_match_reference_layout():
+    """sizes/offsets measured on the reference's types.hpp (Eigen 3.4.90, x86-64)."""
+    assert C.sizeof(pod.Mat) == 24 and C.sizeof(pod.Vec) == 16
+    assert C.sizeof(pod.TinySolution) == 56 and C.sizeof(pod.TinyCache) == 280
+    assert C.sizeof(pod.TinySettings) == 88 and C.sizeof(pod.TinyWorkspace) == 1328 and C.sizeof(pod.TinySolver) == 32
+    W = pod.TinyWorkspace
+    for name, off in (("x", 16), ("x_min", 304), ("numStateCones", 400), ("cx", 408), ("vc", 504), ("Alin_x", 656),
+                      ("vl", 736), ("numtvStateLinear", 880), ("vl_tv", 984), ("Q", 1128), ("Adyn", 1160),
+                      ("Xref", 1224), ("Qu", 1272), ("primal_residual_state", 1288), ("status", 1320), ("iter", 1324)):
+        assert getattr(W, name).offset == off, name
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/src/tinympc"), reason="needs the reference headers")
+def test_layout_against_the_real_reference_header(tmp_path):
+    """offsetof/sizeof from the reference's OWN types.hpp vs the plain-data mirrors of our header."""
+    fields = ["x", "u", "vnew", "x_min", "numStateCones", "cx", "Acx", "vc", "numStateLinear", "Alin_x", "blin_x", "vl",
+              "numtvStateLinear", "tv_Alin_x", "vl_tv", "Q", "R", "Adyn", "fdyn", "Xref", "Uref", "Qu",
+              "primal_residual_state", "status", "iter"]
+    body = "".join(f'printf("{f} %zu\\n", offsetof(TinyWorkspace, {f}));' for f in fields)
+    prog = ("#include <cstdio>\n#include <cstddef>\n#include \"@INC@\"\nint main(){"
+            "printf(\"sizes %zu %zu %zu %zu %zu\\n\", sizeof(TinySolution), sizeof(TinyCache), sizeof(TinySettings),"
+            " sizeof(TinyWorkspace), sizeof(TinySolver));" + body + "return 0;}")
+    outs = []
+    for tag, inc, flags in (("ref", "tinympc/types.hpp", ["-I" + REF + "/src", "-I" + REF + "/include/Eigen", "-I" + REF + "/include"]),
+                            ("ours", HEADER, [])):
+        src = tmp_path / f"{tag}.cpp"
+        src.write_text(prog.replace("@INC@", inc))
+        exe = tmp_path / tag
+        subprocess.check_call(["g++", "-std=c++17", "-w", "-Wno-invalid-offsetof", *flags, str(src), "-o", str(exe)])
+        outs.append(subprocess.check_output([str(exe)]).decode())
+    assert outs[0] == outs[1], f"layout drift:\n{outs[0]}\nvs\n{outs[1]}"
+
+
+def test_no_gpu_fails_loudly():
+    if tm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    prob, _ = tm.load_problem("cartpole")
+    with pytest.raises(tm.TinyMPCError, match="no CPU fallback"):
+        tm.TinyBatchSolver.from_problem(prob, 8)
+
+
+def _setup(name, N=None, verbose=0):
+    L = tm.lib()
+    prob, extra = sc.load_problem(name)
+    nx, nu, N = prob["nx"], prob["nu"], N or prob["N"]
+    keep = []
+    A, k = pod.mat(prob["A"]); keep.append(k)
+    B, k = pod.mat(prob["B"]); keep.append(k)
+    f, k = pod.mat(prob["f"]); keep.append(k)
+    Q, k = pod.mat(np.diag(prob["Q"])); keep.append(k)
+    R, k = pod.mat(np.diag(prob["R"])); keep.append(k)
+    sp = C.POINTER(pod.TinySolver)()
+    L.tiny_setup.argtypes = [C.POINTER(C.POINTER(pod.TinySolver))] + [C.POINTER(pod.Mat)] * 5 + [C.c_double] + [C.c_int] * 4
+    rc = L.tiny_setup(C.byref(sp), C.byref(A), C.byref(B), C.byref(f), C.byref(Q), C.byref(R), prob["rho"], nx, nu, N, verbose)
+    return L, sp, prob, extra, rc
+
+
+@pytest.mark.parametrize("name", ["codegen_random", "cartpole", "quadrotor_20hz", "rocket_landing_20hz"])
+def test_tiny_setup_host_logic_matches_reference_cache(name):
+    """tiny_setup + tiny_precompute_and_set_cache (host, no GPU): cache vs the reference's (golden KAT)."""
+    L, sp, prob, _, rc = _setup(name)
+    assert rc == 0
+    kat = np.load(os.path.join(GOLDEN, "cache_kat.npz"))
+    s = sp.contents
+    for k in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "APf", "BPf"):
+        got = pod.to_np(getattr(s.cache.contents, k)).reshape(kat[f"{name}.{k}"].shape)
+        err = np.max(np.abs(got - kat[f"{name}.{k}"])) / max(np.max(np.abs(kat[f"{name}.{k}"])), 1e-300)
+        assert err < 1e-12, (name, k, err)
+    w = s.work.contents
+    assert np.allclose(pod.to_np(w.Q), prob["Q"] + prob["rho"]) and np.allclose(pod.to_np(w.R), prob["R"] + prob["rho"])
+    assert np.array_equal(pod.to_np(s.cache.contents.C1), pod.to_np(s.cache.contents.Quu_inv))     # tiny_api.cpp:375
+    st = s.settings.contents
+    assert (st.abs_pri_tol, st.max_iter, st.check_termination, st.en_state_bound, st.en_state_soc, st.adaptive_rho) == \
+        (1e-3, 1000, 1, 1, 0, 0)
+    assert (w.x.rows, w.x.cols, w.u.rows, w.u.cols, w.Xref.cols) == (prob["nx"], prob["N"], prob["nu"], prob["N"] - 1, prob["N"])
+    # setters
+    L.tiny_set_x0.argtypes = [C.POINTER(pod.TinySolver), C.POINTER(pod.Vec)]
+    x0, k0 = pod.vec(np.arange(1, prob["nx"] + 1))
+    assert L.tiny_set_x0(sp, C.byref(x0)) == 0
+    assert np.array_equal(pod.to_np(w.x)[:, 0], np.arange(1, prob["nx"] + 1)) and np.all(pod.to_np(w.x)[:, 1:] == 0)
+    L.tiny_set_bound_constraints.argtypes = [C.POINTER(pod.TinySolver)] + [C.POINTER(pod.Mat)] * 4
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    ms = [pod.mat(np.full(shp, v)) for shp, v in (((nx, N), -1.0), ((nx, N), 2.0), ((nu, N - 1), -3.0), ((nu, N - 1), 4.0))]
+    assert L.tiny_set_bound_constraints(sp, *[C.byref(m[0]) for m in ms]) == 0
+    assert np.all(pod.to_np(w.u_max) == 4.0) and w.x_min.rows == nx
+    L.tiny_update_settings.argtypes = [C.POINTER(pod.TinySettings), C.c_double, C.c_double] + [C.c_int] * 10
+    assert L.tiny_update_settings(s.settings, 2e-3, 1e-4, 77, 3, 0, 1, 0, 1, 0, 0, 0, 0) == 0
+    assert (st.abs_pri_tol, st.abs_dua_tol, st.max_iter, st.check_termination, st.en_state_bound, st.en_input_soc) == \
+        (2e-3, 1e-4, 77, 3, 0, 1)
+    L.tiny_destroy.argtypes = [C.POINTER(pod.TinySolver)]
+    assert L.tiny_destroy(sp) == 0
+
+
+def test_tiny_setup_rejects_bad_dimensions(capfd):
+    L = tm.lib()
+    A, k1 = pod.mat(np.eye(3)); B, k2 = pod.mat(np.ones((4, 1))); f, k3 = pod.mat(np.zeros(4))
+    Q, k4 = pod.mat(np.eye(4)); R, k5 = pod.mat(np.eye(1))
+    sp = C.POINTER(pod.TinySolver)()
+    L.tiny_setup.argtypes = [C.POINTER(C.POINTER(pod.TinySolver))] + [C.POINTER(pod.Mat)] * 5 + [C.c_double] + [C.c_int] * 4
+    assert L.tiny_setup(C.byref(sp), C.byref(A), C.byref(B), C.byref(f), C.byref(Q), C.byref(R), 1.0, 4, 1, 10, 0) == 1
+    assert "State transition matrix (A) has 3 rows. Expected 4." in capfd.readouterr().out     # tiny_api.cpp:13-19
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "tests", "dropin", "_build", "cartpole_example")),
+                    reason="drop-in binaries not built (tests/dropin/build.sh needs /root/reference)")
+@pytest.mark.parametrize("ex", ["cartpole_example", "quadrotor_hovering", "rocket_landing_mpc"])
+def test_dropin_example_setup_output_matches_reference(ex):
+    """The reference's own example main(), compiled against the reference's headers and linked against
+    libtinympc_amd.so: everything it prints during tiny_setup (verbose cache dump, Eigen IOFormat) must equal
+    the reference's stdout.  (The solves need a GPU: tests/test_gpu_dropin.py.)"""
+    if tm.device_count() > 0:
+        pytest.skip("full run covered by the GPU test")
+    exe = os.path.join(ROOT, "tests", "dropin", "_build", ex)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    gold = open(os.path.join(GOLDEN, f"stdout_{ex}.txt")).read()
+    marker = "Precomputation finished!\n\n"
+    assert marker in p.stdout and marker in gold
+    assert p.stdout.split(marker)[0] == gold.split(marker)[0]
+    assert "no CPU path" in p.stderr or "has no CPU" in p.stderr       # the solves refuse to run without a GPU

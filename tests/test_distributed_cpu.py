@@ -1,0 +1,69 @@
+"""World-size-2 CPU (gloo) test of the multi-GPU path: batch sharding and the one statistics all-reduce
+(the RCCL collective of bench.py).  The per-rank "solve" is played by the plain-C
+oracle here (test infrastructure only); on GPUs each rank runs libtinympc_amd.so on its shard."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tinympc_amd.distributed import allreduce_stats, shard_bounds, shard_indices
+
+
+def test_sharding_covers_everything_once():
+    for total in (1, 7, 64, 65536, 1000003):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_bounds(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+            if total < 100:
+                inter = sorted(i for r in range(world) for i in shard_indices(total, r, world, interleaved=True))
+                assert inter == list(range(total))
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import scenarios as sc
+    from cpu_solvers import OracleSolver
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    suite = sc.tracking_random_suite(B=10, seed=77)
+    lo, hi = shard_bounds(10, rank, world)
+    mine = dict(problem=suite["problem"], config=suite["config"], cases={k: v[lo:hi] for k, v in suite["cases"].items()})
+    out = sc.run_cases(OracleSolver, mine)
+    n = hi - lo
+    stats = torch.tensor([out["iter"].sum(), out["sol_solved"].sum(), n, out["primal_residual_state"].max(),
+                          out["primal_residual_input"].max(), out["dual_residual_state"].max(),
+                          out["dual_residual_input"].max(), out["iter"].sum(), out["sol_solved"].sum(), 0.0],
+                         dtype=torch.float64)
+    total = allreduce_stats(stats, dist)
+    q.put((rank, total.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_stats_allreduce_matches_single_process():
+    import torch.multiprocessing as mp
+    import scenarios as sc
+    from cpu_solvers import OracleSolver
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = sc.run_cases(OracleSolver, sc.tracking_random_suite(B=10, seed=77))
+    expect = [ref["iter"].sum(), ref["sol_solved"].sum(), 10, ref["primal_residual_state"].max(),
+              ref["primal_residual_input"].max(), ref["dual_residual_state"].max(), ref["dual_residual_input"].max(),
+              ref["iter"].sum(), ref["sol_solved"].sum(), 0.0]
+    assert np.allclose(res[0], expect) and res[0] == res[1]

@@ -215,3 +215,27 @@ def test_tracking_full_batch_properties():
     assert solved.mean() > 0.99
     assert np.all(out["primal_residual_state"][solved] < 1e-3) and np.all(out["dual_residual_input"][solved] < 1e-3)
     assert np.all(np.abs(out["znew"]) <= 0.5 + 1e-15) and np.all(np.abs(out["vnew"]) <= 5 + 1e-15)
+
+
+def test_rocket_soc_full_batch_properties():
+    """BASELINE config 4 at full per-job size: 65 536 rocket-landing instances with the second-order-cone
+    thrust constraint on, perturbed initial states.  The first 128 are checked against the oracle; all of
+    them through properties of the cone projection: zcnew lies inside the cone ||u_xy|| <= mu * u_z
+    (up to rounding), box slack inside the box, iteration counts in range."""
+    B = 65536
+    base = sc.rocket_random_suite(B=2048, seed=31337)
+    suite = dict(problem=base["problem"], config=base["config"],
+                 cases={k: np.concatenate([v] * (B // 2048), axis=0) for k, v in base["cases"].items()})
+    out = run_cases_hip(suite)
+    ref = sc.run_cases(OracleSolver, dict(problem=base["problem"], config=base["config"],
+                                          cases={k: v[:128] for k, v in base["cases"].items()}))
+    assert np.array_equal(out["iter"][:128].astype(int), ref["iter"].astype(int))
+    for k in ("x", "u", "znew", "zcnew", "yc", "g"):
+        assert rel_err(out[k][:128], ref[k]) < RTOL, k
+    assert np.array_equal(out["iter"][:2048], out["iter"][-2048:])
+    zc = out["zcnew"]                                    # [B, 3, N-1]
+    mu = float(np.float32(base["config"]["input_cone"][2][0]))
+    nrm = np.sqrt(zc[:, 0] ** 2 + zc[:, 1] ** 2)
+    assert np.all(nrm <= mu * zc[:, 2] * (1 + 1e-6) + 1e-9)
+    assert np.all(out["znew"] <= 105 + 1e-12) and np.all(out["znew"] >= -10 - 1e-12)
+    assert out["iter"].min() >= 1 and out["iter"].max() <= 100

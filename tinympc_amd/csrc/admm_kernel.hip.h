@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         const double vn = vmin64(hi, vmax64(lo, t));                // :91-98
                         pmax = fmax(pmax, fabs(xi - vn));
                         dmax = fmax(dmax, fabs(VP[s] - vn));
-                        G[s] = (G[s] + xi) - vn;                                    // :222 / :225
+                        G[s] = t - vn;                      // :222 / :225  g + x - vnew; (g + x) == t bit-for-bit
                         VN[s] = vn;
                         if constexpr (SOC) {
                             double vc = soc_lane ? (xi + GC[s]) : 0.0;              // :102-109

@@ -49,7 +49,7 @@ struct TinyBatch {
     bool tab_dirty = true;
     // options
     bool advance_x0 = false, debug = false;
-    int grid_waves_per_cu = 0, dpp_mode = 0, steps_per_launch = 1;
+    int grid_waves_per_cu = 0, dpp_mode = 2, steps_per_launch = 1;
     bool step_log = false;
     // timing
     std::vector<hipEvent_t> ev_start, ev_stop;
