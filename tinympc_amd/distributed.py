@@ -36,11 +36,9 @@ def allreduce_stats(stats, dist=None, group=None):
         import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return stats.clone()
-    counts = stats[list(COUNT_IDX)].contiguous()
-    resid = stats[list(MAX_IDX)].contiguous()
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(resid, op=dist.ReduceOp.MAX, group=group)
-    out = torch.zeros_like(stats)
-    out[list(COUNT_IDX)] = counts
-    out[list(MAX_IDX)] = resid
-    return out
+    total = stats.clone()
+    peak = stats.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)     # counts
+    dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)      # residual maxima
+    total[MAX_IDX[0]:MAX_IDX[-1] + 1] = peak[MAX_IDX[0]:MAX_IDX[-1] + 1]
+    return total
