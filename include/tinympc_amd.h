@@ -68,6 +68,14 @@ typedef enum {
     TINY_F_R,           /* available after tiny_batch_set_option("debug", 1)   */
     TINY_F_P,
     TINY_F_D,
+    TINY_F_VLNEW,       /* work->vlnew / zlnew / gl / yl: static linear-constraint slack + dual   */
+    TINY_F_ZLNEW,
+    TINY_F_GL,
+    TINY_F_YL,
+    TINY_F_VLNEW_TV,    /* work->vlnew_tv / zlnew_tv / gl_tv / yl_tv: time-varying linear          */
+    TINY_F_ZLNEW_TV,
+    TINY_F_GL_TV,
+    TINY_F_YL_TV,
     TINY_F_COUNT
 } TinyField;
 
@@ -98,8 +106,17 @@ int tiny_batch_set_bound_constraints(TinyBatch* b, const double* x_min, const do
 int tiny_batch_set_cone_constraints(TinyBatch* b, int n_state_cones, const int* Acx, const int* qcx,
                                     const double* cx, int n_input_cones, const int* Acu,
                                     const int* qcu, const double* cu);
-/* == tiny_update_settings (tiny_api.hpp:36-42).  The linear / time-varying-linear switches must
- * be 0 (out of the hot-path scope): non-zero -> TINY_ERR_UNSUPPORTED. */
+/* == tiny_set_linear_constraints (tiny_api.hpp:19-21, tiny_api.cpp:210-251): half-spaces a_k' z <= b_k,
+ * Alin_x is n_state x nx column-major (one ROW per constraint), blin_x n_state; same for the inputs. */
+int tiny_batch_set_linear_constraints(TinyBatch* b, int n_state, const double* Alin_x, const double* blin_x,
+                                      int n_input, const double* Alin_u, const double* blin_u);
+/* == tiny_set_tv_linear_constraints (tiny_api.hpp:22-24, tiny_api.cpp:253-304): counts are PER KNOT POINT;
+ * tv_Alin_x is (n_state*N) x nx column-major (row n_state*i + k = constraint k at knot i), tv_blin_x
+ * n_state x N; tv_Alin_u (n_input*(N-1)) x nu, tv_blin_u n_input x (N-1). */
+int tiny_batch_set_tv_linear_constraints(TinyBatch* b, int n_state, const double* tv_Alin_x, const double* tv_blin_x,
+                                         int n_input, const double* tv_Alin_u, const double* tv_blin_u);
+/* == tiny_update_settings (tiny_api.hpp:36-42).  With a linear / time-varying-linear switch on (or a shape
+ * without a register-resident instantiation) the solve runs the coverage kernel (general_kernel.hip.h). */
 int tiny_batch_update_settings(TinyBatch* b, double abs_pri_tol, double abs_dua_tol, int max_iter,
                                int check_termination, int en_state_bound, int en_input_bound,
                                int en_state_soc, int en_input_soc, int en_state_linear,
@@ -138,7 +155,8 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * the examples' closed loop, examples/quadrotor_hovering.cpp:92), "debug" (1: keep q,r,p,d),
  * "grid_waves_per_cu" (persistent-grid size, 0 = one wave per tile), "dpp_mode" (2 [default] fused
  * v_fmac_f64_dpp on one accumulator chain, 0 the same on two chains, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves),
- * "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
+ * "force_general" (1: use the coverage kernel even when a
+ * register-resident instantiation exists), "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
  * x0 <- A x0 + B u[:,0] + f, solve, ... -- inside ONE launch with the ADMM state held in registers;
  * references stay fixed during the launch), "step_log" (1: keep per-step iteration counts / u0). */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
@@ -248,6 +266,11 @@ int tiny_set_bound_constraints(TinySolver* solver, const TinyMatrixPOD* x_min, c
 int tiny_set_cone_constraints(TinySolver* solver, const TinyVectorXiPOD* Acx, const TinyVectorXiPOD* qcx,
                               const TinyVectorPOD* cx, const TinyVectorXiPOD* Acu,
                               const TinyVectorXiPOD* qcu, const TinyVectorPOD* cu);
+/* tiny_api.hpp:19-24 */
+int tiny_set_linear_constraints(TinySolver* solver, const TinyMatrixPOD* Alin_x, const TinyVectorPOD* blin_x,
+                                const TinyMatrixPOD* Alin_u, const TinyVectorPOD* blin_u);
+int tiny_set_tv_linear_constraints(TinySolver* solver, const TinyMatrixPOD* tv_Alin_x, const TinyMatrixPOD* tv_blin_x,
+                                   const TinyMatrixPOD* tv_Alin_u, const TinyMatrixPOD* tv_blin_u);
 /* tiny_api.hpp:25-27 */
 int tiny_precompute_and_set_cache(TinyCache* cache, const TinyMatrixPOD* Adyn, const TinyMatrixPOD* Bdyn,
                                   const TinyMatrixPOD* fdyn, const TinyMatrixPOD* Q, const TinyMatrixPOD* R,

@@ -71,6 +71,8 @@ class _CpuSolver:
             getattr(lib, p + "free").restype = None
             getattr(lib, p + "set_bounds").argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
             getattr(lib, p + "set_cones").argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp]
+            getattr(lib, p + "set_linear").argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+            getattr(lib, p + "set_tv_linear").argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
             f = getattr(lib, p + "ptr")
             f.restype = _dp
             f.argtypes = [C.c_void_p, C.c_char_p, _ip, _ip]
@@ -130,6 +132,22 @@ class _CpuSolver:
                                     a[2].ctypes.data_as(_dp), len(a[3]), a[3].ctypes.data_as(_ip),
                                     a[4].ctypes.data_as(_ip), a[5].ctypes.data_as(_dp))
 
+    def set_linear(self, Alin_x, blin_x, Alin_u, blin_u):
+        """Static half-spaces a_k' z <= b_k: Alin_x (n_s, nx), blin_x (n_s,), Alin_u (n_i, nu), blin_u (n_i,)."""
+        Ax, Au = np.asarray(Alin_x, dtype=np.float64).reshape(-1, self.nx), np.asarray(Alin_u, dtype=np.float64).reshape(-1, self.nu)
+        a = [_d(Ax), _d(blin_x), _d(Au), _d(blin_u)]
+        return self._f("set_linear")(self.h, Ax.shape[0], a[0].ctypes.data_as(_dp), a[1].ctypes.data_as(_dp),
+                                     Au.shape[0], a[2].ctypes.data_as(_dp), a[3].ctypes.data_as(_dp))
+
+    def set_tv_linear(self, tv_Alin_x, tv_blin_x, tv_Alin_u, tv_blin_u):
+        """Time-varying half-spaces: tv_Alin_x (n_s*N, nx) [row n_s*i+k = constraint k at knot i], tv_blin_x (n_s, N),
+        tv_Alin_u (n_i*(N-1), nu), tv_blin_u (n_i, N-1)."""
+        Ax, Au = np.asarray(tv_Alin_x, dtype=np.float64).reshape(-1, self.nx), np.asarray(tv_Alin_u, dtype=np.float64).reshape(-1, self.nu)
+        bx, bu = np.asarray(tv_blin_x, dtype=np.float64).reshape(-1, self.N), np.asarray(tv_blin_u, dtype=np.float64).reshape(-1, self.N - 1)
+        a = [_d(Ax), _d(bx), _d(Au), _d(bu)]
+        return self._f("set_tv_linear")(self.h, bx.shape[0], a[0].ctypes.data_as(_dp), a[1].ctypes.data_as(_dp),
+                                        bu.shape[0], a[2].ctypes.data_as(_dp), a[3].ctypes.data_as(_dp))
+
     def __getitem__(self, name) -> np.ndarray:
         r, c = C.c_int(), C.c_int()
         p = self._f("ptr")(self.h, name.encode(), C.byref(r), C.byref(c))
@@ -172,6 +190,7 @@ class _CpuSolver:
 
     STATE_FIELDS = ("x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y",
                     "vc", "vcnew", "zc", "zcnew", "gc", "yc")
+    LINEAR_FIELDS = ("vlnew", "zlnew", "gl", "yl", "vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv")
 
     def snapshot(self, fields=None):
         return {k: self[k].copy() for k in (fields or self.STATE_FIELDS)}

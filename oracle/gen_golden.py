@@ -48,11 +48,25 @@ def main():
         "sweep_4_2_10": sc.sweep_suite(4, 2, 10),
         "sweep_8_4_30": sc.sweep_suite(8, 4, 30, B=3),
         "sweep_12_2_10": sc.sweep_suite(12, 2, 10, B=3),
+        "sweep_20_8_10": sc.sweep_suite(20, 8, 10, B=2),
+        "linear_random_all": sc.random_linear_suite("quadrotor_20hz", B=4, seed=21),
+        "linear_random_rocket_soc": sc.random_linear_suite("rocket_landing_20hz", B=4, seed=22, soc=True),
+        "linear_random_tv_only": sc.random_linear_suite("cartpole", B=4, seed=23, static=False, box=False),
     }
+    for tv in (False, True):
+        subs, its, solved = sc.linear_example_suite(RefSolver, tv)
+        for n, sub in enumerate(subs):
+            suites[f"linear_example_{'tv' if tv else 'static'}_{n}"] = sub
+        print("linear example", "tv" if tv else "static", "solved", int(solved.sum()), "of", len(solved),
+              "converged-iteration sum", int(its[solved == 1].sum()))
     slim = ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc")
     for name, suite in suites.items():
         soc = suite["config"]["en_state_soc"] or suite["config"]["en_input_soc"]
         fields = [f for f in slim if soc or f not in ("vcnew", "zcnew", "gc", "yc")]
+        if suite["config"].get("en_state_linear") or suite["config"].get("en_input_linear"):
+            fields += ["vlnew", "zlnew", "gl", "yl"]
+        if suite["config"].get("en_tv_state_linear") or suite["config"].get("en_tv_input_linear"):
+            fields += ["vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv"]
         if name.startswith("random_state"):
             fields += ["q", "r", "p", "d", "sol_x", "sol_u"]
         out = sc.run_cases(RefSolver, suite, fields=fields)

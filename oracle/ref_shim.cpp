@@ -67,6 +67,19 @@ int ref_set_cones(void* hv, int nsc, const int* Acx, const int* qcx, const doubl
     return tiny_set_cone_constraints(s, aAcx, aqcx, acx, aAcu, aqcu, acu);
 }
 
+int ref_set_linear(void* hv, int nsl, const double* Ax, const double* bx, int nil, const double* Au, const double* bu) {
+    TinySolver* s = static_cast<RefHandle*>(hv)->solver;
+    return tiny_set_linear_constraints(s, cm(Ax, nsl, s->work->nx), tinyVector(cm(bx, nsl, 1)),
+                                       cm(Au, nil, s->work->nu), tinyVector(cm(bu, nil, 1)));
+}
+
+int ref_set_tv_linear(void* hv, int ntsl, const double* Ax, const double* bx, int ntil, const double* Au, const double* bu) {
+    TinySolver* s = static_cast<RefHandle*>(hv)->solver;
+    const int nx = s->work->nx, nu = s->work->nu, N = s->work->N;
+    return tiny_set_tv_linear_constraints(s, cm(Ax, ntsl * N, nx), cm(bx, ntsl, N), cm(Au, ntil * (N - 1), nu),
+                                          cm(bu, ntil, N - 1));
+}
+
 double* ref_ptr(void* hv, const char* name, int* rows, int* cols) {
     TinySolver* s = static_cast<RefHandle*>(hv)->solver;
     TinyWorkspace* w = s->work;
@@ -85,6 +98,8 @@ double* ref_ptr(void* hv, const char* name, int* rows, int* cols) {
     M_("x_min", w->x_min) M_("x_max", w->x_max) M_("u_min", w->u_min) M_("u_max", w->u_max)
     M_("vc", w->vc) M_("vcnew", w->vcnew) M_("zc", w->zc) M_("zcnew", w->zcnew) M_("gc", w->gc) M_("yc", w->yc)
     M_("sol_x", s->solution->x) M_("sol_u", s->solution->u)
+    M_("vlnew", w->vlnew) M_("zlnew", w->zlnew) M_("gl", w->gl) M_("yl", w->yl)
+    M_("vlnew_tv", w->vlnew_tv) M_("zlnew_tv", w->zlnew_tv) M_("gl_tv", w->gl_tv) M_("yl_tv", w->yl_tv)
 #undef M_
 #undef V_
     if (m) { if (rows) *rows = (int)m->rows(); if (cols) *cols = (int)m->cols(); return m->data(); }
@@ -103,6 +118,10 @@ double ref_get(void* hv, const char* name) {
     if (n == "en_input_bound") return s->settings->en_input_bound;
     if (n == "en_state_soc") return s->settings->en_state_soc;
     if (n == "en_input_soc") return s->settings->en_input_soc;
+    if (n == "en_state_linear") return s->settings->en_state_linear;
+    if (n == "en_input_linear") return s->settings->en_input_linear;
+    if (n == "en_tv_state_linear") return s->settings->en_tv_state_linear;
+    if (n == "en_tv_input_linear") return s->settings->en_tv_input_linear;
     if (n == "primal_residual_state") return s->work->primal_residual_state;
     if (n == "primal_residual_input") return s->work->primal_residual_input;
     if (n == "dual_residual_state") return s->work->dual_residual_state;
@@ -129,6 +148,10 @@ int ref_set(void* hv, const char* name, double v) {
     else if (n == "en_input_bound") s->settings->en_input_bound = (int)v;
     else if (n == "en_state_soc") s->settings->en_state_soc = (int)v;
     else if (n == "en_input_soc") s->settings->en_input_soc = (int)v;
+    else if (n == "en_state_linear") s->settings->en_state_linear = (int)v;
+    else if (n == "en_input_linear") s->settings->en_input_linear = (int)v;
+    else if (n == "en_tv_state_linear") s->settings->en_tv_state_linear = (int)v;
+    else if (n == "en_tv_input_linear") s->settings->en_tv_input_linear = (int)v;
     else return 1;
     return 0;
 }

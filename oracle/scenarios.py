@@ -23,10 +23,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROBLEMS_JSON = os.path.join(_HERE, "..", "tinympc_amd", "data", "problems.json")
 
-STATE_IN = ("vnew", "g", "v", "x", "gc")       # nx x N
-INPUT_IN = ("znew", "y", "z", "u", "yc")       # nu x (N-1)
-STATE_OUT = ("x", "vnew", "g", "v", "vcnew", "gc", "q", "p", "sol_x")
-INPUT_OUT = ("u", "znew", "y", "z", "zcnew", "yc", "r", "d", "sol_u")
+STATE_IN = ("vnew", "g", "v", "x", "gc", "gl", "gl_tv")       # nx x N
+INPUT_IN = ("znew", "y", "z", "u", "yc", "yl", "yl_tv")       # nu x (N-1)
+STATE_OUT = ("x", "vnew", "g", "v", "vcnew", "gc", "q", "p", "sol_x", "vlnew", "gl", "vlnew_tv", "gl_tv")
+INPUT_OUT = ("u", "znew", "y", "z", "zcnew", "yc", "r", "d", "sol_u", "zlnew", "yl", "zlnew_tv", "yl_tv")
+LINEAR_FLAGS = ("en_state_linear", "en_input_linear", "en_tv_state_linear", "en_tv_input_linear")
 SCALARS_OUT = ("iter", "status", "sol_iter", "sol_solved", "primal_residual_state", "primal_residual_input",
                "dual_residual_state", "dual_residual_input")
 
@@ -47,7 +48,10 @@ def default_config(prob, **kw):
                en_state_bound=1, en_input_bound=1, en_state_soc=0, en_input_soc=0,
                x_min=np.full((nx, N), -1e17), x_max=np.full((nx, N), 1e17),
                u_min=np.full((nu, N - 1), -1e17), u_max=np.full((nu, N - 1), 1e17),
-               state_cone=None, input_cone=None)
+               state_cone=None, input_cone=None,
+               en_state_linear=0, en_input_linear=0, en_tv_state_linear=0, en_tv_input_linear=0,
+               linear=None,        # (Alin_x (ns,nx), blin_x (ns,), Alin_u (ni,nu), blin_u (ni,))
+               tv_linear=None)     # (tv_Alin_x (ns*N,nx), tv_blin_x (ns,N), tv_Alin_u (ni*(N-1),nu), tv_blin_u (ni,N-1))
     cfg.update(kw)
     for k, shp in (("x_min", (nx, N)), ("x_max", (nx, N)), ("u_min", (nu, N - 1)), ("u_max", (nu, N - 1))):
         a = np.asarray(cfg[k], dtype=np.float64)
@@ -75,9 +79,13 @@ def make_solver(cls, prob, cfg):
         sc = sc or ([], [], [])
         ic = ic or ([], [], [])
         s.set_cones(sc[0], sc[1], sc[2], ic[0], ic[1], ic[2])
+    if cfg.get("linear") is not None:
+        s.set_linear(*cfg["linear"])
+    if cfg.get("tv_linear") is not None:
+        s.set_tv_linear(*cfg["tv_linear"])
     for k in ("max_iter", "abs_pri_tol", "abs_dua_tol", "check_termination", "en_state_bound", "en_input_bound",
-              "en_state_soc", "en_input_soc"):
-        s.set(k, cfg[k])
+              "en_state_soc", "en_input_soc") + LINEAR_FLAGS:
+        s.set(k, cfg.get(k, 0))
     return s
 
 
@@ -311,6 +319,83 @@ def random_state_suite(name="quadrotor_20hz", B=8, seed=7, scale=0.3, soc=False)
     return dict(problem=prob, config=cfg, cases=cases)
 
 
+def linear_example_cfg(prob, tv=False, k=0):
+    """examples/quadrotor_linear_constraints.cpp:41-73 / quadrotor_tv_linear_constraints.cpp:41-103: altitude
+    ceiling z <= 3 (time-varying: z <= z_lim(k+i)) and total thrust u1+u2+u3+u4 <= 6, boxes disabled."""
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    NTOTAL = 50
+    ax = np.zeros((1, nx)); ax[0, 2] = 1.0
+    au = np.ones((1, nu))
+    if not tv:
+        return default_config(prob, max_iter=100, en_state_bound=0, en_input_bound=0, en_state_linear=1,
+                              en_input_linear=1, linear=(ax, np.array([3.0]), au, np.array([6.0])))
+    zlim = np.array([1.1 + (3.0 - 1.1) * i / (NTOTAL - N - 1) for i in range(NTOTAL)])
+    return default_config(prob, max_iter=100, en_state_bound=0, en_input_bound=0, en_tv_state_linear=1,
+                          en_tv_input_linear=1,
+                          tv_linear=(np.tile(ax, (N, 1)), zlim[k:k + N].reshape(1, N), np.tile(au, (N - 1, 1)),
+                                     np.full((1, N - 1), 6.0)))
+
+
+def linear_example_suite(cls, tv=False, steps=(0, 1, 5, 20, 39)):
+    """Warm states along the 40-step loop of the (tv_)linear-constraint examples (16 / 17 of
+    40 solves converge, converged-iteration sums 544 / 634).  For tv the bounds change every step, so each case
+    carries its own config; suites returned as a list of single-step suites."""
+    prob, _ = load_problem("quadrotor_20hz")
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    NTOTAL = 50
+    x0 = np.array([-2.0, -2.0, 1.0] + [0.0] * 9)
+    xgoal = np.array([2.0, 2.0, 4.0] + [0.0] * 9)
+    s = make_solver(cls, prob, linear_example_cfg(prob, tv, 0))
+    x = x0.copy()
+    out_suites, iters, solved = [], [], []
+    for k in range(NTOTAL - N):
+        cfg = linear_example_cfg(prob, tv, k)
+        if tv:
+            s.set_tv_linear(*cfg["tv_linear"])
+        for i in range(N):
+            alpha = float(k + i) / (NTOTAL - 1)
+            s["Xref"][:, i] = (1 - alpha) * x0 + alpha * xgoal
+        s["x"][:, 0] = x
+        if k in steps:
+            cases = zero_cases(prob, 1)
+            cases["x0"][0] = x
+            cases["Xref"][0] = s["Xref"]
+            for f in STATE_IN + INPUT_IN:
+                cases[f][0] = s[f]
+            out_suites.append(dict(problem=prob, config=cfg, cases=cases))
+        s.solve()
+        iters.append(int(s.get("sol_iter")))
+        solved.append(int(s.get("sol_solved")))
+        x = prob["A"] @ x + prob["B"] @ s["u"][:, 0]
+    s.close()
+    return out_suites, np.array(iters), np.array(solved)
+
+
+def random_linear_suite(name="quadrotor_20hz", B=6, seed=21, tv=True, static=True, box=True, soc=False):
+    """Every slack family at once on a fully random workspace: box + (cone) + static + time-varying half-spaces,
+    several constraints per knot (sequential projections, admm.cpp:148-211)."""
+    prob, _ = load_problem(name)
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(seed)
+    kw = dict(max_iter=29, en_state_bound=int(box), en_input_bound=int(box),
+              x_min=rng.uniform(-1.0, -0.2, (nx, N)), x_max=rng.uniform(0.2, 1.0, (nx, N)),
+              u_min=rng.uniform(-0.5, -0.1, (nu, N - 1)), u_max=rng.uniform(0.1, 0.5, (nu, N - 1)))
+    if static:
+        kw.update(en_state_linear=1, en_input_linear=1,
+                  linear=(rng.normal(0, 1, (3, nx)), rng.normal(0, 0.3, 3), rng.normal(0, 1, (2, nu)), rng.normal(0, 0.3, 2)))
+    if tv:
+        kw.update(en_tv_state_linear=1, en_tv_input_linear=1,
+                  tv_linear=(rng.normal(0, 1, (2 * N, nx)), rng.normal(0, 0.3, (2, N)),
+                             rng.normal(0, 1, (1 * (N - 1), nu)), rng.normal(0, 0.3, (1, N - 1))))
+    if soc:
+        kw.update(en_state_soc=1, en_input_soc=1, state_cone=([1], [3], [0.7]), input_cone=([0], [3], [0.4]))
+    cfg = default_config(prob, **kw)
+    cases = zero_cases(prob, B)
+    for k, v in cases.items():
+        cases[k] = rng.normal(0.0, 0.3, v.shape)
+    return dict(problem=prob, config=cfg, cases=cases)
+
+
 # ----------------------------------------------------------------------------- (de)serialisation
 
 def save_suite(path, suite, outputs):
@@ -320,7 +405,10 @@ def save_suite(path, suite, outputs):
     for k, v in suite["config"].items():
         if v is None:
             continue
-        if k.endswith("_cone"):
+        if k in ("linear", "tv_linear"):
+            for part, arr in zip(("Ax", "bx", "Au", "bu"), v):
+                flat[f"config.{k}.{part}"] = np.asarray(arr, dtype=np.float64)
+        elif k.endswith("_cone"):
             flat[f"config.{k}.A"] = np.asarray(v[0], dtype=np.int32)
             flat[f"config.{k}.q"] = np.asarray(v[1], dtype=np.int32)
             flat[f"config.{k}.c"] = np.asarray(v[2], dtype=np.float64)
@@ -347,7 +435,7 @@ def load_suite(path):
         if grp == "problem":
             prob[name] = v.item() if v.ndim == 0 else v
         elif grp == "config":
-            if "_cone." in name:
+            if "_cone." in name or name.startswith(("linear.", "tv_linear.")):
                 cn, part = name.split(".")
                 cones.setdefault(cn, {})[part] = v
             else:
@@ -363,6 +451,10 @@ def load_suite(path):
     prob["rho"] = float(prob["rho"])
     for k in ("max_iter", "check_termination", "en_state_bound", "en_input_bound", "en_state_soc", "en_input_soc"):
         cfg[k] = int(cfg[k])
+    for k in LINEAR_FLAGS:
+        cfg[k] = int(cfg.get(k, 0))
+    for k in ("linear", "tv_linear"):
+        cfg[k] = tuple(cones[k][p] for p in ("Ax", "bx", "Au", "bu")) if k in cones else None
     for cn in ("state_cone", "input_cone"):
         cfg[cn] = (cones[cn]["A"], cones[cn]["q"], cones[cn]["c"]) if cn in cones else None
     B = int(cases.pop("B"))

@@ -47,12 +47,21 @@ int oracle_set_cones(OracleSolver* s,
                      int n_state_cones, const int* Acx, const int* qcx, const double* cx,
                      int n_input_cones, const int* Acu, const int* qcu, const double* cu);
 
+/* tiny_set_linear_constraints (tiny_api.cpp:210-251) / tiny_set_tv_linear_constraints (:253-304):
+ * half-spaces a_k' z <= b_k; A matrices column-major, one ROW per constraint; the time-varying
+ * counts are per knot point (tv_Alin_x is (n*N) x nx, tv_blin_x n x N, ...). */
+int oracle_set_linear(OracleSolver* s, int n_state, const double* Alin_x, const double* blin_x,
+                      int n_input, const double* Alin_u, const double* blin_u);
+int oracle_set_tv_linear(OracleSolver* s, int n_state, const double* tv_Alin_x, const double* tv_blin_x,
+                         int n_input, const double* tv_Alin_u, const double* tv_blin_u);
+
 /* Named access to every matrix/vector of TinyCache / TinyWorkspace / TinySolution
  * (names = reference field names; "sol_x"/"sol_u" for TinySolution).  Returns
  * NULL for unknown names. rows/cols may be NULL. */
 double* oracle_ptr(OracleSolver* s, const char* name, int* rows, int* cols);
 /* Named scalar access: settings (abs_pri_tol, abs_dua_tol, max_iter,
- * check_termination, en_state_bound, en_input_bound, en_state_soc, en_input_soc),
+ * check_termination, en_state_bound, en_input_bound, en_state_soc, en_input_soc,
+ * en_state_linear, en_input_linear, en_tv_state_linear, en_tv_input_linear),
  * status (primal_residual_state, ..., status, iter, sol_iter, sol_solved),
  * rho, riccati_iters. */
 double oracle_get(OracleSolver* s, const char* name);

@@ -14,7 +14,7 @@ OUT=$HERE/_build; mkdir -p "$OUT"
 INC="-I$REF/src -I$REF/include/Eigen -I$REF/include -I$REF/examples"
 # default alignment flags on purpose: Eigen must use plain malloc/free (SURVEY.md 8(b) ownership row)
 CXXFLAGS="-O2 -DNDEBUG -std=c++17 -w"
-EXAMPLES="cartpole_example quadrotor_hovering quadrotor_tracking rocket_landing_mpc"
+EXAMPLES="cartpole_example quadrotor_hovering quadrotor_tracking rocket_landing_mpc quadrotor_linear_constraints quadrotor_tv_linear_constraints"
 for ex in $EXAMPLES; do
   g++ $CXXFLAGS $INC -o "$OUT/$ex" "$REF/examples/$ex.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
       -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &

@@ -4,8 +4,12 @@ import numpy as np
 import tinympc_amd as tm
 
 IN_FIELDS = ("Xref", "Uref", "vnew", "znew", "g", "y", "v", "z", "x", "u", "gc", "yc")
+LIN_IN = ("gl", "yl")
+TV_IN = ("gl_tv", "yl_tv")
 OUT_FIELDS = ("x", "u", "vnew", "znew", "g", "y", "v", "z")
 SOC_OUT = ("vcnew", "zcnew", "gc", "yc")
+LIN_OUT = ("vlnew", "zlnew", "gl", "yl")
+TV_OUT = ("vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv")
 
 
 def make_batch(suite, batch=None, replicate=1):
@@ -19,8 +23,14 @@ def make_batch(suite, batch=None, replicate=1):
         sc_ = sc_ or ([], [], [])
         ic_ = ic_ or ([], [], [])
         s.set_cone_constraints(sc_[0], sc_[1], sc_[2], ic_[0], ic_[1], ic_[2])
+    if cfg.get("linear") is not None:
+        s.set_linear_constraints(*cfg["linear"])
+    if cfg.get("tv_linear") is not None:
+        s.set_tv_linear_constraints(*cfg["tv_linear"])
     s.update_settings(cfg["abs_pri_tol"], cfg["abs_dua_tol"], cfg["max_iter"], cfg["check_termination"],
-                      cfg["en_state_bound"], cfg["en_input_bound"], cfg["en_state_soc"], cfg["en_input_soc"])
+                      cfg["en_state_bound"], cfg["en_input_bound"], cfg["en_state_soc"], cfg["en_input_soc"],
+                      cfg.get("en_state_linear", 0), cfg.get("en_input_linear", 0), cfg.get("en_tv_state_linear", 0),
+                      cfg.get("en_tv_input_linear", 0))
     return s
 
 
@@ -34,13 +44,17 @@ def run_cases_hip(suite, replicate=1, debug=False, options=None):
         s.set_option("debug", 1)
     rep = (lambda a: np.concatenate([a] * replicate, axis=0)) if replicate > 1 else (lambda a: a)
     s.set_x0(rep(cases["x0"]))
-    for f in IN_FIELDS:
+    cfg = suite["config"]
+    lin = cfg.get("en_state_linear", 0) or cfg.get("en_input_linear", 0)
+    tvl = cfg.get("en_tv_state_linear", 0) or cfg.get("en_tv_input_linear", 0)
+    for f in IN_FIELDS + (LIN_IN if lin else ()) + (TV_IN if tvl else ()):
         if f in cases:
             s.set(f, rep(cases[f]))
     ret = s.solve()
-    soc = suite["config"]["en_state_soc"] or suite["config"]["en_input_soc"]
-    out = {f: s.get(f) for f in OUT_FIELDS + (SOC_OUT if soc else ())}
-    if debug:
+    soc = cfg["en_state_soc"] or cfg["en_input_soc"]
+    out = {f: s.get(f) for f in OUT_FIELDS + (SOC_OUT if soc else ()) + (LIN_OUT if lin else ()) + (TV_OUT if tvl else ())}
+    general = lin or tvl or (options or {}).get("force_general")
+    if debug or general:
         for f in ("q", "r", "p", "d"):
             out[f] = s.get(f)
     st = s.status()

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "dropin", "_build")
 
 
-@pytest.mark.parametrize("ex", ["cartpole_example", "quadrotor_hovering", "quadrotor_tracking", "rocket_landing_mpc"])
+@pytest.mark.parametrize("ex", ["cartpole_example", "quadrotor_hovering", "quadrotor_tracking", "rocket_landing_mpc",
+                                "quadrotor_linear_constraints", "quadrotor_tv_linear_constraints"])
 def test_reference_example_stdout_identical(ex):
     exe = os.path.join(BUILD, ex)
     if not os.path.exists(exe):

@@ -31,9 +31,9 @@ def rel_err(a, b):
 
 
 def supported(suite):
-    import tinympc_amd as tm
+    """Every shape with nx + nu <= 32 runs: register-resident kernel where instantiated, else the coverage kernel."""
     p = suite["problem"]
-    return (p["nx"], p["nu"], p["N"]) in tm.supported_dims()
+    return p["nx"] + p["nu"] <= 32
 
 
 def assert_match(out, ref, rtol, what):
@@ -61,6 +61,14 @@ def test_hip_matches_reference_golden(name):
     assert worst <= CONTRACT_RTOL
 
 
+@pytest.mark.parametrize("name", SUITES)
+def test_coverage_kernel_matches_reference_golden(name):
+    """force_general = 1: the shape-agnostic coverage kernel (general_kernel.hip.h) on the same fixtures."""
+    suite, ref = sc.load_suite(os.path.join(GOLDEN, name + ".npz"))
+    out = run_cases_hip(suite, options={"force_general": 1})
+    assert_match(out, ref, RTOL, name + " [general]")
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_dpp_modes_agree_with_golden(mode):
     """dpp_mode 0 = fused v_fmac_f64_dpp row_newbcast (two accumulator chains), 2 = one chain,
@@ -79,6 +87,14 @@ def test_dpp_modes_agree_with_golden(mode):
     lambda: sc.sweep_suite(8, 2, 10, B=5),
     lambda: sc.sweep_suite(4, 4, 10, B=5),
     lambda: sc.sweep_suite(8, 8, 10, B=3),
+    # shapes / constraint families served by the coverage kernel
+    lambda: sc.sweep_suite(12, 8, 10, B=3),
+    lambda: sc.sweep_suite(20, 8, 30, B=2, max_iter=120),
+    lambda: sc.sweep_suite(20, 4, 50, B=2, max_iter=60),
+    lambda: sc.sweep_suite(4, 2, 50, B=5, max_iter=200),
+    lambda: sc.random_linear_suite("quadrotor_20hz", B=9, seed=301),
+    lambda: sc.random_linear_suite("rocket_landing_20hz", B=5, seed=302, soc=True),
+    lambda: sc.random_linear_suite("quadrotor_20hz", B=3, seed=303, tv=False, box=False),
 ])
 def test_hip_matches_oracle_seeded(maker):
     """Ragged batch sizes (not multiples of 4 -> partially filled wavefronts), divergent iteration counts."""

@@ -28,19 +28,21 @@ HOST, DEVICE, BROADCAST = 0, 1, 2
 
 # TinyField (include/tinympc_amd.h)
 FIELDS = ("x0", "Xref", "Uref", "x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc",
-          "q", "r", "p", "d")
+          "q", "r", "p", "d", "vlnew", "zlnew", "gl", "yl", "vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv")
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
-STATE_FIELDS = {"Xref", "x", "vnew", "g", "v", "vcnew", "gc", "q", "p"}
+STATE_FIELDS = {"Xref", "x", "vnew", "g", "v", "vcnew", "gc", "q", "p", "vlnew", "gl", "vlnew_tv", "gl_tv"}
 
 # every extern "C" symbol include/tinympc_amd.h declares (checked by tests/test_abi_symbols.py)
 BATCH_SYMBOLS = (
     "tiny_batch_device_count", "tiny_batch_setup", "tiny_batch_destroy", "tiny_batch_set_bound_constraints",
-    "tiny_batch_set_cone_constraints", "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
+    "tiny_batch_set_cone_constraints", "tiny_batch_set_linear_constraints", "tiny_batch_set_tv_linear_constraints",
+    "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
 REFERENCE_SYMBOLS = (
-    "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_precompute_and_set_cache",
+    "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
+    "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
     "tiny_solve", "solve", "tiny_update_settings", "tiny_set_default_settings", "tiny_set_x0", "tiny_set_x_ref",
     "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy")
 
@@ -73,6 +75,8 @@ def lib():
         L.tiny_batch_destroy.argtypes = [C.c_void_p]
         L.tiny_batch_set_bound_constraints.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.tiny_batch_set_cone_constraints.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp]
+        L.tiny_batch_set_linear_constraints.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        L.tiny_batch_set_tv_linear_constraints.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         L.tiny_batch_update_settings.argtypes = [C.c_void_p, C.c_double, C.c_double] + [C.c_int] * 10
         L.tiny_batch_get_cache.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
         L.tiny_batch_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -180,6 +184,28 @@ class TinyBatchSolver:
             self._h, len(ia[0]), ia[0].ctypes.data_as(_ip), ia[1].ctypes.data_as(_ip), da[0].ctypes.data_as(_dp),
             len(ia[2]), ia[2].ctypes.data_as(_ip), ia[3].ctypes.data_as(_ip), da[1].ctypes.data_as(_dp)),
             "set_cone_constraints")
+
+    def set_linear_constraints(self, Alin_x, blin_x, Alin_u, blin_u):
+        """Half-spaces a_k' z <= b_k (tiny_set_linear_constraints): Alin_x (n_s, nx), blin_x (n_s,), Alin_u (n_i, nu)."""
+        Ax = np.asarray(Alin_x, dtype=np.float64).reshape(-1, self.nx)
+        Au = np.asarray(Alin_u, dtype=np.float64).reshape(-1, self.nu)
+        a = [np.ascontiguousarray(Ax.T).ravel(), _f64(blin_x).ravel(), np.ascontiguousarray(Au.T).ravel(), _f64(blin_u).ravel()]
+        self._check(lib().tiny_batch_set_linear_constraints(self._h, Ax.shape[0], a[0].ctypes.data_as(_dp), a[1].ctypes.data_as(_dp),
+                                                            Au.shape[0], a[2].ctypes.data_as(_dp), a[3].ctypes.data_as(_dp)),
+                    "set_linear_constraints")
+
+    def set_tv_linear_constraints(self, tv_Alin_x, tv_blin_x, tv_Alin_u, tv_blin_u):
+        """tiny_set_tv_linear_constraints: tv_Alin_x (n_s*N, nx) [row n_s*i+k = constraint k at knot i], tv_blin_x (n_s, N),
+        tv_Alin_u (n_i*(N-1), nu), tv_blin_u (n_i, N-1)."""
+        Ax = np.asarray(tv_Alin_x, dtype=np.float64).reshape(-1, self.nx)
+        Au = np.asarray(tv_Alin_u, dtype=np.float64).reshape(-1, self.nu)
+        bx = np.asarray(tv_blin_x, dtype=np.float64).reshape(-1, self.N)
+        bu = np.asarray(tv_blin_u, dtype=np.float64).reshape(-1, self.N - 1)
+        a = [np.ascontiguousarray(Ax.T).ravel(), np.ascontiguousarray(bx.T).ravel(), np.ascontiguousarray(Au.T).ravel(),
+             np.ascontiguousarray(bu.T).ravel()]
+        self._check(lib().tiny_batch_set_tv_linear_constraints(self._h, bx.shape[0], a[0].ctypes.data_as(_dp), a[1].ctypes.data_as(_dp),
+                                                               bu.shape[0], a[2].ctypes.data_as(_dp), a[3].ctypes.data_as(_dp)),
+                    "set_tv_linear_constraints")
 
     def update_settings(self, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=1000, check_termination=1,
                         en_state_bound=1, en_input_bound=1, en_state_soc=0, en_input_soc=0, en_state_linear=0,

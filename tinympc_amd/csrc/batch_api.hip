@@ -3,6 +3,7 @@
 // Mirrors the reference operator interface for the hot path (src/tinympc/tiny_api.cpp:21-147
 // setup, :149-208 constraint setters, :388-411 settings, :443-477 x0/xref/uref, :384-386 solve)
 // with a leading batch axis; the ADMM iteration itself is admm_kernel.hip.h.  No CPU fallback.
+#define TINYMPC_GENERAL_KERNEL_IMPL
 #include "batch_impl.hpp"
 
 #include <cstdarg>
@@ -188,6 +189,114 @@ static void build_tables(TinyBatch* b) {
             }
 }
 
+static bool linear_active(const TinyBatch* b) {
+    return b->set.en_state_linear || b->set.en_input_linear || b->set.en_tv_state_linear || b->set.en_tv_input_linear;
+}
+static bool use_general(const TinyBatch* b) { return !b->kernel || b->force_general || linear_active(b); }
+
+// Tables of the coverage kernel (general_kernel.hip.h): row-major [row][nz+1] matrices + vectors + constraints.
+static void build_general_tables(TinyBatch* b) {
+    const int nx = b->nx, nu = b->nu, N = b->N, nz = nx + nu, ld = nz + 1;
+    const Cache& c = b->cache;
+    GeneralArgs& g = b->gargs;
+    int off = 0;
+    auto take = [&](int n) { int o = off; off += n; return o; };
+    g.o_mb = take(nz * ld); g.o_mf1 = take(nz * ld); g.o_mf2 = take(nz * ld); g.o_pt = take(nz * ld);
+    g.o_cb = take(nz); g.o_cf = take(nz); g.o_qr = take(nz);
+    g.o_lo = take(N * nz); g.o_hi = take(N * nz);
+    g.o_sc = take(2 * (int)b->Acx.size() + 2); g.o_ic = take(2 * (int)b->Acu.size() + 2);
+    g.o_ax = take(b->nsl * nx + 1); g.o_bx = take(b->nsl + 1); g.o_au = take(b->nil * nu + 1); g.o_bu = take(b->nil + 1);
+    g.o_tax = take(N * b->ntsl * nx + 1); g.o_tbx = take(N * b->ntsl + 1);
+    g.o_tau = take((N - 1) * b->ntil * nu + 1); g.o_tbu = take((N - 1) * b->ntil + 1);
+    std::vector<double>& t = b->h_gtab;
+    t.assign(off, 0.0);
+    Mat QBt = c.Quu_inv * transpose(b->B);
+    Mat QBPf = c.Quu_inv * c.BPf;
+    for (int j = 0; j < nx; ++j) {
+        for (int k = 0; k < nx; ++k) {
+            t[g.o_mb + j * ld + k] = c.AmBKt(j, k);
+            t[g.o_mf1 + j * ld + k] = b->A(j, k);
+            t[g.o_pt + j * ld + k] = c.Pinf(k, j);
+        }
+        for (int m = 0; m < nu; ++m) {
+            t[g.o_mb + j * ld + nx + m] = -c.Kinf(m, j);
+            t[g.o_mf2 + j * ld + nx + m] = b->B(j, m);
+        }
+        t[g.o_cb + j] = c.APf(j, 0); t[g.o_cf + j] = b->f(j, 0); t[g.o_qr + j] = b->Qw[j];
+    }
+    for (int a = 0; a < nu; ++a) {
+        const int j = nx + a;
+        for (int k = 0; k < nx; ++k) { t[g.o_mb + j * ld + k] = QBt(a, k); t[g.o_mf1 + j * ld + k] = -c.Kinf(a, k); }
+        for (int m = 0; m < nu; ++m) t[g.o_mb + j * ld + nx + m] = c.Quu_inv(a, m);
+        t[g.o_cb + j] = QBPf(a, 0); t[g.o_qr + j] = b->Rw[a];
+    }
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int e = 0; e < N * nz; ++e) { t[g.o_lo + e] = -inf; t[g.o_hi + e] = inf; }
+    if (b->set.en_state_bound && b->have_bounds)
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < nx; ++j) { t[g.o_lo + i * nz + j] = b->x_min[(size_t)i * nx + j]; t[g.o_hi + i * nz + j] = b->x_max[(size_t)i * nx + j]; }
+    if (b->set.en_input_bound && b->have_bounds)
+        for (int i = 0; i < N - 1; ++i)
+            for (int a = 0; a < nu; ++a) { t[g.o_lo + i * nz + nx + a] = b->u_min[(size_t)i * nu + a]; t[g.o_hi + i * nz + nx + a] = b->u_max[(size_t)i * nu + a]; }
+    for (size_t k = 0; k < b->Acx.size(); ++k) { t[g.o_sc + 2 * k] = b->Acx[k]; t[g.o_sc + 2 * k + 1] = b->cx[k]; }
+    for (size_t k = 0; k < b->Acu.size(); ++k) { t[g.o_ic + 2 * k] = b->Acu[k]; t[g.o_ic + 2 * k + 1] = b->cu[k]; }
+    std::copy(b->Alin_x.begin(), b->Alin_x.end(), t.begin() + g.o_ax); std::copy(b->blin_x.begin(), b->blin_x.end(), t.begin() + g.o_bx);
+    std::copy(b->Alin_u.begin(), b->Alin_u.end(), t.begin() + g.o_au); std::copy(b->blin_u.begin(), b->blin_u.end(), t.begin() + g.o_bu);
+    std::copy(b->tvA_x.begin(), b->tvA_x.end(), t.begin() + g.o_tax); std::copy(b->tvb_x.begin(), b->tvb_x.end(), t.begin() + g.o_tbx);
+    std::copy(b->tvA_u.begin(), b->tvA_u.end(), t.begin() + g.o_tau); std::copy(b->tvb_u.begin(), b->tvb_u.end(), t.begin() + g.o_tbu);
+}
+
+static int ensure_kpi(TinyBatch* b, double** p) {
+    if (*p) return TINY_OK;
+    const size_t kpi_bytes = (size_t)b->batch * b->N * (b->nx + b->nu) * sizeof(double);
+    HIP_TRY(b, hipMalloc(p, kpi_bytes));
+    HIP_TRY(b, hipMemsetAsync(*p, 0, kpi_bytes, b->stream));
+    return TINY_OK;
+}
+
+static int launch_general(TinyBatch* b) {
+    if (b->nx + b->nu > 32) return fail(b, TINY_ERR_UNSUPPORTED, "nx + nu = %d > 32", b->nx + b->nu);
+    if (b->steps_per_launch > 1) return fail(b, TINY_ERR_UNSUPPORTED, "steps_per_launch needs a register-resident kernel instantiation");
+    double** need[] = {&b->d_dbg_qr, &b->d_dbg_pd, &b->d_lslack, &b->d_ldual, &b->d_tlslack, &b->d_tldual};
+    const bool want[] = {true, true, b->set.en_state_linear || b->set.en_input_linear, b->set.en_state_linear || b->set.en_input_linear,
+                         b->set.en_tv_state_linear || b->set.en_tv_input_linear, b->set.en_tv_state_linear || b->set.en_tv_input_linear};
+    for (int i = 0; i < 6; ++i)
+        if (want[i]) { if (int rc = ensure_kpi(b, need[i])) return rc; }
+    if (b->tab_dirty || b->h_gtab.empty()) {
+        build_general_tables(b);
+        if (b->gtab_doubles < b->h_gtab.size()) {
+            if (b->d_gtab) hipFree(b->d_gtab);
+            HIP_TRY(b, hipMalloc(&b->d_gtab, b->h_gtab.size() * sizeof(double)));
+            b->gtab_doubles = b->h_gtab.size();
+        }
+        HIP_TRY(b, hipMemcpyAsync(b->d_gtab, b->h_gtab.data(), b->h_gtab.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
+    GeneralArgs a = b->gargs;
+    a.gtab = b->d_gtab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack; a.dual = b->d_dual;
+    a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual; a.lslack = b->d_lslack; a.ldual = b->d_ldual;
+    a.tlslack = b->d_tlslack; a.tldual = b->d_tldual; a.qr = b->d_dbg_qr; a.pd = b->d_dbg_pd;
+    a.status = b->d_status; a.resid = b->d_resid; a.accum = b->d_accum; a.x0_next = b->advance_x0 ? b->d_x0 : nullptr;
+    a.rho = b->cache.rho; a.tol_pri = b->set.abs_pri_tol; a.tol_dua = b->set.abs_dua_tol;
+    a.batch = b->batch; a.max_iter = b->set.max_iter; a.check_termination = b->set.check_termination;
+    a.nx = b->nx; a.nu = b->nu; a.N = b->N;
+    a.soc_s = b->set.en_state_soc && !b->Acx.empty(); a.soc_i = b->set.en_input_soc && !b->Acu.empty();
+    a.n_sc = b->set.en_state_soc ? (int)b->Acx.size() : 0; a.n_ic = b->set.en_input_soc ? (int)b->Acu.size() : 0;
+    a.lin_s = b->set.en_state_linear; a.lin_i = b->set.en_input_linear;
+    a.tlin_s = b->set.en_tv_state_linear; a.tlin_i = b->set.en_tv_input_linear;
+    a.nsl = b->nsl; a.nil = b->nil; a.ntsl = b->ntsl; a.ntil = b->ntil;
+    const int nz = b->nx + b->nu;
+    const size_t lds = (size_t)(4 * nz * (nz + 1) + nz + b->nu + b->nx) * sizeof(double);
+    int grid = b->batch;
+    const long cap = (long)b->num_cus * 8;
+    if (cap < grid) grid = (int)cap;
+    const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
+    if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
+    hipLaunchKernelGGL(admm_general_kernel, dim3(grid), dim3(64), lds, b->stream, a);
+    HIP_TRY(b, hipGetLastError());
+    if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
+    return TINY_OK;
+}
+
 static int upload_tables(TinyBatch* b) {
     if (!b->tab_dirty) return TINY_OK;
     build_tables(b);
@@ -203,6 +312,12 @@ static bool soc_active(const TinyBatch* b) {
 }
 
 int launch_solve(TinyBatch* b) {
+    if (use_general(b)) {
+        const int rc = launch_general(b);
+        if (rc == TINY_OK) b->tab_dirty = false;
+        return rc;
+    }
+    b->h_gtab.clear();
     if (int rc = upload_tables(b)) return rc;
     const bool soc = soc_active(b);
     SolveArgs a;
@@ -250,7 +365,8 @@ int launch_solve(TinyBatch* b) {
 static int field_geometry(const TinyBatch* b, TinyField f, double** kpi, int* rows, int* row_off, int* cols) {
     const int nx = b->nx, nu = b->nu, N = b->N;
     const bool st = (f == TINY_F_XREF || f == TINY_F_X || f == TINY_F_VNEW || f == TINY_F_G || f == TINY_F_V ||
-                     f == TINY_F_VCNEW || f == TINY_F_GC || f == TINY_F_Q || f == TINY_F_P);
+                     f == TINY_F_VCNEW || f == TINY_F_GC || f == TINY_F_Q || f == TINY_F_P || f == TINY_F_VLNEW ||
+                     f == TINY_F_GL || f == TINY_F_VLNEW_TV || f == TINY_F_GL_TV);
     *rows = st ? nx : nu; *row_off = st ? 0 : nx; *cols = st ? N : N - 1;
     switch (f) {
         case TINY_F_XREF: case TINY_F_UREF: *kpi = b->d_ref; break;
@@ -262,6 +378,10 @@ static int field_geometry(const TinyBatch* b, TinyField f, double** kpi, int* ro
         case TINY_F_GC: case TINY_F_YC: *kpi = b->d_cdual; break;
         case TINY_F_Q: case TINY_F_R: *kpi = b->d_dbg_qr; break;
         case TINY_F_P: case TINY_F_D: *kpi = b->d_dbg_pd; break;
+        case TINY_F_VLNEW: case TINY_F_ZLNEW: *kpi = b->d_lslack; break;
+        case TINY_F_GL: case TINY_F_YL: *kpi = b->d_ldual; break;
+        case TINY_F_VLNEW_TV: case TINY_F_ZLNEW_TV: *kpi = b->d_tlslack; break;
+        case TINY_F_GL_TV: case TINY_F_YL_TV: *kpi = b->d_tldual; break;
         default: return TINY_ERR_ARG;
     }
     return TINY_OK;
@@ -302,9 +422,9 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     if (!out || !Adyn || !Bdyn || !Qdiag || !Rdiag) return TINY_ERR_NULL;
     *out = nullptr;
     if (nx <= 0 || nu <= 0 || N < 2 || batch <= 0) return TINY_ERR_DIM;
-    const KernelEntry* ke = find_kernel(nx, nu, N);
-    if (!ke) {
-        if (verbose) fprintf(stderr, "tinympc_amd: no kernel instantiated for (nx,nu,N)=(%d,%d,%d)\n", nx, nu, N);
+    const KernelEntry* ke = find_kernel(nx, nu, N);   // nullptr -> coverage kernel (general_kernel.hip.h)
+    if (!ke && nx + nu > 32) {
+        if (verbose) fprintf(stderr, "tinympc_amd: (nx,nu,N)=(%d,%d,%d): nx+nu > 32 is not supported\n", nx, nu, N);
         return TINY_ERR_UNSUPPORTED;
     }
     int ndev = 0;
@@ -364,7 +484,7 @@ int tiny_batch_destroy(TinyBatch* b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     void* bufs[] = {b->d_ref, b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual, b->d_x0,
                     b->d_stage, b->d_status, b->d_resid, b->d_stats, b->d_tab, b->d_dbg_qr, b->d_dbg_pd, b->d_accum,
-                    b->d_iter_log, b->d_u0_log};
+                    b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab};
     for (void* p : bufs)
         if (p) hipFree(p);
     for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
@@ -416,11 +536,43 @@ int tiny_batch_update_settings(TinyBatch* b, double abs_pri_tol, double abs_dua_
                                int en_state_linear, int en_input_linear, int en_tv_state_linear,
                                int en_tv_input_linear) {
     if (!b) { printf("Error in tiny_update_settings: settings is nullptr\n"); return 1; }        // tiny_api.cpp:393-396
-    if (en_state_linear || en_input_linear || en_tv_state_linear || en_tv_input_linear)
-        return fail(b, TINY_ERR_UNSUPPORTED, "linear constraints are outside the accelerated hot path (SURVEY.md 8(f))");
     b->set.abs_pri_tol = abs_pri_tol; b->set.abs_dua_tol = abs_dua_tol; b->set.max_iter = max_iter;
     b->set.check_termination = check_termination; b->set.en_state_bound = en_state_bound;
     b->set.en_input_bound = en_input_bound; b->set.en_state_soc = en_state_soc; b->set.en_input_soc = en_input_soc;
+    b->set.en_state_linear = en_state_linear; b->set.en_input_linear = en_input_linear;
+    b->set.en_tv_state_linear = en_tv_state_linear; b->set.en_tv_input_linear = en_tv_input_linear;
+    b->tab_dirty = true;
+    return TINY_OK;
+}
+
+// column-major (n x cols) -> row-major [k][cols]
+static void rows_of(const double* colmajor, int n, int cols, std::vector<double>* out) {
+    out->assign((size_t)n * cols, 0.0);
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < cols; ++c) (*out)[(size_t)k * cols + c] = colmajor[(size_t)c * n + k];
+}
+
+int tiny_batch_set_linear_constraints(TinyBatch* b, int n_state, const double* Alin_x, const double* blin_x, int n_input,
+                                      const double* Alin_u, const double* blin_u) {
+    if (!b) { printf("Error in tiny_set_linear_constraints: solver is nullptr\n"); return 1; }   // tiny_api.cpp:213-216
+    if (n_state < 0 || n_input < 0) return fail(b, TINY_ERR_DIM, "negative constraint count");
+    b->nsl = n_state; b->nil = n_input;
+    rows_of(Alin_x, n_state, b->nx, &b->Alin_x); b->blin_x.assign(blin_x, blin_x + n_state);
+    rows_of(Alin_u, n_input, b->nu, &b->Alin_u); b->blin_u.assign(blin_u, blin_u + n_input);
+    b->tab_dirty = true;
+    return TINY_OK;
+}
+
+int tiny_batch_set_tv_linear_constraints(TinyBatch* b, int n_state, const double* tv_Alin_x, const double* tv_blin_x,
+                                         int n_input, const double* tv_Alin_u, const double* tv_blin_u) {
+    if (!b) { printf("Error in tiny_set_linear_constraints: solver is nullptr\n"); return 1; }   // tiny_api.cpp:256-259
+    if (n_state < 0 || n_input < 0) return fail(b, TINY_ERR_DIM, "negative constraint count");
+    const int N = b->N;
+    b->ntsl = n_state; b->ntil = n_input;
+    // tv_Alin_x is (n_state*N) x nx column-major with row n_state*i + k = constraint k at knot i (admm.cpp:189):
+    // row-major it is already [knot][k][nx]; tv_blin_x is n_state x N column-major = [knot][k]
+    rows_of(tv_Alin_x, n_state * N, b->nx, &b->tvA_x); b->tvb_x.assign(tv_blin_x, tv_blin_x + (size_t)n_state * N);
+    rows_of(tv_Alin_u, n_input * (N - 1), b->nu, &b->tvA_u); b->tvb_u.assign(tv_blin_u, tv_blin_u + (size_t)n_input * (N - 1));
     b->tab_dirty = true;
     return TINY_OK;
 }
@@ -458,7 +610,11 @@ int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags) 
         if (!dev) HIP_TRY(b, hipStreamSynchronize(b->stream));
         return TINY_OK;
     }
-    if (field >= TINY_F_Q) return fail(b, TINY_ERR_ARG, "q/r/p/d are outputs");
+    if (field >= TINY_F_Q && field <= TINY_F_D) return fail(b, TINY_ERR_ARG, "q/r/p/d are outputs");
+    if (field >= TINY_F_VLNEW && field < TINY_F_COUNT) {     // linear-constraint records are allocated on first use
+        double** arr[] = {&b->d_lslack, &b->d_lslack, &b->d_ldual, &b->d_ldual, &b->d_tlslack, &b->d_tlslack, &b->d_tldual, &b->d_tldual};
+        if (int rc = ensure_kpi(b, arr[field - TINY_F_VLNEW])) return rc;
+    }
     double* kpi; int rows, row_off, cols;
     if (field_geometry(b, field, &kpi, &rows, &row_off, &cols)) return fail(b, TINY_ERR_ARG, "bad field %d", (int)field);
     const size_t n = (size_t)(bc ? 1 : b->batch) * rows * cols;
@@ -480,9 +636,11 @@ int tiny_batch_get(TinyBatch* b, TinyField field, double* dst, int flags) {
         if (!dev) HIP_TRY(b, hipStreamSynchronize(b->stream));
         return TINY_OK;
     }
-    if (field >= TINY_F_Q && !b->debug) return fail(b, TINY_ERR_ARG, "q/r/p/d need set_option(\"debug\", 1) before the solve");
+    if (field >= TINY_F_Q && field <= TINY_F_D && !b->debug && !b->d_dbg_qr)
+        return fail(b, TINY_ERR_ARG, "q/r/p/d need set_option(\"debug\", 1) before the solve");
     double* kpi; int rows, row_off, cols;
     if (field_geometry(b, field, &kpi, &rows, &row_off, &cols)) return fail(b, TINY_ERR_ARG, "bad field %d", (int)field);
+    if (!kpi) return fail(b, TINY_ERR_ARG, "field %d has no record yet (constraint family never enabled)", (int)field);
     const size_t n = (size_t)b->batch * rows * cols;
     double* d = dev ? dst : b->d_stage;
     hipLaunchKernelGGL(unpack_kpi_kernel, dim3(2048), dim3(256), 0, b->stream, kpi, d, b->batch, b->N, b->nx + b->nu, rows,
@@ -499,8 +657,10 @@ int tiny_batch_reset(TinyBatch* b) {
     if (!b) return TINY_ERR_NULL;
     HIP_TRY(b, hipSetDevice(b->device));
     const size_t kpi_bytes = (size_t)b->batch * b->N * (b->nx + b->nu) * sizeof(double);
-    double* z[] = {b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual};
-    for (double* p : z) HIP_TRY(b, hipMemsetAsync(p, 0, kpi_bytes, b->stream));
+    double* z[] = {b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual, b->d_lslack, b->d_ldual,
+                   b->d_tlslack, b->d_tldual};
+    for (double* p : z)
+        if (p) HIP_TRY(b, hipMemsetAsync(p, 0, kpi_bytes, b->stream));
     HIP_TRY(b, hipMemsetAsync(b->d_accum, 0, (size_t)b->batch * sizeof(uint2), b->stream));
     return TINY_OK;
 }
@@ -569,6 +729,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     } else if (!strcmp(name, "grid_waves_per_cu")) b->grid_waves_per_cu = (int)value;
     else if (!strcmp(name, "dpp_mode")) b->dpp_mode = (int)value;
     else if (!strcmp(name, "steps_per_launch")) b->steps_per_launch = (int)value;
+    else if (!strcmp(name, "force_general")) { b->force_general = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "timing")) {
         HIP_TRY(b, hipStreamSynchronize(b->stream));

@@ -7,6 +7,7 @@
 
 #include "../../include/tinympc_amd.h"
 #include "admm_kernel.hip.h"
+#include "general_kernel.hip.h"
 #include "cache.hpp"
 
 namespace tinympc_amd {
@@ -17,6 +18,7 @@ struct Settings {              // TinySettings (types.hpp:63-82) hot-path subset
     double abs_pri_tol = 1e-3, abs_dua_tol = 1e-3;
     int max_iter = 1000, check_termination = 1;
     int en_state_bound = 1, en_input_bound = 1, en_state_soc = 0, en_input_soc = 0;
+    int en_state_linear = 0, en_input_linear = 0, en_tv_state_linear = 0, en_tv_input_linear = 0;
 };
 
 }  // namespace tinympc_amd
@@ -33,6 +35,9 @@ struct TinyBatch {
     std::vector<double> x_min, x_max, u_min, u_max;
     std::vector<int> Acx, qcx, Acu, qcu;
     std::vector<double> cx, cu;
+    // half-space constraints a_k' z <= b_k (row-major copies: [k][n]); time-varying: [knot][k][n]
+    int nsl = 0, nil = 0, ntsl = 0, ntil = 0;
+    std::vector<double> Alin_x, blin_x, Alin_u, blin_u, tvA_x, tvb_x, tvA_u, tvb_u;
     // device state (KPI records, see admm_kernel.hip.h)
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -41,6 +46,11 @@ struct TinyBatch {
            *d_stage = nullptr, *d_stats = nullptr, *d_dbg_qr = nullptr, *d_dbg_pd = nullptr;
     int4* d_status = nullptr;
     uint2* d_accum = nullptr;
+    double *d_lslack = nullptr, *d_ldual = nullptr, *d_tlslack = nullptr, *d_tldual = nullptr, *d_gtab = nullptr;
+    size_t gtab_doubles = 0;
+    std::vector<double> h_gtab;
+    tinympc_amd::GeneralArgs gargs;      // table offsets filled by build_general_tables
+    bool force_general = false;
     int* d_iter_log = nullptr;
     double* d_u0_log = nullptr;
     int log_steps = 0;

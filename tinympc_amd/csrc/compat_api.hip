@@ -112,8 +112,8 @@ int sync_family(TinyBatch* b, const TinySolver* s) {
     const TinyCache* c = s->cache;
     const TinySettings* st = s->settings;
     const int nx = w->nx, nu = w->nu, N = w->N;
-    if (st->en_state_linear || st->en_input_linear || st->en_tv_state_linear || st->en_tv_input_linear || st->adaptive_rho)
-        return fail(b, TINY_ERR_UNSUPPORTED, "linear constraints / adaptive rho are outside the accelerated hot path");
+    if (st->adaptive_rho)
+        return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho is outside the accelerated hot path (SURVEY.md section 2 row 4)");
     if (!shaped(c->Kinf, nu, nx) || !shaped(c->Pinf, nx, nx) || !shaped(c->Quu_inv, nu, nu) || !shaped(c->AmBKt, nx, nx) ||
         c->APf.rows != nx || c->BPf.rows != nu || !shaped(w->Adyn, nx, nx) || !shaped(w->Bdyn, nx, nu))
         return fail(b, TINY_ERR_DIM, "cache / dynamics have unexpected shapes");
@@ -127,6 +127,21 @@ int sync_family(TinyBatch* b, const TinySolver* s) {
     b->set.abs_pri_tol = st->abs_pri_tol; b->set.abs_dua_tol = st->abs_dua_tol; b->set.max_iter = st->max_iter;
     b->set.check_termination = st->check_termination; b->set.en_state_bound = st->en_state_bound;
     b->set.en_input_bound = st->en_input_bound; b->set.en_state_soc = st->en_state_soc; b->set.en_input_soc = st->en_input_soc;
+    b->set.en_state_linear = st->en_state_linear; b->set.en_input_linear = st->en_input_linear;
+    b->set.en_tv_state_linear = st->en_tv_state_linear; b->set.en_tv_input_linear = st->en_tv_input_linear;
+    if (st->en_state_linear || st->en_input_linear) {
+        if (w->Alin_x.rows != w->numStateLinear || w->Alin_u.rows != w->numInputLinear ||
+            (w->numStateLinear && w->Alin_x.cols != nx) || (w->numInputLinear && w->Alin_u.cols != nu))
+            return fail(b, TINY_ERR_DIM, "linear constraints enabled but not set (tiny_set_linear_constraints)");
+        if (int rc = tiny_batch_set_linear_constraints(b, w->numStateLinear, w->Alin_x.data, w->blin_x.data, w->numInputLinear,
+                                                       w->Alin_u.data, w->blin_u.data)) return rc;
+    }
+    if (st->en_tv_state_linear || st->en_tv_input_linear) {
+        if (w->tv_Alin_x.rows != (int64_t)w->numtvStateLinear * N || w->tv_Alin_u.rows != (int64_t)w->numtvInputLinear * (N - 1))
+            return fail(b, TINY_ERR_DIM, "time-varying linear constraints enabled but not set (tiny_set_tv_linear_constraints)");
+        if (int rc = tiny_batch_set_tv_linear_constraints(b, w->numtvStateLinear, w->tv_Alin_x.data, w->tv_blin_x.data,
+                                                          w->numtvInputLinear, w->tv_Alin_u.data, w->tv_blin_u.data)) return rc;
+    }
     b->have_bounds = false;
     if (st->en_state_bound || st->en_input_bound) {
         if (!shaped(w->x_min, nx, N) || !shaped(w->x_max, nx, N) || !shaped(w->u_min, nu, N - 1) || !shaped(w->u_max, nu, N - 1))
@@ -157,10 +172,20 @@ const FieldMap kOut[] = {{TINY_F_X, &TinyWorkspace::x}, {TINY_F_U, &TinyWorkspac
                          {TINY_F_P, &TinyWorkspace::p}, {TINY_F_D, &TinyWorkspace::d}};
 const FieldMap kOutSocS[] = {{TINY_F_VCNEW, &TinyWorkspace::vcnew}, {TINY_F_GC, &TinyWorkspace::gc}};
 const FieldMap kOutSocI[] = {{TINY_F_ZCNEW, &TinyWorkspace::zcnew}, {TINY_F_YC, &TinyWorkspace::yc}};
+// linear / time-varying linear: duals in, slack + duals out; x,u in (the slack is initialised from them, admm.cpp:361-375)
+const FieldMap kInLinS[] = {{TINY_F_GL, &TinyWorkspace::gl}};
+const FieldMap kInLinI[] = {{TINY_F_YL, &TinyWorkspace::yl}};
+const FieldMap kInTvS[] = {{TINY_F_GL_TV, &TinyWorkspace::gl_tv}};
+const FieldMap kInTvI[] = {{TINY_F_YL_TV, &TinyWorkspace::yl_tv}};
+const FieldMap kOutLinS[] = {{TINY_F_VLNEW, &TinyWorkspace::vlnew}, {TINY_F_GL, &TinyWorkspace::gl}};
+const FieldMap kOutLinI[] = {{TINY_F_ZLNEW, &TinyWorkspace::zlnew}, {TINY_F_YL, &TinyWorkspace::yl}};
+const FieldMap kOutTvS[] = {{TINY_F_VLNEW_TV, &TinyWorkspace::vlnew_tv}, {TINY_F_GL_TV, &TinyWorkspace::gl_tv}};
+const FieldMap kOutTvI[] = {{TINY_F_ZLNEW_TV, &TinyWorkspace::zlnew_tv}, {TINY_F_YL_TV, &TinyWorkspace::yl_tv}};
 
 bool is_state_field(TinyField f) {
     return f == TINY_F_XREF || f == TINY_F_X || f == TINY_F_VNEW || f == TINY_F_G || f == TINY_F_V || f == TINY_F_VCNEW ||
-           f == TINY_F_GC || f == TINY_F_Q || f == TINY_F_P;
+           f == TINY_F_GC || f == TINY_F_Q || f == TINY_F_P || f == TINY_F_VLNEW || f == TINY_F_GL || f == TINY_F_VLNEW_TV ||
+           f == TINY_F_GL_TV;
 }
 
 int solve_group(TinySolver** solvers, int n) {
@@ -197,8 +222,17 @@ int solve_group(TinySolver** solvers, int n) {
         return tiny_batch_set(b, fm.f, buf.data(), TINY_HOST);
     };
     for (const FieldMap& fm : kIn) if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
-    if (s_soc || i_soc)
-        for (const FieldMap& fm : kInSoc) if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    const TinySettings* st0 = s0->settings;
+    const bool any_lin = st0->en_state_linear || st0->en_input_linear || st0->en_tv_state_linear || st0->en_tv_input_linear;
+    if (s_soc || i_soc || any_lin)
+        for (const FieldMap& fm : kInSoc) {
+            if ((fm.f == TINY_F_GC || fm.f == TINY_F_YC) && !(s_soc || i_soc)) continue;
+            if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        }
+    if (st0->en_state_linear) for (const FieldMap& fm : kInLinS) if (int rc = gather(fm)) return rc;
+    if (st0->en_input_linear) for (const FieldMap& fm : kInLinI) if (int rc = gather(fm)) return rc;
+    if (st0->en_tv_state_linear) for (const FieldMap& fm : kInTvS) if (int rc = gather(fm)) return rc;
+    if (st0->en_tv_input_linear) for (const FieldMap& fm : kInTvI) if (int rc = gather(fm)) return rc;
     for (int k = 0; k < n; ++k) memcpy(&buf[(size_t)k * nx], solvers[k]->work->x.data, nx * sizeof(double));   // x[:,0] = x0
     if (int rc = tiny_batch_set(b, TINY_F_X0, buf.data(), TINY_HOST)) return rc;
 
@@ -216,6 +250,10 @@ int solve_group(TinySolver** solvers, int n) {
     for (const FieldMap& fm : kOut) if (int rc = scatter(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
     if (s_soc) for (const FieldMap& fm : kOutSocS) if (int rc = scatter(fm)) return rc;
     if (i_soc) for (const FieldMap& fm : kOutSocI) if (int rc = scatter(fm)) return rc;
+    if (st0->en_state_linear) for (const FieldMap& fm : kOutLinS) if (int rc = scatter(fm)) return rc;
+    if (st0->en_input_linear) for (const FieldMap& fm : kOutLinI) if (int rc = scatter(fm)) return rc;
+    if (st0->en_tv_state_linear) for (const FieldMap& fm : kOutTvS) if (int rc = scatter(fm)) return rc;
+    if (st0->en_tv_input_linear) for (const FieldMap& fm : kOutTvI) if (int rc = scatter(fm)) return rc;
     std::vector<int4> st(n);
     std::vector<double> res((size_t)n * 4);
     if (hipMemcpyAsync(st.data(), b->d_status, n * sizeof(int4), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
@@ -398,6 +436,54 @@ int tiny_set_cone_constraints(TinySolver* solver, const TinyVectorXiPOD* Acx, co
     w->numStateCones = nsc; w->numInputCones = nic;
     ivec_assign(&w->Acx, Acx->data, nsc); ivec_assign(&w->qcx, qcx->data, nsc); vec_assign(&w->cx, cx->data, nsc);
     ivec_assign(&w->Acu, Acu->data, nic); ivec_assign(&w->qcu, qcu->data, nic); vec_assign(&w->cu, cu->data, nic);
+    return 0;
+}
+
+int tiny_set_linear_constraints(TinySolver* solver, const TinyMatrixPOD* Alin_x, const TinyVectorPOD* blin_x,
+                                const TinyMatrixPOD* Alin_u, const TinyVectorPOD* blin_u) {   // tiny_api.cpp:210-251
+    if (!solver) { std::cout << "Error in tiny_set_linear_constraints: solver is nullptr" << std::endl; return 1; }
+    TinyWorkspace* w = solver->work;
+    const int nsl = (int)Alin_x->rows, nil = (int)Alin_u->rows;
+    int status = 0;
+    if (nsl > 0) {
+        status |= check_dimension("State linear constraint matrix (Alin_x)", "columns", Alin_x->cols, w->nx);
+        status |= check_dimension("State linear constraint vector (blin_x)", "rows", blin_x->rows, nsl);
+    }
+    if (nil > 0) {
+        status |= check_dimension("Input linear constraint matrix (Alin_u)", "columns", Alin_u->cols, w->nu);
+        status |= check_dimension("Input linear constraint vector (blin_u)", "rows", blin_u->rows, nil);
+    }
+    if (status) return status;
+    w->numStateLinear = nsl; w->numInputLinear = nil;
+    mat_assign(&w->Alin_x, Alin_x->data, Alin_x->rows, Alin_x->cols); vec_assign(&w->blin_x, blin_x->data, blin_x->rows);
+    mat_assign(&w->Alin_u, Alin_u->data, Alin_u->rows, Alin_u->cols); vec_assign(&w->blin_u, blin_u->data, blin_u->rows);
+    return 0;
+}
+
+int tiny_set_tv_linear_constraints(TinySolver* solver, const TinyMatrixPOD* tv_Alin_x, const TinyMatrixPOD* tv_blin_x,
+                                   const TinyMatrixPOD* tv_Alin_u, const TinyMatrixPOD* tv_blin_u) {   // tiny_api.cpp:253-304
+    if (!solver) { std::cout << "Error in tiny_set_linear_constraints: solver is nullptr" << std::endl; return 1; }
+    TinyWorkspace* w = solver->work;
+    const int nts = (int)(tv_Alin_x->rows / w->N), nti = (int)(tv_Alin_u->rows / (w->N - 1));
+    int status = 0;
+    if (nts > 0) {
+        status |= check_dimension("State time-varying linear constraint matrix (tv_Alin_x)", "rows", tv_Alin_x->rows, (long)nts * w->N);
+        status |= check_dimension("State time-varying linear constraint matrix (tv_Alin_x)", "columns", tv_Alin_x->cols, w->nx);
+        status |= check_dimension("State time-varying linear constraint vector (tv_blin_x)", "rows", tv_blin_x->rows, nts);
+        status |= check_dimension("State time-varying linear constraint vector (tv_blin_x)", "columns", tv_blin_x->cols, w->N);
+    }
+    if (nti > 0) {
+        status |= check_dimension("Input time-varying linear constraint matrix (tv_Alin_u)", "rows", tv_Alin_u->rows, (long)nti * (w->N - 1));
+        status |= check_dimension("Input time-varying linear constraint matrix (tv_Alin_u)", "columns", tv_Alin_u->cols, w->nu);
+        status |= check_dimension("Input time-varying linear constraint vector (tv_blin_u)", "rows", tv_blin_u->rows, nti);
+        status |= check_dimension("Input time-varying linear constraint vector (tv_blin_u)", "columns", tv_blin_u->cols, w->N - 1);
+    }
+    if (status) return status;
+    w->numtvStateLinear = nts; w->numtvInputLinear = nti;
+    mat_assign(&w->tv_Alin_x, tv_Alin_x->data, tv_Alin_x->rows, tv_Alin_x->cols);
+    mat_assign(&w->tv_blin_x, tv_blin_x->data, tv_blin_x->rows, tv_blin_x->cols);
+    mat_assign(&w->tv_Alin_u, tv_Alin_u->data, tv_Alin_u->rows, tv_Alin_u->cols);
+    mat_assign(&w->tv_blin_u, tv_blin_u->data, tv_blin_u->rows, tv_blin_u->cols);
     return 0;
 }
 

@@ -1,0 +1,305 @@
+// general_kernel.hip.h -- coverage kernel: the same tiny_solve() (reference src/tinympc/admm.cpp:331-455)
+// for ANY (nx, nu, N) with nx + nu <= 32 and for every slack family of update_slack (box :91-98, second-order
+// cone :102-135, static linear :137-173, time-varying linear :176-211).
+//
+// The register-resident kernel (admm_kernel.hip.h) is the fast path for the shapes it is instantiated for
+// (nx+nu <= 16, N-long register arrays, box + cone).  This kernel trades speed for generality:
+//   * one wavefront per instance (persistent, grid-stride), lane j = row j of the stacked knot vector for the
+//     Riccati sweeps, all 64 lanes striding over the record for the element-wise phases;
+//   * the ADMM state stays in the instance's HBM records (knot-point interleaved, same layout as the fast
+//     path) and is L2-resident across iterations; q|r and p|d live in two extra work records;
+//   * the shared matrices sit in LDS ([row][nz+1] padded: conflict-free row reads), the knot vector being
+//     multiplied is broadcast-read from LDS.  That formulation is LDS-bandwidth bound (see admm_kernel.hip.h)
+//     -- acceptable for a coverage path, and it has no shape restriction.
+// Arithmetic follows the reference's order (d_i = Quu_inv (B' p + r + BPf) uses the same pre-multiplied
+// Quu_inv B' table as the fast path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tinympc_amd {
+
+struct GeneralArgs {
+    const double* gtab;       // layout below (offsets in doubles)
+    const double* x0;
+    const double* ref;
+    double *prim, *slack, *dual, *slack_prev, *cslack, *cdual, *lslack, *ldual, *tlslack, *tldual, *qr, *pd;
+    int4* status;
+    double* resid;
+    uint2* accum;
+    double* x0_next;
+    double rho, tol_pri, tol_dua;
+    int batch, max_iter, check_termination;
+    int nx, nu, N;
+    int soc_s, soc_i;                 // cone slack active for state / input rows (en_* && num* > 0)
+    int n_sc, n_ic;                   // cones projected (0 when the enable switch is off)
+    int lin_s, lin_i, tlin_s, tlin_i; // enable switches (the slack exists even with 0 constraints, admm.cpp:138-145)
+    int nsl, nil, ntsl, ntil;         // constraint counts (per knot for the time-varying ones)
+    // offsets into gtab
+    int o_mb, o_mf1, o_mf2, o_pt, o_cb, o_cf, o_qr, o_lo, o_hi, o_sc, o_ic, o_ax, o_bx, o_au, o_bu, o_tax, o_tbx,
+        o_tau, o_tbu;
+};
+
+#ifdef TINYMPC_GENERAL_KERNEL_IMPL   // the kernel body is compiled into batch_api.hip only
+
+__device__ __forceinline__ double wave_max64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// project_soc (admm.cpp:39-60) on 3 consecutive entries in place
+__device__ __forceinline__ void soc3_inplace(double* s, double mu_d) {
+    const float mu = (float)mu_d;
+    const double u0 = s[2] * (double)mu;
+    const float a = (float)sqrt(__dadd_rn(__dmul_rn(s[0], s[0]), __dmul_rn(s[1], s[1])));
+    if ((double)a <= -u0) { s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; }
+    else if ((double)a <= u0) {}
+    else if ((double)a >= fabs(u0)) {
+        const double scale = 0.5 * (1.0 + u0 / (double)a);
+        s[0] = scale * s[0]; s[1] = scale * s[1]; s[2] = scale * (double)(a / mu);
+    } else { s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; }
+}
+
+// one column z (n entries, stride 1) against the half-space a'z <= b (admm.cpp:150-157, project_hyperplane :70-73)
+__device__ __forceinline__ void halfspace_inplace(double* z, int n, const double* a, double b) {
+    double cv = 0.0;
+    for (int c = 0; c < n; ++c) cv = __dadd_rn(cv, __dmul_rn(a[c], z[c]));
+    if (cv > b) {
+        double nn = 0.0;
+        for (int c = 0; c < n; ++c) nn = __dadd_rn(nn, __dmul_rn(a[c], a[c]));
+        const double dist = (cv - b) / nn;
+        for (int c = 0; c < n; ++c) z[c] = z[c] - dist * a[c];
+    }
+}
+
+__global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
+    double* sMB = lds;
+    double* sMF1 = sMB + nz * ld;
+    double* sMF2 = sMF1 + nz * ld;
+    double* sPT = sMF2 + nz * ld;
+    double* sW = sPT + nz * ld;        // [nz]  knot vector being multiplied
+    double* sU = sW + nz;              // [nu]
+    double* sPX = sU + nu;             // [nx]  terminal term -(Xref' Pinf)
+    for (int e = lane; e < nz * ld; e += 64) {
+        sMB[e] = P.gtab[P.o_mb + e]; sMF1[e] = P.gtab[P.o_mf1 + e];
+        sMF2[e] = P.gtab[P.o_mf2 + e]; sPT[e] = P.gtab[P.o_pt + e];
+    }
+    const double* CB = P.gtab + P.o_cb;
+    const double* CF = P.gtab + P.o_cf;
+    const double* QR = P.gtab + P.o_qr;
+    const double* LO = P.gtab + P.o_lo;
+    const double* HI = P.gtab + P.o_hi;
+    const double rho = P.rho;
+    const bool is_state = lane < nx, is_input = lane >= nx && lane < nz;
+    const int rec_n = N * nz;
+    __syncthreads();
+
+    for (int b = blockIdx.x; b < P.batch; b += gridDim.x) {
+        const size_t rec = (size_t)b * rec_n;
+        // ---- per-solve setup: x[:,0] = x0, terminal term, slack initialisation (admm.cpp:352-376)
+        if (is_state) {
+            const double x0v = P.x0[(size_t)b * nx + lane];
+            P.prim[rec + lane] = x0v;
+            double acc = 0.0;
+            for (int k = 0; k < nx; ++k) acc = fma(P.ref[rec + (size_t)(N - 1) * nz + k], sPT[lane * ld + k], acc);
+            sPX[lane] = -acc;                                          // admm.cpp:292
+        }
+        __syncthreads();
+        for (int e = lane; e < rec_n; e += 64) {
+            const int i = e / nz, j = e - i * nz;
+            const bool st = j < nx;
+            if (!st && i == N - 1) continue;
+            const double xv = P.prim[rec + e];
+            if (st ? P.soc_s : P.soc_i) P.cslack[rec + e] = xv;        // vcnew = x / zcnew = u
+            if (st ? P.lin_s : P.lin_i) P.lslack[rec + e] = xv;        // vlnew = x / zlnew = u
+            if (st ? P.tlin_s : P.tlin_i) P.tlslack[rec + e] = xv;     // vlnew_tv / zlnew_tv
+        }
+        __syncthreads();
+
+        int iter = 0, solved = 0, checked = 0, countdown = P.check_termination;
+        double r_ps = 0.0, r_pi = 0.0, r_ds = 0.0, r_di = 0.0;
+        for (int it = 0; it < P.max_iter; ++it) {
+            // ---- v = vnew of the previous iteration (admm.cpp:445-446), then update_linear_cost (:262-302)
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                const bool st = j < nx;
+                if (!st && i == N - 1) continue;
+                const double vn = P.slack[rec + e];
+                if (it > 0) P.slack_prev[rec + e] = vn;
+                double qv = -(P.ref[rec + e] * QR[j]);                                            // :266 / :279
+                qv -= rho * (vn - P.dual[rec + e]);                                               // :267 / :280
+                double pv = (st && i == N - 1) ? (sPX[j] - rho * (vn - P.dual[rec + e])) : 0.0;   // :292-293
+                if (st ? P.soc_s : P.soc_i) {
+                    const double tt = rho * (P.cslack[rec + e] - P.cdual[rec + e]);               // :269 / :282 / :295
+                    qv -= tt; pv -= tt;
+                }
+                if (st ? P.lin_s : P.lin_i) {
+                    const double tt = rho * (P.lslack[rec + e] - P.ldual[rec + e]);               // :272 / :285 / :298
+                    qv -= tt; pv -= tt;
+                }
+                if (st ? P.tlin_s : P.tlin_i) {
+                    const double tt = rho * (P.tlslack[rec + e] - P.tldual[rec + e]);             // :275 / :288 / :301
+                    qv -= tt; pv -= tt;
+                }
+                P.qr[rec + e] = qv;
+                if (st && i == N - 1) P.pd[rec + e] = pv;
+            }
+            __syncthreads();
+            // ---- backward_pass_grad (admm.cpp:13-20)
+            if (is_state) sW[lane] = P.pd[rec + (size_t)(N - 1) * nz + lane];
+            for (int i = N - 2; i >= 0; --i) {
+                const size_t o = rec + (size_t)i * nz;
+                if (is_input) sW[lane] = P.qr[o + lane];               // r_i
+                __syncthreads();
+                double acc = 0.0;
+                if (lane < nz)
+                    for (int k = 0; k < nz; ++k) acc = fma(sMB[lane * ld + k], sW[k], acc);
+                __syncthreads();
+                if (is_state) {
+                    const double p = P.qr[o + lane] + acc + CB[lane];  // q_i + AmBKt p - Kinf' r + APf
+                    P.pd[o + lane] = p;
+                    sW[lane] = p;
+                } else if (is_input) {
+                    P.pd[o + lane] = acc + CB[lane];                   // d_i = Quu_inv (B' p + r + BPf)
+                }
+            }
+            __syncthreads();
+            // ---- forward_pass (admm.cpp:25-32)
+            if (is_state) sW[lane] = P.prim[rec + lane];
+            for (int i = 0; i < N - 1; ++i) {
+                const size_t o = rec + (size_t)i * nz;
+                __syncthreads();
+                double acc = 0.0;
+                if (lane < nz)
+                    for (int k = 0; k < nx; ++k) acc = fma(sMF1[lane * ld + k], sW[k], acc);
+                if (is_input) {
+                    const double u = acc - P.pd[o + lane];             // -Kinf x_i - d_i
+                    P.prim[o + lane] = u;
+                    sU[lane - nx] = u;
+                }
+                __syncthreads();
+                if (is_state) {
+                    double xn = acc;
+                    for (int m = 0; m < nu; ++m) xn = fma(sMF2[lane * ld + nx + m], sU[m], xn);
+                    xn += CF[lane];
+                    P.prim[o + nz + lane] = xn;
+                    sW[lane] = xn;
+                }
+            }
+            __syncthreads();
+            // ---- update_slack (box) + update_dual + residuals (admm.cpp:85-98, 222-225, 314-317)
+            double m_ps = 0.0, m_pi = 0.0, m_ds = 0.0, m_di = 0.0;
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                const bool st = j < nx;
+                if (!st && i == N - 1) continue;
+                const double xv = P.prim[rec + e];
+                const double t = xv + P.dual[rec + e];
+                const double vn = fmin(HI[i * nz + j], fmax(LO[i * nz + j], t));
+                const double pr = fabs(xv - vn), du = fabs(P.slack_prev[rec + e] - vn);
+                if (st) { m_ps = fmax(m_ps, pr); m_ds = fmax(m_ds, du); }
+                else { m_pi = fmax(m_pi, pr); m_di = fmax(m_di, du); }
+                P.dual[rec + e] = t - vn;
+                P.slack[rec + e] = vn;
+                // cone / linear slacks: refresh (admm.cpp:102-109, 138-145, 176-183); projected below
+                if (st ? P.soc_s : P.soc_i) P.cslack[rec + e] = xv + P.cdual[rec + e];
+                if (st ? P.lin_s : P.lin_i) P.lslack[rec + e] = xv + P.ldual[rec + e];
+                if (st ? P.tlin_s : P.tlin_i) P.tlslack[rec + e] = xv + P.tldual[rec + e];
+            }
+            __syncthreads();
+            // ---- projections: one lane per knot point, constraints applied sequentially (admm.cpp:112-211)
+            for (int i = lane; i < N; i += 64) {
+                double* vcol;
+                double zbuf[32];
+                const size_t o = rec + (size_t)i * nz;
+                for (int k = 0; k < P.n_sc; ++k) {
+                    vcol = P.cslack + o + (int)P.gtab[P.o_sc + 2 * k];
+                    double s3[3] = {vcol[0], vcol[1], vcol[2]};
+                    soc3_inplace(s3, P.gtab[P.o_sc + 2 * k + 1]);
+                    vcol[0] = s3[0]; vcol[1] = s3[1]; vcol[2] = s3[2];
+                }
+                if (i < N - 1)
+                    for (int k = 0; k < P.n_ic; ++k) {
+                        vcol = P.cslack + o + nx + (int)P.gtab[P.o_ic + 2 * k];
+                        double s3[3] = {vcol[0], vcol[1], vcol[2]};
+                        soc3_inplace(s3, P.gtab[P.o_ic + 2 * k + 1]);
+                        vcol[0] = s3[0]; vcol[1] = s3[1]; vcol[2] = s3[2];
+                    }
+                if (P.lin_s && P.nsl > 0) {
+                    for (int c = 0; c < nx; ++c) zbuf[c] = P.lslack[o + c];
+                    for (int k = 0; k < P.nsl; ++k) halfspace_inplace(zbuf, nx, P.gtab + P.o_ax + k * nx, P.gtab[P.o_bx + k]);
+                    for (int c = 0; c < nx; ++c) P.lslack[o + c] = zbuf[c];
+                }
+                if (P.lin_i && P.nil > 0 && i < N - 1) {
+                    for (int c = 0; c < nu; ++c) zbuf[c] = P.lslack[o + nx + c];
+                    for (int k = 0; k < P.nil; ++k) halfspace_inplace(zbuf, nu, P.gtab + P.o_au + k * nu, P.gtab[P.o_bu + k]);
+                    for (int c = 0; c < nu; ++c) P.lslack[o + nx + c] = zbuf[c];
+                }
+                if (P.tlin_s && P.ntsl > 0) {
+                    for (int c = 0; c < nx; ++c) zbuf[c] = P.tlslack[o + c];
+                    for (int k = 0; k < P.ntsl; ++k)
+                        halfspace_inplace(zbuf, nx, P.gtab + P.o_tax + (size_t)(i * P.ntsl + k) * nx, P.gtab[P.o_tbx + i * P.ntsl + k]);
+                    for (int c = 0; c < nx; ++c) P.tlslack[o + c] = zbuf[c];
+                }
+                if (P.tlin_i && P.ntil > 0 && i < N - 1) {
+                    for (int c = 0; c < nu; ++c) zbuf[c] = P.tlslack[o + nx + c];
+                    for (int k = 0; k < P.ntil; ++k)
+                        halfspace_inplace(zbuf, nu, P.gtab + P.o_tau + (size_t)(i * P.ntil + k) * nu, P.gtab[P.o_tbu + i * P.ntil + k]);
+                    for (int c = 0; c < nu; ++c) P.tlslack[o + nx + c] = zbuf[c];
+                }
+            }
+            __syncthreads();
+            // ---- duals of the cone / linear slacks (admm.cpp:228-255)
+            if (P.soc_s | P.soc_i | P.lin_s | P.lin_i | P.tlin_s | P.tlin_i) {
+                for (int e = lane; e < rec_n; e += 64) {
+                    const int i = e / nz, j = e - i * nz;
+                    const bool st = j < nx;
+                    if (!st && i == N - 1) continue;
+                    const double xv = P.prim[rec + e];
+                    if (st ? P.soc_s : P.soc_i) P.cdual[rec + e] = (P.cdual[rec + e] + xv) - P.cslack[rec + e];
+                    if (st ? P.lin_s : P.lin_i) P.ldual[rec + e] = (P.ldual[rec + e] + xv) - P.lslack[rec + e];
+                    if (st ? P.tlin_s : P.tlin_i) P.tldual[rec + e] = (P.tldual[rec + e] + xv) - P.tlslack[rec + e];
+                }
+                __syncthreads();
+            }
+            iter += 1;
+            // ---- termination_condition (admm.cpp:310-328): box slack only
+            bool conv = false;
+            if (countdown > 0 && --countdown == 0) {
+                countdown = P.check_termination;
+                checked = 1;
+                r_ps = wave_max64(m_ps); r_pi = wave_max64(m_pi);
+                r_ds = wave_max64(m_ds) * rho; r_di = wave_max64(m_di) * rho;
+                conv = (r_ps < P.tol_pri) && (r_pi < P.tol_pri) && (r_ds < P.tol_dua) && (r_di < P.tol_dua);
+            }
+            if (conv) { solved = 1; break; }
+        }
+        if (!solved && iter > 0) {                                     // the last v = vnew (admm.cpp:445-446)
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                if (j >= nx && i == N - 1) continue;
+                P.slack_prev[rec + e] = P.slack[rec + e];
+            }
+        }
+        if (P.x0_next && is_state) P.x0_next[(size_t)b * nx + lane] = P.prim[rec + nz + lane];
+        if (lane == 0) {
+            P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
+            *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(r_ps, r_pi, r_ds, r_di);
+            if (P.accum) {
+                uint2 ac = P.accum[b];
+                ac.x += (unsigned)iter;
+                ac.y += (unsigned)solved;
+                P.accum[b] = ac;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+#endif  // TINYMPC_GENERAL_KERNEL_IMPL
+
+}  // namespace tinympc_amd
