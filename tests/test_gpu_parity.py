@@ -255,3 +255,58 @@ def test_rocket_soc_full_batch_properties():
     assert np.all(nrm <= mu * zc[:, 2] * (1 + 1e-6) + 1e-9)
     assert np.all(out["znew"] <= 105 + 1e-12) and np.all(out["znew"] >= -10 - 1e-12)
     assert out["iter"].min() >= 1 and out["iter"].max() <= 100
+
+
+def test_device_pointer_set_get_roundtrip():
+    """TINY_DEVICE flags: a host that already owns HBM buffers (here torch tensors) hands them over / receives
+    results without a PCIe round trip; must equal the host-pointer path.  Runs in a fresh interpreter that imports
+    torch FIRST (torch bundles its own HIP runtime; it cannot initialise after libtinympc_amd's is already live)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "device_ptr_check.py")
+    p = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "device pointer path ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_tiny_solve_batch_over_reference_structs():
+    """tiny_solve_batch(TinySolver**, n): n ordinary reference-layout solvers (plain-data mirrors), one launch;
+    every workspace field the reference's solve() writes must match the oracle."""
+    import ctypes as C
+    import pod
+    import tinympc_amd as tm
+    L = tm.lib()
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    suite = sc.tracking_random_suite(B=5, seed=123)
+    ref = sc.run_cases(OracleSolver, suite)
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    L.tiny_setup.argtypes = [C.POINTER(C.POINTER(pod.TinySolver))] + [C.POINTER(pod.Mat)] * 5 + [C.c_double] + [C.c_int] * 4
+    L.tiny_set_bound_constraints.argtypes = [C.POINTER(pod.TinySolver)] + [C.POINTER(pod.Mat)] * 4
+    L.tiny_solve_batch.argtypes = [C.POINTER(C.POINTER(pod.TinySolver)), C.c_int]
+    L.tiny_destroy.argtypes = [C.POINTER(pod.TinySolver)]
+    keep, solvers = [], (C.POINTER(pod.TinySolver) * 5)()
+    for b in range(5):
+        ms = [pod.mat(prob["A"]), pod.mat(prob["B"]), pod.mat(prob["f"]), pod.mat(np.diag(prob["Q"])), pod.mat(np.diag(prob["R"]))]
+        keep.append(ms)
+        sp = C.POINTER(pod.TinySolver)()
+        assert L.tiny_setup(C.byref(sp), *[C.byref(m[0]) for m in ms], prob["rho"], nx, nu, N, 0) == 0
+        cfg = suite["config"]
+        bs = [pod.mat(cfg[k]) for k in ("x_min", "x_max", "u_min", "u_max")]
+        keep.append(bs)
+        assert L.tiny_set_bound_constraints(sp, *[C.byref(m[0]) for m in bs]) == 0
+        sp.contents.settings.contents.max_iter = cfg["max_iter"]
+        w = sp.contents.work.contents
+        pod.to_np(w.Xref)[...] = suite["cases"]["Xref"][b]
+        pod.to_np(w.Uref)[...] = suite["cases"]["Uref"][b]
+        pod.to_np(w.x)[:, 0] = suite["cases"]["x0"][b]
+        solvers[b] = sp
+    rc = L.tiny_solve_batch(solvers, 5)
+    assert rc == int(np.any(ref["sol_solved"] == 0))
+    for b in range(5):
+        s = solvers[b].contents
+        w = s.work.contents
+        assert w.iter == int(ref["iter"][b]) and w.status == int(ref["status"][b]) and s.solution.contents.solved == int(ref["sol_solved"][b])
+        for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "q", "r", "p", "d"):
+            assert rel_err(pod.to_np(getattr(w, k)), ref[k][b]) < RTOL, (b, k)
+        assert rel_err(pod.to_np(s.solution.contents.x), ref["sol_x"][b]) < RTOL
+        assert abs(w.primal_residual_input - ref["primal_residual_input"][b]) < 1e-11
+        L.tiny_destroy(solvers[b])

@@ -332,3 +332,22 @@ def load_problem(name):
                 Q=np.array(p["Q"], dtype=np.float64), R=np.array(p["R"], dtype=np.float64))
     extra = {k: v for k, v in p.items() if k not in prob and k != "source"}
     return prob, extra
+
+
+def random_problem(nx, nu, N):
+    """The synthetic problem family of BASELINE configs[4]: one shared (A, B, Q, R)
+    per (nx, nu, N) cell, seeded; A is scaled to spectral radius 0.95."""
+    rng = np.random.default_rng(1000 * nx + 10 * nu + N)
+    M = rng.standard_normal((nx, nx))
+    A = M * 0.95 / np.max(np.abs(np.linalg.eigvals(M)))
+    B = rng.standard_normal((nx, nu)) / np.sqrt(nx)
+    Q = rng.uniform(1, 10, nx)
+    R = rng.uniform(0.1, 1, nu)
+    return dict(nx=nx, nu=nu, N=N, rho=1.0, A=A, B=B, f=np.zeros(nx), Q=Q, R=R), rng
+
+
+def flops_per_iter(nx, nu, N):
+    """FLOPs of one ADMM iteration with box constraints (footnote 1)."""
+    S = nx * N + nu * (N - 1)
+    return (4 * S + 2 * nx * nx + 3 * nx + (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nu * nu + 2 * nu + 3 * nx)
+            + (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nx + 2 * nu) + 11 * S)

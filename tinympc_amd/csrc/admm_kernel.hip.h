@@ -265,8 +265,16 @@ __device__ __forceinline__ double soc_component(double s0, double s1, double s2,
 // slot s = knot s.  Input lanes: slot s = knot s-1 (slot 0 is a neutral dummy), because the forward
 // step i produces x_{i+1} on the state lanes and u_i on the input lanes in the SAME instruction
 // stream -- storing both at slot i+1 needs no per-lane select.
+// Register budget: 6 N-long FP64 arrays per lane (+2 with a cone) + the matrix rows.  N <= 12 fits the
+// 256-VGPR budget of two waves per SIMD; longer horizons take the whole 512-entry file (one wave per SIMD).
+constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
+    return (n <= 10 || 2 * ((soc ? 8 : 6) * n + 2 * nz + 8) + 40 <= 256) ? 2 : 1;
+}
+
 template <int NX, int NU, int N, bool SOC, bool DBG, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void admm_solve_kernel(const SolveArgs P) {
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(solve_kernel_waves_per_simd(NX + NU, N, SOC), solve_kernel_waves_per_simd(NX + NU, N, SOC))))
+void admm_solve_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
     const int lane = threadIdx.x & 63;

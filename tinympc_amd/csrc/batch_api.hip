@@ -285,9 +285,17 @@ static int launch_general(TinyBatch* b) {
     a.tlin_s = b->set.en_tv_state_linear; a.tlin_i = b->set.en_tv_input_linear;
     a.nsl = b->nsl; a.nil = b->nil; a.ntsl = b->ntsl; a.ntil = b->ntil;
     const int nz = b->nx + b->nu;
-    const size_t lds = (size_t)(4 * nz * (nz + 1) + nz + b->nu + b->nx) * sizeof(double);
+    const size_t lds = (size_t)(4 * nz * (nz + 1) + nz + b->nu + b->nx + 3 * b->N * nz) * sizeof(double);
+    if (lds > 160 * 1024) return fail(b, TINY_ERR_UNSUPPORTED, "(nx,nu,N)=(%d,%d,%d) needs %zu B of LDS per instance (> 160 KiB)", b->nx, b->nu, b->N, lds);
+    if (lds > 64 * 1024 && lds > b->general_lds_limit) {
+        HIP_TRY(b, hipFuncSetAttribute(reinterpret_cast<const void*>(admm_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        b->general_lds_limit = lds;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) per_cu = 1;
     int grid = b->batch;
-    const long cap = (long)b->num_cus * 8;
+    const long cap = (long)b->num_cus * per_cu;
     if (cap < grid) grid = (int)cap;
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));

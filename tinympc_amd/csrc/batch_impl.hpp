@@ -47,7 +47,7 @@ struct TinyBatch {
     int4* d_status = nullptr;
     uint2* d_accum = nullptr;
     double *d_lslack = nullptr, *d_ldual = nullptr, *d_tlslack = nullptr, *d_tldual = nullptr, *d_gtab = nullptr;
-    size_t gtab_doubles = 0;
+    size_t gtab_doubles = 0, general_lds_limit = 0;
     std::vector<double> h_gtab;
     tinympc_amd::GeneralArgs gargs;      // table offsets filled by build_general_tables
     bool force_general = false;

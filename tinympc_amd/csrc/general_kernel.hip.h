@@ -6,8 +6,9 @@
 // (nx+nu <= 16, N-long register arrays, box + cone).  This kernel trades speed for generality:
 //   * one wavefront per instance (persistent, grid-stride), lane j = row j of the stacked knot vector for the
 //     Riccati sweeps, all 64 lanes striding over the record for the element-wise phases;
-//   * the ADMM state stays in the instance's HBM records (knot-point interleaved, same layout as the fast
-//     path) and is L2-resident across iterations; q|r and p|d live in two extra work records;
+//   * the slack / dual state stays in the instance's HBM records (knot-point interleaved, same layout as the
+//     fast path, L2-resident across iterations); the trajectories the sequential sweeps walk (x|u, q|r, p|d)
+//     are staged in LDS for the whole solve, so a sweep step never waits on global memory;
 //   * the shared matrices sit in LDS ([row][nz+1] padded: conflict-free row reads), the knot vector being
 //     multiplied is broadcast-read from LDS.  That formulation is LDS-bandwidth bound (see admm_kernel.hip.h)
 //     -- acceptable for a coverage path, and it has no shape restriction.
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
     double* sW = sPT + nz * ld;        // [nz]  knot vector being multiplied
     double* sU = sW + nz;              // [nu]
     double* sPX = sU + nu;             // [nx]  terminal term -(Xref' Pinf)
+    double* sX = sPX + nx;             // [N*nz] x|u trajectory (work->x, work->u)
+    double* sQR = sX + N * nz;         // [N*nz] q|r
+    double* sPD = sQR + N * nz;        // [N*nz] p|d
     for (int e = lane; e < nz * ld; e += 64) {
         sMB[e] = P.gtab[P.o_mb + e]; sMF1[e] = P.gtab[P.o_mf1 + e];
         sMF2[e] = P.gtab[P.o_mf2 + e]; sPT[e] = P.gtab[P.o_pt + e];
@@ -101,9 +105,11 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
     for (int b = blockIdx.x; b < P.batch; b += gridDim.x) {
         const size_t rec = (size_t)b * rec_n;
         // ---- per-solve setup: x[:,0] = x0, terminal term, slack initialisation (admm.cpp:352-376)
+        for (int e = lane; e < rec_n; e += 64) sX[e] = P.prim[rec + e];   // previous solve's x|u (cone / linear slack init)
+        __syncthreads();
         if (is_state) {
             const double x0v = P.x0[(size_t)b * nx + lane];
-            P.prim[rec + lane] = x0v;
+            sX[lane] = x0v;
             double acc = 0.0;
             for (int k = 0; k < nx; ++k) acc = fma(P.ref[rec + (size_t)(N - 1) * nz + k], sPT[lane * ld + k], acc);
             sPX[lane] = -acc;                                          // admm.cpp:292
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
             const int i = e / nz, j = e - i * nz;
             const bool st = j < nx;
             if (!st && i == N - 1) continue;
-            const double xv = P.prim[rec + e];
+            const double xv = sX[e];
             if (st ? P.soc_s : P.soc_i) P.cslack[rec + e] = xv;        // vcnew = x / zcnew = u
             if (st ? P.lin_s : P.lin_i) P.lslack[rec + e] = xv;        // vlnew = x / zlnew = u
             if (st ? P.tlin_s : P.tlin_i) P.tlslack[rec + e] = xv;     // vlnew_tv / zlnew_tv
@@ -145,40 +151,40 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
                     const double tt = rho * (P.tlslack[rec + e] - P.tldual[rec + e]);             // :275 / :288 / :301
                     qv -= tt; pv -= tt;
                 }
-                P.qr[rec + e] = qv;
-                if (st && i == N - 1) P.pd[rec + e] = pv;
+                sQR[e] = qv;
+                if (st && i == N - 1) sPD[e] = pv;
             }
             __syncthreads();
             // ---- backward_pass_grad (admm.cpp:13-20)
-            if (is_state) sW[lane] = P.pd[rec + (size_t)(N - 1) * nz + lane];
+            if (is_state) sW[lane] = sPD[(N - 1) * nz + lane];
             for (int i = N - 2; i >= 0; --i) {
-                const size_t o = rec + (size_t)i * nz;
-                if (is_input) sW[lane] = P.qr[o + lane];               // r_i
+                const int o = i * nz;
+                if (is_input) sW[lane] = sQR[o + lane];                // r_i
                 __syncthreads();
                 double acc = 0.0;
                 if (lane < nz)
                     for (int k = 0; k < nz; ++k) acc = fma(sMB[lane * ld + k], sW[k], acc);
                 __syncthreads();
                 if (is_state) {
-                    const double p = P.qr[o + lane] + acc + CB[lane];  // q_i + AmBKt p - Kinf' r + APf
-                    P.pd[o + lane] = p;
+                    const double p = sQR[o + lane] + acc + CB[lane];   // q_i + AmBKt p - Kinf' r + APf
+                    sPD[o + lane] = p;
                     sW[lane] = p;
                 } else if (is_input) {
-                    P.pd[o + lane] = acc + CB[lane];                   // d_i = Quu_inv (B' p + r + BPf)
+                    sPD[o + lane] = acc + CB[lane];                    // d_i = Quu_inv (B' p + r + BPf)
                 }
             }
             __syncthreads();
             // ---- forward_pass (admm.cpp:25-32)
-            if (is_state) sW[lane] = P.prim[rec + lane];
+            if (is_state) sW[lane] = sX[lane];
             for (int i = 0; i < N - 1; ++i) {
-                const size_t o = rec + (size_t)i * nz;
+                const int o = i * nz;
                 __syncthreads();
                 double acc = 0.0;
                 if (lane < nz)
                     for (int k = 0; k < nx; ++k) acc = fma(sMF1[lane * ld + k], sW[k], acc);
                 if (is_input) {
-                    const double u = acc - P.pd[o + lane];             // -Kinf x_i - d_i
-                    P.prim[o + lane] = u;
+                    const double u = acc - sPD[o + lane];              // -Kinf x_i - d_i
+                    sX[o + lane] = u;
                     sU[lane - nx] = u;
                 }
                 __syncthreads();
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
                     double xn = acc;
                     for (int m = 0; m < nu; ++m) xn = fma(sMF2[lane * ld + nx + m], sU[m], xn);
                     xn += CF[lane];
-                    P.prim[o + nz + lane] = xn;
+                    sX[o + nz + lane] = xn;
                     sW[lane] = xn;
                 }
             }
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
                 const int i = e / nz, j = e - i * nz;
                 const bool st = j < nx;
                 if (!st && i == N - 1) continue;
-                const double xv = P.prim[rec + e];
+                const double xv = sX[e];
                 const double t = xv + P.dual[rec + e];
                 const double vn = fmin(HI[i * nz + j], fmax(LO[i * nz + j], t));
                 const double pr = fabs(xv - vn), du = fabs(P.slack_prev[rec + e] - vn);
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
                     const int i = e / nz, j = e - i * nz;
                     const bool st = j < nx;
                     if (!st && i == N - 1) continue;
-                    const double xv = P.prim[rec + e];
+                    const double xv = sX[e];
                     if (st ? P.soc_s : P.soc_i) P.cdual[rec + e] = (P.cdual[rec + e] + xv) - P.cslack[rec + e];
                     if (st ? P.lin_s : P.lin_i) P.ldual[rec + e] = (P.ldual[rec + e] + xv) - P.lslack[rec + e];
                     if (st ? P.tlin_s : P.tlin_i) P.tldual[rec + e] = (P.tldual[rec + e] + xv) - P.tlslack[rec + e];
@@ -285,7 +291,14 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
                 P.slack_prev[rec + e] = P.slack[rec + e];
             }
         }
-        if (P.x0_next && is_state) P.x0_next[(size_t)b * nx + lane] = P.prim[rec + nz + lane];
+        for (int e = lane; e < rec_n; e += 64) {                       // trajectories back to the HBM records
+            const int i = e / nz, j = e - i * nz;
+            if (j >= nx && i == N - 1) continue;
+            P.prim[rec + e] = sX[e];
+            P.qr[rec + e] = sQR[e];
+            P.pd[rec + e] = sPD[e];
+        }
+        if (P.x0_next && is_state) P.x0_next[(size_t)b * nx + lane] = sX[nz + lane];
         if (lane == 0) {
             P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
             *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(r_ps, r_pi, r_ds, r_di);
