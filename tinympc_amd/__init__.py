@@ -55,7 +55,7 @@ def build(force: bool = False) -> str:
     """Compile libtinympc_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j", str(min(16, os.cpu_count() or 1))], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 

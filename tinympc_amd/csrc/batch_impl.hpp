@@ -6,13 +6,11 @@
 #include <vector>
 
 #include "../../include/tinympc_amd.h"
-#include "admm_kernel.hip.h"
+#include "kernel_entry.hpp"
 #include "general_kernel.hip.h"
 #include "cache.hpp"
 
 namespace tinympc_amd {
-
-struct KernelEntry;
 
 struct Settings {              // TinySettings (types.hpp:63-82) hot-path subset; defaults tiny_api.cpp:413-441
     double abs_pri_tol = 1e-3, abs_dua_tol = 1e-3;
