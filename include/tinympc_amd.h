@@ -158,9 +158,16 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * "force_general" (1: use the coverage kernel even when a
  * register-resident instantiation exists), "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
  * x0 <- A x0 + B u[:,0] + f, solve, ... -- inside ONE launch with the ADMM state held in registers;
- * references stay fixed during the launch), "step_log" (1: keep per-step iteration counts / u0). */
+ * references stay fixed during the launch), "step_log" (1: keep per-step iteration counts / u0),
+ * "reset_duals" (1: g = 0, y = 0 before every solve, examples/quadrotor_tracking.cpp:92-93), "traj_step". */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
+/* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state
+ * vectors ([n_points][nx] doubles), shared by every instance.  While it is set, the state reference of a solve
+ * is the N-knot window starting at (MPC step counter + offsets[instance]); the counter starts at 0, advances by
+ * one per MPC step (also inside fused launches) and can be moved with set_option("traj_step", k).  offsets may be
+ * NULL; xref_points == NULL switches back to the per-instance Xref records.  Register-resident shapes only. */
+int tiny_batch_set_reference_trajectory(TinyBatch* b, const double* xref_points, int n_points, const int* offsets, int flags);
 /* After a launch with "steps_per_launch" = T > 1 and "step_log" = 1: per fused MPC step and instance,
  * iters[T][batch] (negative = that solve hit max_iter) and the applied control u0[T][batch][nu]. */
 int tiny_batch_get_step_log(TinyBatch* b, int* iters, double* u0, int steps);

@@ -212,6 +212,38 @@ def test_fused_closed_loop_steps(T):
     assert sf[7] == sa[7] == 882.0 * B and sf[8] == sa[8] == 95.0 * B
 
 
+@pytest.mark.parametrize("T", [97, 1])
+def test_fused_tracking_episode(T):
+    """examples/quadrotor_tracking.cpp on device: a shared 301-point reference trajectory whose N-knot window advances
+    one knot per MPC step, duals reset before every solve, plant stepped on device.  291 steps in 3 launches of 97
+    (or 291 launches of 1) must reproduce the reference's per-step iteration sequence (725 total) and final state."""
+    gold = np.load(os.path.join(GOLDEN, "tracking_episode.npz"))
+    suite, _ = sc.load_suite(os.path.join(GOLDEN, "hover_warm.npz"))
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    traj = np.array(extra["y_axis_line"])
+    B = 37
+    s = make_batch(suite, batch=B)
+    s.set_reference_trajectory(traj)
+    s.set_option("reset_duals", 1)
+    s.set_option("advance_x0", 1)
+    s.set_option("steps_per_launch", T)
+    s.set_option("step_log", 1)
+    s.set_x0(traj[0], broadcast=True)
+    its = []
+    for _ in range(291 // T):
+        s.solve_async()
+        if T > 1:
+            its.append(s.step_log(T)[0])
+        else:
+            its.append(s.status()["iter"][None, :] * np.where(s.status()["solved"] == 1, 1, -1)[None, :])
+    its = np.concatenate(its)
+    assert np.all(its == its[:, :1])
+    assert np.array_equal(np.abs(its[:, 0]), gold["iters"]) and int(np.abs(its[:, 0]).sum()) == 725
+    x_final = s.get("x0")
+    assert rel_err(x_final[0], gold["x_final"]) < 1e-6 and np.all(x_final == x_final[0])
+    s.close()
+
+
 def test_tracking_full_batch_properties():
     """BASELINE config 3 at full size (262 144 instances, per-instance random references): the first
     4096 instances are checked against the oracle, the rest through properties (iteration counts in

@@ -39,7 +39,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
-    "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
+    "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
 REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
@@ -90,6 +90,7 @@ def lib():
         L.tiny_batch_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.tiny_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_get_timing.argtypes = [C.c_void_p, _fp, C.c_int]
+        L.tiny_batch_set_reference_trajectory.argtypes = [C.c_void_p, _dp, C.c_int, _ip, C.c_int]
         L.tiny_batch_get_step_log.argtypes = [C.c_void_p, _ip, _dp, C.c_int]
         L.tiny_batch_last_error.argtypes = [C.c_void_p]
         L.tiny_batch_last_error.restype = C.c_char_p
@@ -310,6 +311,18 @@ class TinyBatchSolver:
         buf = np.zeros(capacity, dtype=np.float32)
         n = lib().tiny_batch_get_timing(self._h, buf.ctypes.data_as(_fp), capacity)
         return buf[:max(n, 0)].astype(np.float64)
+
+    def set_reference_trajectory(self, xref_points, offsets=None):
+        """xref_points: [n_points, nx] shared state-reference trajectory; the solve at MPC step k tracks the window
+        k + offsets[b] ... + N - 1 (examples/quadrotor_tracking.cpp).  None removes it."""
+        if xref_points is None:
+            self._check(lib().tiny_batch_set_reference_trajectory(self._h, None, 0, None, HOST), "set_reference_trajectory")
+            return
+        t = _f64(xref_points).reshape(-1, self.nx)
+        off = None if offsets is None else np.ascontiguousarray(np.asarray(offsets, dtype=np.int32).ravel())
+        self._check(lib().tiny_batch_set_reference_trajectory(
+            self._h, t.ctypes.data_as(_dp), t.shape[0], None if off is None else off.ctypes.data_as(_ip), HOST),
+            "set_reference_trajectory")
 
     def step_log(self, steps):
         """(iters[steps, batch] (negative: hit max_iter), u0[steps, batch, nu]) of the last fused launch."""

@@ -81,6 +81,13 @@ struct SolveArgs {
     double rho, tol_pri, tol_dua;
     int batch, max_iter, check_termination;
     int steps;                // closed-loop MPC steps fused into this launch (>= 1; > 1 implies the plant step)
+    // Reference-trajectory window (examples/quadrotor_tracking.cpp:65,89): when traj != nullptr the state
+    // reference of MPC step k is traj[k + offset_b + 0 .. N-1][nx] (shared by all instances) instead of the
+    // Xref part of the ref record; the window advances one knot per fused step.
+    const double* traj;       // [traj_points][nx] or nullptr
+    const int* traj_offsets;  // optional [batch] per-instance start offsets
+    int traj_points, traj_step0;
+    int reset_duals;          // 1: g = 0, y = 0 before every solve (examples/quadrotor_tracking.cpp:92-93)
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -347,14 +354,16 @@ void admm_solve_kernel(const SolveArgs P) {
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
             double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;           // tiny_set_x0
-            {   // terminal cost  -(Xref[:,N-1]^T Pinf)   (admm.cpp:292); only state lanes' ref_last is broadcast
+            auto terminal_term = [&]() {   // -(Xref[:,N-1]^T Pinf) (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
                 for (int k = 0; k < NX; ++k) pt[k] = sPt[k * 16 + j];
                 const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
                 QX[N - 1] = is_state ? -xp : QX[N - 1];
-            }
+            };
+            if (!P.traj) terminal_term();
+            const int traj_k0 = P.traj ? (P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0)) : 0;
 
             int iter = 0, solved = 0, checked = 0;
             unsigned acc_iter = 0, acc_solved = 0;
@@ -362,6 +371,23 @@ void admm_solve_kernel(const SolveArgs P) {
             const int nsteps = P.steps > 1 ? P.steps : 1;
             for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch
                 X[0] = x0v;                                    // work->x.col(0) = x0
+                if (P.traj) {                                  // work->Xref = Xref_total.block(0, k, nx, N)
+                    if (is_state) {
+#pragma unroll
+                        for (int s = 0; s < N; ++s) {
+                            int kk = traj_k0 + step + s;
+                            kk = kk < P.traj_points ? kk : P.traj_points - 1;
+                            const double r = P.traj[(size_t)kk * NX + j];
+                            QX[s] = -(r * qr);
+                            if (s == N - 1) ref_last = r;
+                        }
+                    }
+                    terminal_term();
+                }
+                if (P.reset_duals) {                           // work->y = 0; work->g = 0
+#pragma unroll
+                    for (int s = 0; s < N; ++s) G[s] = 0.0;
+                }
                 if constexpr (SOC) {
                     if (step > 0) {                            // vcnew = x, zcnew = u of the previous solve (admm.cpp:352-357)
 #pragma unroll

@@ -58,7 +58,11 @@ struct TinyBatch {
     // options
     bool advance_x0 = false, debug = false;
     int grid_waves_per_cu = 0, dpp_mode = 2, steps_per_launch = 1;
-    bool step_log = false;
+    bool step_log = false, reset_duals = false;
+    double* d_traj = nullptr;
+    int* d_traj_offsets = nullptr;
+    int traj_points = 0;
+    long traj_step = 0;
     // timing
     std::vector<hipEvent_t> ev_start, ev_stop;
     int timing_n = 0, timing_left = 0;
