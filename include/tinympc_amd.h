@@ -95,6 +95,15 @@ int tiny_batch_device_count(void);
 int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn,
                      const double* Qdiag, const double* Rdiag, double rho,
                      int nx, int nu, int N, int batch, int device, int verbose);
+/* Heterogeneous batch: instance i has its OWN (A_i, B_i, f_i, Q_i, R_i, rho_i) -- arrays with a leading batch
+ * axis ([batch][nx*nx] column-major, [batch][nx*nu], [batch][nx] (may be NULL), [batch][nx], [batch][nu], [batch]).
+ * tiny_precompute_and_set_cache (tiny_api.cpp:307-381) runs on the GPU for all instances at once; the solve kernel
+ * then streams each instance's own cache.  Bounds, cones and settings stay shared.  nx + nu <= 16, registered N. */
+int tiny_batch_setup_hetero(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn,
+                            const double* Qdiag, const double* Rdiag, const double* rho,
+                            int nx, int nu, int N, int batch, int device, int verbose);
+/* one instance's cache member (names as tiny_batch_get_cache, plus "riccati_iters") */
+int tiny_batch_get_cache_instance(TinyBatch* b, int instance, const char* name, double* out, int capacity);
 int tiny_batch_destroy(TinyBatch* b);
 
 /* == tiny_set_bound_constraints (tiny_api.hpp:13-15): nx x N, nx x N, nu x (N-1), nu x (N-1),

@@ -1,0 +1,110 @@
+"""GPU tests of heterogeneous problem families: every instance has its own
+(A, B, f, Q, R, rho); the Riccati recursion of tiny_precompute_and_set_cache runs on the GPU for all instances.
+Each instance is checked against its OWN oracle solver."""
+import numpy as np
+import pytest
+
+import scenarios as sc
+import tinympc_amd as tm
+from cpu_solvers import OracleSolver
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def random_family(nx, nu, N, seed):
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((nx, nx))
+    A = M * rng.uniform(0.7, 0.99) / np.max(np.abs(np.linalg.eigvals(M)))
+    return dict(nx=nx, nu=nu, N=N, rho=float(rng.uniform(0.5, 5.0)), A=A, B=rng.standard_normal((nx, nu)) / np.sqrt(nx),
+                f=rng.normal(0, 0.01, nx), Q=rng.uniform(1, 10, nx), R=rng.uniform(0.1, 1, nu))
+
+
+def test_identical_instances_reproduce_the_host_cache():
+    """The device recursion follows the host code's operation order (no FMA contraction): same Riccati step count,
+    caches equal to rounding."""
+    prob, _ = sc.load_problem("quadrotor_20hz")
+    B = 6
+    het = tm.TinyBatchSolver.hetero(np.stack([prob["A"]] * B), np.stack([prob["B"]] * B), np.stack([prob["f"]] * B),
+                                    np.stack([prob["Q"]] * B), np.stack([prob["R"]] * B), np.full(B, prob["rho"]), prob["N"])
+    hom = tm.TinyBatchSolver.from_problem(prob, B)
+    worst = 0.0
+    for name in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "APf", "BPf", "Q", "R"):
+        for i in (0, B - 1):
+            e = rel_err(het.cache_instance(i, name), hom.cache(name))
+            worst = max(worst, e)
+            assert e < 1e-13, (name, e)
+    print("worst device-vs-host cache deviation", worst)
+    assert int(het.cache_instance(3, "riccati_iters")[0, 0]) == 55
+    het.close()
+    hom.close()
+
+
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 10), (6, 3, 10), (4, 2, 30)])
+def test_every_instance_matches_its_own_oracle(nx, nu, N):
+    B = 11
+    fams = [random_family(nx, nu, N, 900 + 17 * i + nx) for i in range(B)]
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (B, nx))
+    Xref = np.repeat(rng.uniform(-0.3, 0.3, (B, nx, 1)), N, axis=2) + rng.normal(0, 0.02, (B, nx, N))
+    Uref = rng.normal(0, 0.05, (B, nu, N - 1))
+    s = tm.TinyBatchSolver.hetero(np.stack([f["A"] for f in fams]), np.stack([f["B"] for f in fams]),
+                                  np.stack([f["f"] for f in fams]), np.stack([f["Q"] for f in fams]),
+                                  np.stack([f["R"] for f in fams]), np.array([f["rho"] for f in fams]), N)
+    s.set_bound_constraints(np.full((nx, 1), -2.0), np.full((nx, 1), 2.0), np.full((nu, 1), -0.4), np.full((nu, 1), 0.4))
+    s.update_settings(max_iter=150)
+    s.set_x0(x0)
+    s.set_x_ref(Xref)
+    s.set_u_ref(Uref)
+    s.solve()
+    st = s.status()
+    out = {k: s.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z")}
+    # second, warm-started solve from a moved x0 (the per-instance cache must persist)
+    s.set_x0(x0 * 0.9)
+    s.solve()
+    st2 = s.status()
+    out2 = {k: s.get(k) for k in ("x", "u", "g")}
+    for i, fam in enumerate(fams):
+        cfg = sc.default_config(fam, max_iter=150, x_min=np.full((nx, 1), -2.0), x_max=np.full((nx, 1), 2.0),
+                                u_min=np.full((nu, 1), -0.4), u_max=np.full((nu, 1), 0.4))
+        o = sc.make_solver(OracleSolver, fam, cfg)
+        for name in ("Kinf", "Pinf", "Quu_inv", "AmBKt", "APf", "BPf"):
+            assert rel_err(s.cache_instance(i, name), o[name]) < 1e-12, (i, name)
+        o["Xref"], o["Uref"] = Xref[i], Uref[i]
+        o["x"][:, 0] = x0[i]
+        o.solve()
+        assert int(o.get("sol_iter")) == st["iter"][i] and int(o.get("sol_solved")) == st["solved"][i], i
+        for k in out:
+            assert rel_err(out[k][i], o[k]) < RTOL, (i, k)
+        o["x"][:, 0] = x0[i] * 0.9
+        o.solve()
+        assert int(o.get("sol_iter")) == st2["iter"][i], i
+        for k in out2:
+            assert rel_err(out2[k][i], o[k]) < RTOL, (i, k, "warm")
+        o.close()
+    s.close()
+
+
+def test_hetero_large_batch_precompute():
+    """65 536 different quadrotor-like families: the batched Riccati precompute finishes and every cache is finite."""
+    B, nx, nu, N = 65536, 12, 4, 10
+    prob, _ = sc.load_problem("quadrotor_20hz")
+    rng = np.random.default_rng(1)
+    A = prob["A"][None] + rng.normal(0, 1e-3, (B, nx, nx))
+    Bm = prob["B"][None] * (1 + rng.normal(0, 0.05, (B, 1, 1)))
+    s = tm.TinyBatchSolver.hetero(A, Bm, None, np.tile(prob["Q"], (B, 1)), np.tile(prob["R"], (B, 1)),
+                                  rng.uniform(3.0, 7.0, B), N)
+    for i in (0, 12345, B - 1):
+        assert np.all(np.isfinite(s.cache_instance(i, "Pinf"))) and 5 < s.cache_instance(i, "riccati_iters")[0, 0] < 1000
+    s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+    s.update_settings(max_iter=100)
+    s.set_x_ref(np.tile(np.array([0, 0, 2.0] + [0] * 9).reshape(nx, 1), (1, N)), broadcast=True)
+    s.set_x0(np.array([0, 1, 0, 0.2, 0, 0, 0.1, 0, 0, 0, 0, 0.0]), broadcast=True)
+    s.solve()
+    st = s.reduce_stats()
+    assert st[0] > 0 and np.all(np.isfinite(s.get("u")))
+    s.close()

@@ -34,7 +34,8 @@ STATE_FIELDS = {"Xref", "x", "vnew", "g", "v", "vcnew", "gc", "q", "p", "vlnew",
 
 # every extern "C" symbol include/tinympc_amd.h declares (checked by tests/test_abi_symbols.py)
 BATCH_SYMBOLS = (
-    "tiny_batch_device_count", "tiny_batch_setup", "tiny_batch_destroy", "tiny_batch_set_bound_constraints",
+    "tiny_batch_device_count", "tiny_batch_setup", "tiny_batch_setup_hetero", "tiny_batch_get_cache_instance",
+    "tiny_batch_destroy", "tiny_batch_set_bound_constraints",
     "tiny_batch_set_cone_constraints", "tiny_batch_set_linear_constraints", "tiny_batch_set_tv_linear_constraints",
     "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
@@ -72,6 +73,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.tiny_batch_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int]
+        L.tiny_batch_setup_hetero.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int]
+        L.tiny_batch_get_cache_instance.argtypes = [C.c_void_p, C.c_int, C.c_char_p, _dp, C.c_int]
         L.tiny_batch_destroy.argtypes = [C.c_void_p]
         L.tiny_batch_set_bound_constraints.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.tiny_batch_set_cone_constraints.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp]
@@ -147,6 +151,38 @@ class TinyBatchSolver:
                    ERR_UNSUPPORTED: f"(nx,nu,N)=({nx},{nu},{N}) has no compiled kernel; have {supported_dims()}",
                    ERR_DIM: "bad dimensions"}.get(rc, f"error {rc}")
             raise TinyMPCError(f"tiny_batch_setup failed: {msg}")
+
+    @classmethod
+    def hetero(cls, A, B, f, Q, R, rho, N, device=0):
+        """Heterogeneous batch: A [batch, nx, nx], B [batch, nx, nu], f [batch, nx] or None, Q [batch, nx], R [batch, nu]
+        (user diagonals), rho [batch].  The Riccati recursion runs on the GPU for every instance."""
+        A = np.asarray(A, dtype=np.float64)
+        Bm = np.asarray(B, dtype=np.float64)
+        batch, nx, nu = A.shape[0], A.shape[1], Bm.shape[2]
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.nx, self.nu, self.N, self.batch = nx, nu, int(N), batch
+        Af = np.ascontiguousarray(A.transpose(0, 2, 1)).ravel()          # column-major per instance
+        Bf = np.ascontiguousarray(Bm.transpose(0, 2, 1)).ravel()
+        ff = None if f is None else _f64(f).ravel()
+        Qf, Rf, rf = _f64(Q).ravel(), _f64(R).ravel(), _f64(np.broadcast_to(rho, (batch,))).ravel()
+        rc = lib().tiny_batch_setup_hetero(C.byref(self._h), Af.ctypes.data_as(_dp), Bf.ctypes.data_as(_dp),
+                                           None if ff is None else ff.ctypes.data_as(_dp), Qf.ctypes.data_as(_dp),
+                                           Rf.ctypes.data_as(_dp), rf.ctypes.data_as(_dp), nx, nu, int(N), batch, device, 0)
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise TinyMPCError(f"tiny_batch_setup_hetero failed ({rc})")
+        return self
+
+    def cache_instance(self, instance, name):
+        shapes = {"Kinf": (self.nu, self.nx), "Pinf": (self.nx, self.nx), "Quu_inv": (self.nu, self.nu),
+                  "AmBKt": (self.nx, self.nx), "APf": (self.nx, 1), "BPf": (self.nu, 1), "Q": (self.nx, 1),
+                  "R": (self.nu, 1), "riccati_iters": (1, 1)}
+        r, c = shapes[name]
+        out = np.zeros(r * c)
+        n = lib().tiny_batch_get_cache_instance(self._h, int(instance), name.encode(), out.ctypes.data_as(_dp), r * c)
+        assert n == r * c, (n, name)
+        return out.reshape((r, c), order="F")
 
     @classmethod
     def from_problem(cls, prob, batch, device=0):

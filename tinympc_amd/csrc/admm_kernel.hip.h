@@ -88,6 +88,9 @@ struct SolveArgs {
     const int* traj_offsets;  // optional [batch] per-instance start offsets
     int traj_points, traj_step0;
     int reset_duals;          // 1: g = 0, y = 0 before every solve (examples/quadrotor_tracking.cpp:92-93)
+    // Heterogeneous problem families (riccati_kernel.hip.h): per-instance matrix/vector tables
+    // ([batch][TAB_BOUNDS] doubles, same layout as `tab`); bounds, cones and masks stay shared.
+    const double* het_tabs;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -307,9 +310,9 @@ void admm_solve_kernel(const SolveArgs P) {
     for (int k = 0; k < NX; ++k) mf1[k] = P.tab[TAB_MF1 + k * 16 + j];
 #pragma unroll
     for (int k = 0; k < NU; ++k) mf2[k] = P.tab[TAB_MF2 + (NX + k) * 16 + j];
-    const double cb = P.tab[TAB_VEC + VEC_CB * 16 + j];
-    const double cf = P.tab[TAB_VEC + VEC_CF * 16 + j];
-    const double qr = P.tab[TAB_VEC + VEC_QR * 16 + j];
+    double cb = P.tab[TAB_VEC + VEC_CB * 16 + j];
+    double cf = P.tab[TAB_VEC + VEC_CF * 16 + j];
+    double qr = P.tab[TAB_VEC + VEC_QR * 16 + j];
     const double smask = P.tab[TAB_VEC + VEC_SMASK * 16 + j];
     const double nim = P.tab[TAB_VEC + VEC_NIM * 16 + j];
     bool soc_lane = false;
@@ -321,7 +324,7 @@ void admm_solve_kernel(const SolveArgs P) {
         cone_mu = P.tab[TAB_VEC + VEC_CONE_MU * 16 + j];
         cone_c = (cone_base >= 0) ? (j - cone_base) : 0;
     }
-    const double rho = P.rho;
+    double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
 
@@ -329,6 +332,19 @@ void admm_solve_kernel(const SolveArgs P) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile * 4 + grp;
         if (b < P.batch) {
+            const double* het = P.het_tabs ? P.het_tabs + (size_t)b * TAB_BOUNDS : nullptr;
+            if (het) {                                         // this instance's own cache (A, B, Q, R, rho differ per instance)
+#pragma unroll
+                for (int k = 0; k < NZ; ++k) mb[k] = het[TAB_MB + k * 16 + j];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) mf1[k] = het[TAB_MF1 + k * 16 + j];
+#pragma unroll
+                for (int k = 0; k < NU; ++k) mf2[k] = het[TAB_MF2 + (NX + k) * 16 + j];
+                cb = het[TAB_VEC + VEC_CB * 16 + j];
+                cf = het[TAB_VEC + VEC_CF * 16 + j];
+                qr = het[TAB_VEC + VEC_QR * 16 + j];
+                rho = het[TAB_VEC + 8 * 16 + j];               // VEC_RHO (riccati_kernel.hip.h)
+            }
             // record base of this lane: input lanes read knot s-1 at slot s
             const size_t lbase = (size_t)b * (N * NZ) + j - (is_input ? NZ : 0);
             double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
@@ -357,7 +373,7 @@ void admm_solve_kernel(const SolveArgs P) {
             auto terminal_term = [&]() {   // -(Xref[:,N-1]^T Pinf) (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
-                for (int k = 0; k < NX; ++k) pt[k] = sPt[k * 16 + j];
+                for (int k = 0; k < NX; ++k) pt[k] = het ? het[TAB_PT + k * 16 + j] : sPt[k * 16 + j];
                 const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
                 QX[N - 1] = is_state ? -xp : QX[N - 1];

@@ -8,6 +8,7 @@
 #include "../../include/tinympc_amd.h"
 #include "kernel_entry.hpp"
 #include "general_kernel.hip.h"
+#include "riccati_kernel.hip.h"
 #include "cache.hpp"
 
 namespace tinympc_amd {
@@ -60,6 +61,12 @@ struct TinyBatch {
     int grid_waves_per_cu = 0, dpp_mode = 2, steps_per_launch = 1;
     bool step_log = false, reset_duals = false;
     double* d_traj = nullptr;
+    // heterogeneous problem families: per-instance problem data, caches and lane tables (device)
+    bool hetero = false;
+    double *d_hA = nullptr, *d_hB = nullptr, *d_hf = nullptr, *d_hQw = nullptr, *d_hRw = nullptr, *d_hrho = nullptr,
+           *d_hK = nullptr, *d_hP = nullptr, *d_hQuu = nullptr, *d_hAmBKt = nullptr, *d_hAPf = nullptr, *d_hBPf = nullptr,
+           *d_het_tabs = nullptr;
+    int* d_hiters = nullptr;
     int* d_traj_offsets = nullptr;
     int traj_points = 0;
     long traj_step = 0;
