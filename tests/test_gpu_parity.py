@@ -342,3 +342,26 @@ def test_tiny_solve_batch_over_reference_structs():
         assert rel_err(pod.to_np(s.solution.contents.x), ref["sol_x"][b]) < RTOL
         assert abs(w.primal_residual_input - ref["primal_residual_input"][b]) < 1e-11
         L.tiny_destroy(solvers[b])
+
+
+def test_api_misuse_is_reported_not_ignored():
+    """Out-of-scope or malformed requests fail loudly with the documented codes (no silent fallback)."""
+    import ctypes as C
+    import tinympc_amd as tm
+    prob, _ = sc.load_problem("quadrotor_20hz")
+    with pytest.raises(tm.TinyMPCError):                       # nx + nu > 32
+        tm.TinyBatchSolver(np.eye(30), np.ones((30, 8)), None, np.ones(30), np.ones(8), 1.0, 30, 8, 10, 4)
+    s = tm.TinyBatchSolver.from_problem(prob, 4)
+    with pytest.raises(tm.TinyMPCError, match="cone dimension"):
+        s.set_cone_constraints([0], [4], [0.5], [], [], [])   # the reference's project_soc only handles 3 (admm.cpp:53)
+    with pytest.raises(tm.TinyMPCError, match="overlapping"):
+        s.set_cone_constraints([0, 2], [3, 3], [0.5, 0.5], [], [], [])
+    with pytest.raises(tm.TinyMPCError, match="out of range"):
+        s.set_cone_constraints([], [], [], [2], [3], [0.5])   # nu = 4: rows 2..4 do not exist
+    with pytest.raises(tm.TinyMPCError):
+        s.get("q")                                            # q/r/p/d need the debug option
+    s.set_option("steps_per_launch", 5)
+    s.update_settings(en_state_linear=1)                      # linear constraints run on the coverage kernel ...
+    with pytest.raises(tm.TinyMPCError, match="steps_per_launch"):
+        s.solve()                                             # ... which has no fused stepping
+    s.close()

@@ -7,8 +7,8 @@
 //                  BEFORE Ptp1 = Pinf, left-to-right products).  Arithmetic is not FMA-contracted and every
 //                  dot product runs in the same order as the host code (cache.hpp): identical problem data give
 //                  the same Riccati step count and caches equal to ~1e-13 on both paths (tests/test_gpu_hetero.py).
-// lane_tables_kernel : cache -> the per-instance lane tables admm_solve_kernel reads (same layout and the
-//                  same pre-multiplied Quu_inv B', Quu_inv BPf as batch_api.hip:build_tables).
+//                  Its epilogue turns the cache into the per-instance lane tables admm_solve_kernel reads (same
+//                  layout and the same pre-multiplied Quu_inv B', Quu_inv BPf as batch_api.hip:build_tables).
 #pragma once
 #include <hip/hip_runtime.h>
 
