@@ -185,6 +185,9 @@ int tiny_batch_get_timing(TinyBatch* b, float* ms, int capacity);
 const char* tiny_batch_last_error(TinyBatch* b);
 /* registered (nx,nu,N) kernel instantiations: writes up to capacity triples, returns the count */
 int tiny_batch_supported_dims(int* triples, int capacity);
+/* which kernel the next solve runs: 0 one-row register-resident kernel (admm_kernel.hip.h), 1 tile kernel
+ * (tile_kernel.hip.h: wide / long shapes, W x R DPP rows per instance), 2 coverage kernel (general_kernel.hip.h) */
+int tiny_batch_kernel_path(TinyBatch* b);
 /* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
  * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */
 long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold);

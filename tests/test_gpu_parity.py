@@ -104,6 +104,27 @@ def test_hip_matches_oracle_seeded(maker):
     assert_match(out, ref, RTOL, "seeded")
 
 
+@pytest.mark.parametrize("dims,B,max_iter", [((12, 8, 10), 7, 150), ((20, 2, 10), 5, 150), ((20, 4, 10), 6, 150), ((20, 8, 10), 9, 200),
+                                              ((4, 2, 50), 9, 200), ((12, 4, 50), 6, 120), ((8, 8, 50), 5, 120),
+                                              ((12, 8, 30), 3, 120), ((20, 8, 30), 3, 120), ((20, 4, 50), 3, 80), ((20, 8, 50), 2, 80)])
+def test_tile_kernel_matches_oracle(dims, B, max_iter):
+    """Wide (nx+nu > 16: W = 2 rows across the knot vector) and long (R = 2 rows along the horizon) shapes on the
+    register-resident tile kernel (tile_kernel.hip.h); ragged batches leave part of the last wavefront empty."""
+    import tinympc_amd as tm
+    suite = sc.sweep_suite(*dims, B=B, max_iter=max_iter)
+    probe = make_batch(suite)
+    assert probe.kernel_path() == "tile", probe.kernel_path()
+    probe.close()
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite)
+    assert_match(out, ref, RTOL, f"tile {dims}")
+    warm = dict(problem=suite["problem"], config=suite["config"], cases=dict(suite["cases"]))   # second solve from the warm state
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        warm["cases"][k] = ref[k]
+    warm["cases"]["x0"] = suite["cases"]["x0"] * 0.8
+    assert_match(run_cases_hip(warm), sc.run_cases(OracleSolver, warm), RTOL, f"tile warm {dims}")
+
+
 def test_persistent_grid_and_replication():
     """Same cases tiled 64x (4 instances per wave, many waves, persistent grid-stride tiles) must give
     bit-identical results to the single copy: no cross-instance interference."""

@@ -40,7 +40,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
-    "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes")
+    "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path")
 REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
@@ -99,6 +99,7 @@ def lib():
         L.tiny_batch_last_error.argtypes = [C.c_void_p]
         L.tiny_batch_last_error.restype = C.c_char_p
         L.tiny_batch_supported_dims.argtypes = [_ip, C.c_int]
+        L.tiny_batch_kernel_path.argtypes = [C.c_void_p]
         L.tiny_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int]
         L.tiny_batch_algorithmic_bytes.restype = C.c_long
         _lib = L
@@ -367,6 +368,9 @@ class TinyBatchSolver:
         self._check(lib().tiny_batch_get_step_log(self._h, it.ctypes.data_as(_ip), u0.ctypes.data_as(_dp), steps),
                     "get_step_log")
         return it, u0
+
+    def kernel_path(self) -> str:
+        return {0: "regs", 1: "tile", 2: "cover"}[lib().tiny_batch_kernel_path(self._h)]
 
     def algorithmic_bytes(self, cold=False) -> int:
         return int(lib().tiny_batch_algorithmic_bytes(self._h, 1 if cold else 0))

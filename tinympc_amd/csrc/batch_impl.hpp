@@ -9,6 +9,7 @@
 #include "kernel_entry.hpp"
 #include "general_kernel.hip.h"
 #include "riccati_kernel.hip.h"
+#include "tile_kernel.hip.h"
 #include "cache.hpp"
 
 namespace tinympc_amd {
@@ -25,6 +26,10 @@ struct Settings {              // TinySettings (types.hpp:63-82) hot-path subset
 struct TinyBatch {
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0, num_cus = 256;
     const tinympc_amd::KernelEntry* kernel = nullptr;
+    const tinympc_amd::TileEntry* tile = nullptr;      // tile_kernel.hip.h instantiation for this shape, if any
+    double* d_ttab = nullptr;
+    std::vector<double> h_ttab;
+    bool no_tile = false;
     // host copies of the problem family
     tinympc_amd::Mat A, B, f;
     std::vector<double> Qw, Rw;                    // work->Q, work->R (user + rho)

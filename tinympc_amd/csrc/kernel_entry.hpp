@@ -8,6 +8,10 @@ struct KernelEntry {
     int nx, nu, N;
     SolveKernel k[2][2][3];   // [soc][dbg][dpp_mode]
 };
+struct TileEntry {
+    int nx, nu, N, W, R;
+    SolveKernel k;
+};
 }  // namespace tinympc_amd
 
 #define KERNELS_MODES(NX, NU, NN, S, D)                                                          \

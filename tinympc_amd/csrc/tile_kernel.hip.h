@@ -1,0 +1,225 @@
+// tile_kernel.hip.h -- register-resident ADMM solve for shapes the one-row kernel (admm_kernel.hip.h) cannot
+// hold: knot vectors wider than 16 rows and/or horizons whose per-lane arrays exceed one lane's registers.
+//
+// An instance occupies a TILE of W x R DPP rows of a wavefront (W * R <= 4):
+//   * W = ceil((nx+nu)/16) rows ACROSS the stacked knot vector: lane (wrow, j16) owns row jj = 16*wrow + j16.
+//     y = M w then needs the other row's half of w: one v_permlane16_swap_b32 pair turns w into
+//     (a, b) = (even row's 16 values, odd row's 16 values) replicated in both rows, and the FMA chain is
+//     sum_k bcast(a,k) M[jj][k] + sum_k bcast(b,k) M[jj][16+k] with the same v_fmac_f64_dpp row_newbcast blocks.
+//   * R rows ALONG the horizon: row hrow owns slots [hrow*L, (hrow+1)*L), L = N/R, as L-long register arrays.
+//     The Riccati sweeps are sequential in the knot index, so the rows take turns (EXEC masks the others) and
+//     hand the running p_{i+1} / r_i (backward) or x_{i+1} | u_i (forward) to the neighbouring row through one
+//     cross-row shuffle per phase; every element-wise phase runs on all rows at once.
+// A whole wavefront's 128 KB of registers can therefore hold ONE large instance (e.g. nx=20, nu=8, N=50:
+// W=2, R=2) or two / four smaller ones.  Same arithmetic, slot convention (input lanes keep knot i in slot i+1),
+// HBM records and parity tests as the one-row kernel; box constraints, one MPC step per launch.
+#pragma once
+#include "admm_kernel.hip.h"
+
+namespace tinympc_amd {
+
+// table layout of the tile kernel (doubles): matrices [column k (0..31)][LW lanes], LW = 16*W
+template <int W>
+struct TileTab {
+    static constexpr int LW = 16 * W;
+    static constexpr int MB = 0, MF1 = 32 * LW, MF2 = 64 * LW, PT = 96 * LW, VEC = 128 * LW, BOUNDS = 128 * LW + 16 * LW;
+    static int doubles(int N) { return BOUNDS + 2 * N * LW; }
+};
+
+// (a, b) = (values of the even DPP row, values of the odd DPP row) of each 32-lane half, visible in both rows
+__device__ __forceinline__ void swap16(double v, double& a, double& b) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double(r1[0], r0[0]);
+    b = __hiloint2double(r1[1], r0[1]);
+}
+
+// init + sum_{k=C0}^{C1-1} M[jj][k] * w[k], w spread one entry per lane over W rows; m[k - C0] = M[jj][k]
+template <int W, int C0, int C1>
+__device__ __forceinline__ double tile_matvec(double init, double src, const double* m) {
+    double acc = init;
+    if constexpr (C1 > C0) {
+        if constexpr (W == 1) {
+            ring1<C0, C1 - C0>(acc, src, m);
+        } else {
+            double a, b;
+            swap16(src, a, b);
+            constexpr int E0 = C1 < 16 ? C1 : 16;          // end of the part that lives in the even row
+            constexpr int S1 = C0 > 16 ? C0 : 16;          // start of the part that lives in the odd row
+            if constexpr (C0 < 16) ring1<C0, E0 - C0>(acc, a, m);
+            if constexpr (C1 > 16) ring1<S1 - 16, C1 - S1>(acc, b, m + (S1 - C0));
+        }
+    }
+    return acc;
+}
+
+template <int NX, int NU, int N, int W, int R>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void admm_tile_kernel(const SolveArgs P) {
+    constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
+    static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4), "tile shape");
+    using T = TileTab<W>;
+    const int lane = threadIdx.x & 63, row = lane >> 4, j16 = lane & 15;
+    const int inst = row / RPI, sub = row % RPI, wrow = sub % W, hrow = sub / W;
+    const int jj = wrow * 16 + j16;
+    const bool is_state = jj < NX, is_input = jj >= NX && jj < NZ;
+
+    __shared__ double sLo[N * LW];
+    __shared__ double sHi[N * LW];
+    __shared__ double sX[(N / R) * 64];    // x|u trajectory of this wave: only a rolling value in the sweep, kept for the output
+    for (int e = lane; e < N * LW; e += 64) {
+        sLo[e] = P.tab[T::BOUNDS + e];
+        sHi[e] = P.tab[T::BOUNDS + N * LW + e];
+    }
+    double mb[NZ], mf1[NX], mf2[NU];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) mb[k] = P.tab[T::MB + k * LW + jj];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) mf1[k] = P.tab[T::MF1 + k * LW + jj];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) mf2[k] = P.tab[T::MF2 + (NX + k) * LW + jj];
+    const double cb = P.tab[T::VEC + VEC_CB * LW + jj];
+    const double cf = P.tab[T::VEC + VEC_CF * LW + jj];
+    const double qr = P.tab[T::VEC + VEC_QR * LW + jj];
+    const double smask = P.tab[T::VEC + VEC_SMASK * LW + jj];
+    const double nim = P.tab[T::VEC + VEC_NIM * LW + jj];
+    const double rho = P.rho;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const unsigned long long inst_mask =
+        (RPI == 4) ? ~0ull : ((((1ull << (16 * RPI)) - 1ull)) << (inst * 16 * RPI));
+    const int ntiles = (P.batch + IPW - 1) / IPW;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile * IPW + inst;
+        if (b < P.batch) {
+            const int g0 = hrow * L;                                   // first global slot of this row
+            double G[L], VN[L], VP[L], QX[L], Dn[L];
+            double ref_last = 0.0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int g = g0 + l;
+                const bool valid = is_state || (is_input && g >= 1);
+                const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
+                const double r = valid ? P.ref[off] : 0.0;
+                VN[l] = valid ? P.slack[off] : 0.0;
+                G[l] = valid ? P.dual[off] : 0.0;
+                VP[l] = valid ? P.slack_prev[off] : 0.0;
+                QX[l] = -(r * qr);
+                Dn[l] = 0.0;
+                if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
+            }
+            const double x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
+            {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
+                double pt[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) pt[k] = P.tab[T::PT + k * LW + jj];
+                const double xp = tile_matvec<W, 0, NX>(0.0, ref_last, pt);
+                if (hrow == R - 1 && is_state) QX[L - 1] = -xp;
+            }
+
+            int iter = 0, solved = 0, checked = 0, countdown = P.check_termination;
+            double rp = 0.0, rd = 0.0;
+            for (int it = 0; it < P.max_iter; ++it) {
+                // ---- backward_pass_grad (admm.cpp:13-20): the horizon rows take turns, last row first
+                double pcur = 0.0, qhi = 0.0;
+#pragma unroll
+                for (int ph = R - 1; ph >= 0; --ph) {
+                    if (ph < R - 1) {                                  // p_{i+1} | r_i handed down from the row above
+                        pcur = __shfl(pcur, (lane + LW) & 63);
+                        qhi = __shfl(qhi, (lane + LW) & 63);
+                    }
+                    if (hrow == ph) {
+#pragma unroll
+                        for (int l = L - 1; l >= 0; --l) {
+                            const double qlo = fma(-rho, VN[l] - G[l], QX[l]);          // admm.cpp:267 | :280 | :293
+                            if (ph == R - 1 && l == L - 1) {
+                                pcur = qlo;                                             // p_{N-1}
+                            } else {
+                                const double src = is_input ? qhi : pcur;
+                                const double res = tile_matvec<W, 0, NZ>(fma(qlo, smask, cb), src, mb);
+                                pcur = res;                                             // p_i | d_i
+                                Dn[l] = res * nim;
+                            }
+                            qhi = qlo;
+                        }
+                    }
+                }
+                // ---- forward_pass (admm.cpp:25-32) + slot updates, first row first
+                double pmax = 0.0, dmax = 0.0, xcarry = 0.0;
+#pragma unroll
+                for (int ph = 0; ph < R; ++ph) {
+                    if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);    // x_g | u_{g-1} of this row's first slot
+                    if (hrow == ph) {
+                        double xcur = (ph > 0) ? xcarry : x0v;         // x_g | u_{g-1} of the slot being processed
+#pragma unroll
+                        for (int l = 0; l < L; ++l) {
+                            const int g = ph * L + l;
+                            const double xi = xcur;
+                            sX[l * 64 + lane] = xi;
+                            if (g < N - 1) {
+                                const double t = tile_matvec<W, 0, NX>(Dn[l], xi, mf1);         // A x_i | u_i
+                                const double xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);       // + f + B u_i | u_i
+                                if (l + 1 < L) xcur = xn; else xcarry = xn;
+                            }
+                            const double tt = xi + G[l];
+                            const double vn = vmin64(sHi[g * LW + jj], vmax64(sLo[g * LW + jj], tt));
+                            pmax = fmax(pmax, fabs(xi - vn));
+                            dmax = fmax(dmax, fabs(VP[l] - vn));
+                            G[l] = tt - vn;
+                            VN[l] = vn;
+                        }
+                    }
+                }
+                iter += 1;
+                bool conv = false;
+                if (countdown > 0 && --countdown == 0) {
+                    countdown = P.check_termination;
+                    checked = 1;
+                    rp = pmax;
+                    rd = dmax * rho;
+                    const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
+                    const unsigned long long bal = __ballot(ok);
+                    conv = (bal & inst_mask) == inst_mask;
+                }
+                if (conv) { solved = 1; break; }
+#pragma unroll
+                for (int l = 0; l < L; ++l) VP[l] = VN[l];
+            }
+
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int g = g0 + l;
+                const bool valid = is_state || (is_input && g >= 1);
+                const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
+                if (valid) {
+                    P.prim[off] = sX[l * 64 + lane];
+                    P.slack[off] = VN[l];
+                    P.dual[off] = G[l];
+                    P.slack_prev[off] = VP[l];
+                }
+            }
+            if (P.x0_next && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = sX[64 + lane];
+            // residual maxima over the instance's lanes (state rows / input rows separately)
+            double ps = is_state ? rp : 0.0, pi = is_input ? rp : 0.0, ds = is_state ? rd : 0.0, di = is_input ? rd : 0.0;
+#pragma unroll
+            for (int off = 8 * RPI; off >= 1; off >>= 1) {
+                ps = fmax(ps, __shfl_xor(ps, off)); pi = fmax(pi, __shfl_xor(pi, off));
+                ds = fmax(ds, __shfl_xor(ds, off)); di = fmax(di, __shfl_xor(di, off));
+            }
+            if (sub == 0 && j16 == 0) {
+                P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
+                *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(ps, pi, ds, di);
+                if (P.accum) {
+                    uint2 ac = P.accum[b];
+                    ac.x += (unsigned)iter;
+                    ac.y += (unsigned)solved;
+                    P.accum[b] = ac;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace tinympc_amd

@@ -4,7 +4,8 @@ x0 / Xref, max_iter 500, u in [-0.5, 0.5].  Prints a markdown roofline table and
 
     python tools/sweep_bench.py --batch 131072 --out profiles/r01_sweep.json
 
-Which kernel serves a cell is reported ("regs" = register-resident DPP kernel, "cover" = coverage kernel).
+Which kernel serves a cell is reported: "regs" = one-row register-resident kernel (admm_kernel.hip.h), "tile" =
+W x R-row tile kernel (tile_kernel.hip.h), "cover" = coverage kernel (general_kernel.hip.h).
 """
 import argparse
 import json
@@ -33,13 +34,14 @@ def run_cell(nx, nu, N, B, reps):
         s.solve_async()
         ms = float(s.timing_ms()[0])
         best = ms if best is None else min(best, ms)
+    path = s.kernel_path()
     st = s.reduce_stats()
     iters, solved = st[0], st[1]
     alg = s.algorithmic_bytes()
     s.close()
     fl = tm.flops_per_iter(nx, nu, N)
     t = best * 1e-3
-    return dict(nx=nx, nu=nu, N=N, batch=B, kernel="regs" if (nx, nu, N) in tm.supported_dims() else "cover",
+    return dict(nx=nx, nu=nu, N=N, batch=B, kernel=path,
                 ms=best, solves_per_s=B / t, iters_per_s=iters / t, iters_per_solve=iters / B, solved_fraction=solved / B,
                 fp64_tflops=iters * fl / t / 1e12, fp64_frac=iters * fl / t / 78.6e12,
                 hbm_gbs=alg * B / t / 1e9, hbm_frac=alg * B / t / 8e12, bytes_per_solve=alg, flops_per_iter=fl)
@@ -58,10 +60,7 @@ def main():
     print("| nx | nu | N | kernel | ms | solves/s | ADMM it/s | it/solve | solved | FP64 frac | HBM frac |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     for nx, nu, N in cells:
-        B = args.batch
-        if (nx, nu, N) not in tm.supported_dims():
-            B = min(B, 16384)          # the coverage kernel is ~30x slower: keep the sweep short
-        r = run_cell(nx, nu, N, B, args.reps)
+        r = run_cell(nx, nu, N, args.batch, args.reps)
         rows.append(r)
         print(f"| {nx} | {nu} | {N} | {r['kernel']} | {r['ms']:.3f} | {r['solves_per_s']:.3e} | {r['iters_per_s']:.3e} | "
               f"{r['iters_per_solve']:.1f} | {r['solved_fraction']:.3f} | {r['fp64_frac']:.3f} | {r['hbm_frac']:.4f} |", flush=True)
