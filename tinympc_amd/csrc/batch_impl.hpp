@@ -61,6 +61,7 @@ struct TinyBatch {
     size_t stage_doubles = 0;
     std::vector<double> h_tab;
     bool tab_dirty = true;
+    int last_path = -1;
     // options
     bool advance_x0 = false, debug = false;
     int grid_waves_per_cu = 0, dpp_mode = 2, steps_per_launch = 1;
