@@ -53,7 +53,7 @@ def run_cases_hip(suite, replicate=1, debug=False, options=None):
     ret = s.solve()
     soc = cfg["en_state_soc"] or cfg["en_input_soc"]
     out = {f: s.get(f) for f in OUT_FIELDS + (SOC_OUT if soc else ()) + (LIN_OUT if lin else ()) + (TV_OUT if tvl else ())}
-    general = lin or tvl or (options or {}).get("force_general")
+    general = s.kernel_path() == "cover"          # the coverage kernel always leaves q|r and p|d behind
     if debug or general:
         for f in ("q", "r", "p", "d"):
             out[f] = s.get(f)

@@ -153,3 +153,20 @@ def test_dropin_example_setup_output_matches_reference(ex):
     assert marker in p.stdout and marker in gold
     assert p.stdout.split(marker)[0] == gold.split(marker)[0]
     assert "no CPU path" in p.stderr or "has no CPU" in p.stderr       # the solves refuse to run without a GPU
+
+
+def test_headline_kernel_register_budget():
+    """The quadrotor instantiation of the one-row kernel must stay at two waves per SIMD without scratch (a feature
+    added to the shared template once pushed it to 256 VGPRs + 236 B of scratch unnoticed)."""
+    src = os.path.join(ROOT, "tinympc_amd", "csrc", "_gen", "k_12_4_10.hip")
+    if not os.path.exists(src):
+        pytest.skip("library not built through the Makefile")
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
+                        p.stderr, re.S)
+    head = [b for b in blocks if "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0E" in b[0]]
+    assert len(head) == 1, [b[0] for b in blocks][:4]
+    _, vgpr, agpr, scratch, occ = head[0]
+    assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, head[0]

@@ -125,6 +125,24 @@ def test_tile_kernel_matches_oracle(dims, B, max_iter):
     assert_match(run_cases_hip(warm), sc.run_cases(OracleSolver, warm), RTOL, f"tile warm {dims}")
 
 
+def test_linear_constraints_register_resident_vs_coverage():
+    """The LIN variants of the one-row kernel (half-space projections as DPP broadcast-FMA row sums) and the coverage
+    kernel must agree with the oracle AND the fast path must really be the one that ran."""
+    suite = sc.random_linear_suite("quadrotor_20hz", B=13, seed=77)
+    ref = sc.run_cases(OracleSolver, suite)
+    probe = make_batch(suite)
+    assert probe.kernel_path() == "regs"
+    probe.set_option("force_general", 1)
+    assert probe.kernel_path() == "cover"
+    probe.close()
+    assert_match(run_cases_hip(suite), ref, RTOL, "LIN regs")
+    assert_match(run_cases_hip(suite, options={"force_general": 1}), ref, RTOL, "LIN cover")
+    for tv in (False, True):                                  # the reference's own linear-constraint examples
+        cfg = sc.linear_example_cfg(suite["problem"], tv, 3)
+        ex = dict(problem=suite["problem"], config=cfg, cases=suite["cases"])
+        assert_match(run_cases_hip(ex), sc.run_cases(OracleSolver, ex), RTOL, f"example tv={tv}")
+
+
 def test_persistent_grid_and_replication():
     """Same cases tiled 64x (4 instances per wave, many waves, persistent grid-stride tiles) must give
     bit-identical results to the single copy: no cross-instance interference."""
@@ -382,7 +400,7 @@ def test_api_misuse_is_reported_not_ignored():
     with pytest.raises(tm.TinyMPCError):
         s.get("q")                                            # q/r/p/d need the debug option
     s.set_option("steps_per_launch", 5)
-    s.update_settings(en_state_linear=1)                      # linear constraints run on the coverage kernel ...
+    s.set_option("force_general", 1)                          # the coverage kernel ...
     with pytest.raises(tm.TinyMPCError, match="steps_per_launch"):
-        s.solve()                                             # ... which has no fused stepping
+        s.solve()                                             # ... has no fused stepping
     s.close()

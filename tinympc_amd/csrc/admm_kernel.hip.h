@@ -56,9 +56,18 @@ enum : int {
     VEC_SOCFLAG = 5,     // 1.0 when this lane's cone slack is enabled (admm.cpp:102-109)
     VEC_CONE_BASE = 6,   // first lane of the cone this lane belongs to, or -1
     VEC_CONE_MU = 7,     // cone coefficient (double; truncated to float as admm.cpp:39 does)
+    VEC_LINFLAG = 9,     // 1.0 when this lane has a static linear-constraint slack (admm.cpp:138-145); 8 = VEC_RHO
+    VEC_TLINFLAG = 10,   // same for the time-varying family (admm.cpp:176-183)
     VEC_COUNT = 16,
 };
-static inline int tab_doubles(int N) { return TAB_BOUNDS + 2 * N * 16; }
+// Half-space tables of the register-resident linear-constraint variant, appended after the bounds.  Each entry is
+// [constraint k < LIN_KMAX][16 lanes]: the coefficient of this lane's row (state lanes: Alin_x[k][j], input lanes:
+// Alin_u[k][j-nx]), the offset b_k and ||a_k||^2 of this lane's family (b = +inf where there is no constraint k).
+// The time-varying tables carry one such block per slot (input lanes shifted by one knot, like the bounds).
+enum : int { LIN_KMAX = 4 };
+static inline int tab_lin_offset(int N) { return TAB_BOUNDS + 2 * N * 16; }
+static inline int tab_tlin_offset(int N) { return tab_lin_offset(N) + 3 * LIN_KMAX * 16; }
+static inline int tab_doubles(int N) { return tab_tlin_offset(N) + 3 * N * LIN_KMAX * 16; }
 
 struct SolveArgs {
     const double* tab;        // tab_doubles(N) doubles
@@ -91,6 +100,10 @@ struct SolveArgs {
     // Heterogeneous problem families (riccati_kernel.hip.h): per-instance matrix/vector tables
     // ([batch][TAB_BOUNDS] doubles, same layout as `tab`); bounds, cones and masks stay shared.
     const double* het_tabs;
+    // register-resident linear constraints (LIN variants): KPI records of vlnew|zlnew, gl|yl, vlnew_tv|zlnew_tv,
+    // gl_tv|yl_tv and the number of half-spaces applied per knot (max over the state / input families)
+    double *lslack, *ldual, *tlslack, *tldual;
+    int n_lin, n_tlin;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -281,10 +294,13 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
     return (n <= 10 || 2 * ((soc ? 8 : 6) * n + 2 * nz + 8) + 40 <= 256) ? 2 : 1;
 }
 
-template <int NX, int NU, int N, bool SOC, bool DBG, int MODE>
+// LIN: bit 0 = static half-spaces (admm.cpp:137-173), bit 1 = time-varying ones (:176-211); 0 = neither
+// HET: per-instance problem data (riccati_kernel.hip.h): the matrix rows are re-loaded for every instance
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(solve_kernel_waves_per_simd(NX + NU, N, SOC), solve_kernel_waves_per_simd(NX + NU, N, SOC))))
+__attribute__((amdgpu_waves_per_eu(LIN ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC), LIN ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC))))
 void admm_solve_kernel(const SolveArgs P) {
+    constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
     const int lane = threadIdx.x & 63;
@@ -297,6 +313,10 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sPt[NX * 16];
     __shared__ double sLo[N * 16];
     __shared__ double sHi[N * 16];
+    __shared__ double sLin[LS ? 3 * LIN_KMAX * 16 : 1];
+    __shared__ double sTLin[LT ? 3 * N * LIN_KMAX * 16 : 1];
+    if constexpr (LS) for (int e = lane; e < 3 * LIN_KMAX * 16; e += 64) sLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + e];
+    if constexpr (LT) for (int e = lane; e < 3 * N * LIN_KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * LIN_KMAX * 16 + e];
     for (int e = lane; e < NX * 16; e += 64) sPt[e] = P.tab[TAB_PT + e];
     for (int e = lane; e < N * 16; e += 64) {
         sLo[e] = P.tab[TAB_BOUNDS + e];
@@ -324,6 +344,12 @@ void admm_solve_kernel(const SolveArgs P) {
         cone_mu = P.tab[TAB_VEC + VEC_CONE_MU * 16 + j];
         cone_c = (cone_base >= 0) ? (j - cone_base) : 0;
     }
+    bool lin_lane = false, tlin_lane = false;
+    if constexpr (LS) lin_lane = P.tab[TAB_VEC + VEC_LINFLAG * 16 + j] != 0.0;
+    if constexpr (LT) tlin_lane = P.tab[TAB_VEC + VEC_TLINFLAG * 16 + j] != 0.0;
+    double ones[LIN ? 16 : 1];
+#pragma unroll
+    for (int k = 0; k < (LIN ? 16 : 1); ++k) ones[k] = 1.0;
     double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
@@ -332,8 +358,9 @@ void admm_solve_kernel(const SolveArgs P) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile * 4 + grp;
         if (b < P.batch) {
-            const double* het = P.het_tabs ? P.het_tabs + (size_t)b * TAB_BOUNDS : nullptr;
-            if (het) {                                         // this instance's own cache (A, B, Q, R, rho differ per instance)
+            const double* het = nullptr;
+            if constexpr (HET) {                               // this instance's own cache (A, B, Q, R, rho differ per instance)
+                het = P.het_tabs + (size_t)b * TAB_BOUNDS;
 #pragma unroll
                 for (int k = 0; k < NZ; ++k) mb[k] = het[TAB_MB + k * 16 + j];
 #pragma unroll
@@ -349,6 +376,7 @@ void admm_solve_kernel(const SolveArgs P) {
             const size_t lbase = (size_t)b * (N * NZ) + j - (is_input ? NZ : 0);
             double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
             double VC[SOC ? N : 1], GC[SOC ? N : 1];
+            double VL[LS ? N : 1], GL[LS ? N : 1], VT[LT ? N : 1], GT[LT ? N : 1];
             double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
             double ref_last = 0.0, qx_last_plain = 0.0;
             // ---- load the instance record (coalesced: contiguous NZ*8-byte knot segments)
@@ -367,13 +395,21 @@ void admm_solve_kernel(const SolveArgs P) {
                     VC[s] = (valid && soc_lane) ? P.prim[off] : 0.0;        // admm.cpp:352-357
                     GC[s] = (valid && soc_lane) ? P.cdual[off] : 0.0;
                 }
+                if constexpr (LS) {
+                    VL[s] = (valid && lin_lane) ? P.prim[off] : 0.0;        // admm.cpp:361-365
+                    GL[s] = (valid && lin_lane) ? P.ldual[off] : 0.0;
+                }
+                if constexpr (LT) {
+                    VT[s] = (valid && tlin_lane) ? P.prim[off] : 0.0;       // admm.cpp:370-374
+                    GT[s] = (valid && tlin_lane) ? P.tldual[off] : 0.0;
+                }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
             double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;           // tiny_set_x0
             auto terminal_term = [&]() {   // -(Xref[:,N-1]^T Pinf) (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
-                for (int k = 0; k < NX; ++k) pt[k] = het ? het[TAB_PT + k * 16 + j] : sPt[k * 16 + j];
+                for (int k = 0; k < NX; ++k) pt[k] = HET ? het[TAB_PT + k * 16 + j] : sPt[k * 16 + j];
                 const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
                 QX[N - 1] = is_state ? -xp : QX[N - 1];
@@ -412,6 +448,18 @@ void admm_solve_kernel(const SolveArgs P) {
                         VC[0] = x0v;
                     }
                 }
+                if constexpr (LS) {                            // vlnew = x, zlnew = u (admm.cpp:361-365)
+                    if (step > 0) {
+#pragma unroll
+                        for (int s = 0; s < N; ++s) VL[s] = lin_lane ? X[s] : 0.0;
+                    } else if (is_state && lin_lane) VL[0] = x0v;
+                }
+                if constexpr (LT) {                            // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
+                    if (step > 0) {
+#pragma unroll
+                        for (int s = 0; s < N; ++s) VT[s] = tlin_lane ? X[s] : 0.0;
+                    } else if (is_state && tlin_lane) VT[0] = x0v;
+                }
                 iter = 0; solved = 0;
                 int countdown = P.check_termination;
                 for (int it = 0; it < P.max_iter; ++it) {
@@ -421,6 +469,8 @@ void admm_solve_kernel(const SolveArgs P) {
                     {
                         double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293 | :280
                         if constexpr (SOC) t = fma(-rho, VC[N - 1] - GC[N - 1], t); // :295 | :282
+                        if constexpr (LS) t = fma(-rho, VL[N - 1] - GL[N - 1], t);  // :298 | :285
+                        if constexpr (LT) t = fma(-rho, VT[N - 1] - GT[N - 1], t);  // :301 | :288
                         qhi = t;
                         if constexpr (DBG) {
                             double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
@@ -435,6 +485,8 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int i = N - 2; i >= 0; --i) {
                         double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
                         if constexpr (SOC) qlo = fma(-rho, VC[i] - GC[i], qlo);     // :269 | :282
+                        if constexpr (LS) qlo = fma(-rho, VL[i] - GL[i], qlo);      // :272 | :285
+                        if constexpr (LT) qlo = fma(-rho, VT[i] - GT[i], qlo);      // :275 | :288
                         // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
                         const double res = ring_sum2<MODE, NX, NU>(fma(qlo, smask, cb), pcur, mb, qhi, mb + NX);
                         pcur = res;                                                 // p_i | d_i
@@ -465,6 +517,37 @@ void admm_solve_kernel(const SolveArgs P) {
                             if (cone_base >= 0 && soc_lane && knot_ok) vc = soc_component(s0, s1, s2, cone_c, cone_mu);
                             GC[s] = soc_lane ? ((GC[s] + xi) - vc) : 0.0;           // :229 / :234
                             VC[s] = vc;
+                        }
+                        // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over
+                        // the row with the broadcast-FMA chain (against a vector of ones), separately for the state
+                        // and the input rows; constraints are applied sequentially, only when violated (:154).
+                        auto halfspaces = [&](double z, const double* tabk, const int nk) {
+                            for (int k = 0; k < nk; ++k) {
+                                const double a = tabk[k * 16 + j];
+                                const double bk = tabk[LIN_KMAX * 16 + k * 16 + j];
+                                const double nn = tabk[2 * LIN_KMAX * 16 + k * 16 + j];
+                                const double prod = a * z;
+                                double cs = 0.0, ci = 0.0;
+                                ring1<0, NX>(cs, prod, ones);
+                                ring1<NX, NU>(ci, prod, ones);
+                                const double cv = is_state ? cs : ci;
+                                if (cv > bk) z = z - ((cv - bk) / nn) * a;
+                            }
+                            return z;
+                        };
+                        if constexpr (LS) {
+                            const bool on = lin_lane && (is_state || s >= 1);
+                            double vl = on ? (xi + GL[s]) : 0.0;                    // :139 / :144
+                            vl = halfspaces(vl, sLin, P.n_lin);
+                            GL[s] = on ? ((GL[s] + xi) - vl) : 0.0;                 // :239 / :244
+                            VL[s] = on ? vl : 0.0;
+                        }
+                        if constexpr (LT) {
+                            const bool on = tlin_lane && (is_state || s >= 1);
+                            double vt = on ? (xi + GT[s]) : 0.0;                    // :177 / :182
+                            vt = halfspaces(vt, sTLin + s * 3 * LIN_KMAX * 16, P.n_tlin);
+                            GT[s] = on ? ((GT[s] + xi) - vt) : 0.0;                 // :249 / :254
+                            VT[s] = on ? vt : 0.0;
                         }
                     };
                     // Software pipeline: the box bounds of slot i+1 are read from LDS one whole step before
@@ -520,6 +603,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         P.cslack[off] = VC[s];
                         P.cdual[off] = GC[s];
                     }
+                    if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
+                    if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }
                     if constexpr (DBG) {
                         if (P.dbg_qr) {
                             P.dbg_qr[off] = Qd[s];                          // work->q | work->r

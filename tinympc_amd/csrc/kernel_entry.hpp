@@ -7,6 +7,8 @@ typedef void (*SolveKernel)(const SolveArgs);
 struct KernelEntry {
     int nx, nu, N;
     SolveKernel k[2][2][3];   // [soc][dbg][dpp_mode]
+    SolveKernel klin[2][4];   // [soc][LIN 1..3]: register-resident linear constraints (dpp_mode 2, no debug outputs)
+    SolveKernel khet[2];      // [soc]: per-instance problem data (dpp_mode 2, no debug outputs)
 };
 struct TileEntry {
     int nx, nu, N, W, R;
@@ -17,6 +19,12 @@ struct TileEntry {
 #define KERNELS_MODES(NX, NU, NN, S, D)                                                          \
     { tinympc_amd::admm_solve_kernel<NX, NU, NN, S, D, 0>, tinympc_amd::admm_solve_kernel<NX, NU, NN, S, D, 1>, \
       tinympc_amd::admm_solve_kernel<NX, NU, NN, S, D, 2> }
+#define KERNELS_LIN(NX, NU, NN, S)                                                                \
+    { nullptr, tinympc_amd::admm_solve_kernel<NX, NU, NN, S, false, 2, 1>,                         \
+      tinympc_amd::admm_solve_kernel<NX, NU, NN, S, false, 2, 2>, tinympc_amd::admm_solve_kernel<NX, NU, NN, S, false, 2, 3> }
 #define KERNELS_FOR(NX, NU, NN)                                                                   \
     { NX, NU, NN, { { KERNELS_MODES(NX, NU, NN, false, false), KERNELS_MODES(NX, NU, NN, false, true) },   \
-                    { KERNELS_MODES(NX, NU, NN, true, false), KERNELS_MODES(NX, NU, NN, true, true) } } }
+                    { KERNELS_MODES(NX, NU, NN, true, false), KERNELS_MODES(NX, NU, NN, true, true) } },    \
+      { KERNELS_LIN(NX, NU, NN, false), KERNELS_LIN(NX, NU, NN, true) },                                    \
+      { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, true>,                               \
+        tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, true> } }
