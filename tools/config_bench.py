@@ -88,8 +88,41 @@ def config4(B=65536):
     return dict(config="rocket_landing x65536, input SOC on, 90-step closed loop (wall clock incl. launches)", batch=B, **out)
 
 
+def linear_example(B=65536, tv=False):
+    """examples/quadrotor_(tv_)linear_constraints.cpp: altitude ceiling + total-thrust half-spaces, boxes off; one
+    cold solve of B perturbed instances on the register-resident LIN kernel and on the coverage kernel."""
+    prob, _ = tm.load_problem("quadrotor_20hz")
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(1)
+    x0 = np.array([-2.0, -2.0, 1.0] + [0.0] * 9) + rng.normal(0, 0.05, (B, nx))
+    xg = np.array([2.0, 2.0, 4.0] + [0.0] * 9)
+    Xref = np.stack([(1 - i / 49.0) * x0 + (i / 49.0) * xg for i in range(N)], axis=2)
+    ax = np.zeros((1, nx)); ax[0, 2] = 1.0
+    out = {}
+    for name, force in (("regs", 0), ("cover", 1)):
+        Bk = B if not force else B // 8
+        s = tm.TinyBatchSolver.from_problem(prob, Bk)
+        if tv:
+            s.set_tv_linear_constraints(np.tile(ax, (N, 1)), np.linspace(1.1, 3.0, N).reshape(1, N), np.ones((N - 1, nu)), np.full((1, N - 1), 6.0))
+            s.update_settings(max_iter=100, en_state_bound=0, en_input_bound=0, en_tv_state_linear=1, en_tv_input_linear=1)
+        else:
+            s.set_linear_constraints(ax, [3.0], np.ones((1, nu)), [6.0])
+            s.update_settings(max_iter=100, en_state_bound=0, en_input_bound=0, en_state_linear=1, en_input_linear=1)
+        s.set_option("force_general", force)
+        s.set_x_ref(Xref[:Bk])
+        s.set_x0(x0[:Bk])
+        s.set_option("timing", 1)
+        s.solve_async()
+        ms = float(s.timing_ms()[0])
+        st = s.reduce_stats()
+        out[name] = dict(kernel=s.kernel_path(), batch=Bk, kernel_ms=ms, solves_per_s=Bk / (ms * 1e-3),
+                         admm_iters_per_s=st[0] / (ms * 1e-3), iters_per_solve=st[0] / Bk)
+        s.close()
+    return dict(config=f"quadrotor {'time-varying ' if tv else ''}linear constraints example, one cold solve", **out)
+
+
 if __name__ == "__main__":
-    res = {"config3": config3(), "config4": config4()}
+    res = {"config3": config3(), "config4": config4(), "linear_static": linear_example(tv=False), "linear_tv": linear_example(tv=True)}
     print(json.dumps(res, indent=1))
     if len(sys.argv) > 1:
         json.dump(res, open(sys.argv[1], "w"), indent=1)
