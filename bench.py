@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("TINYMPC_STEPS_PER_LAUNCH", "0")),
                     help="closed-loop MPC steps fused into one kernel launch (ADMM state stays in registers); "
                          "0 = auto: the largest divisor of --steps and --warmup that is <= 100; 1 = one launch per step")
+    ap.add_argument("--opt", action="append", default=[], help="solver option name=value (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -88,6 +89,9 @@ def main():
     s.set_option("advance_x0", 1)
     s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
     s.set_option("dpp_mode", args.dpp_mode)
+    for kv in args.opt:                              # experiments: --opt dynamic_rows=1
+        k, v = kv.split("=")
+        s.set_option(k, int(v))
     T = args.steps_per_launch
     if T <= 0:
         import math

@@ -1,4 +1,6 @@
 """Run a parity suite (oracle/scenarios.py) through the product: libtinympc_amd.so via the C ABI."""
+import os
+
 import numpy as np
 
 import tinympc_amd as tm
@@ -31,6 +33,9 @@ def make_batch(suite, batch=None, replicate=1):
                       cfg["en_state_bound"], cfg["en_input_bound"], cfg["en_state_soc"], cfg["en_input_soc"],
                       cfg.get("en_state_linear", 0), cfg.get("en_input_linear", 0), cfg.get("en_tv_state_linear", 0),
                       cfg.get("en_tv_input_linear", 0))
+    for kv in filter(None, os.environ.get("TINYMPC_TEST_OPTS", "").split(",")):     # rerun the suite under any option set
+        k, v = kv.split("=")
+        s.set_option(k, int(v))
     return s
 
 

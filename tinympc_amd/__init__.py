@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinympc_amd.so")
+LIB_PATH = os.environ.get("TINYMPC_AMD_LIB") or os.path.join(_HERE, "libtinympc_amd.so")   # override: A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 _dp = C.POINTER(C.c_double)

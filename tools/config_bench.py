@@ -18,6 +18,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_amd as tm  # noqa: E402
 
 
+def apply_opts(s):
+    """TINYMPC_OPTS="dynamic_rows=1,grid_waves_per_cu=8": solver options for an experiment, applied to every solver here."""
+    for kv in filter(None, os.environ.get("TINYMPC_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        s.set_option(k, int(v))
+
+
 def config3(B=262144, reps=3):
     prob, extra = tm.load_problem("quadrotor_20hz")
     nx, nu, N = prob["nx"], prob["nu"], prob["N"]
@@ -29,6 +36,7 @@ def config3(B=262144, reps=3):
     x0 = Xref[:, :, 0].copy()
     x0[:, :3] += rng.normal(0, 0.1, (B, 3))
     s = tm.TinyBatchSolver.from_problem(prob, B)
+    apply_opts(s)
     s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
     s.update_settings(max_iter=100)
     s.set_x_ref(Xref)
@@ -61,6 +69,7 @@ def config4(B=65536):
     xinit, xg = np.array(m["xinit"], dtype=float), np.array(m["xg"], dtype=float)
     traj = np.stack([xinit + (xg - xinit) * float(i) / (m["NTOTAL"] - 1) for i in range(m["NTOTAL"])])   # Xref window source
     s = tm.TinyBatchSolver.from_problem(prob, B)
+    apply_opts(s)
     s.set_bound_constraints(np.array(m["x_min"]), np.array(m["x_max"]), np.full((nu, 1), m["u_min"]), np.full((nu, 1), m["u_max"]))
     s.set_cone_constraints(m["state_cone"]["A"], m["state_cone"]["q"], m["state_cone"]["c"],
                            m["input_cone"]["A"], m["input_cone"]["q"], m["input_cone"]["c"])
@@ -122,7 +131,10 @@ def linear_example(B=65536, tv=False):
 
 
 if __name__ == "__main__":
-    res = {"config3": config3(), "config4": config4(), "linear_static": linear_example(tv=False), "linear_tv": linear_example(tv=True)}
+    runs = {"config3": config3, "config4": config4, "linear_static": lambda: linear_example(tv=False),
+            "linear_tv": lambda: linear_example(tv=True)}
+    pick = sys.argv[2].split(",") if len(sys.argv) > 2 else list(runs)
+    res = {k: runs[k]() for k in pick}
     print(json.dumps(res, indent=1))
     if len(sys.argv) > 1:
         json.dump(res, open(sys.argv[1], "w"), indent=1)
