@@ -24,6 +24,7 @@
 #define TINYMPC_AMD_H
 
 #include <stdint.h>
+#include <stdbool.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -64,9 +65,9 @@ typedef enum {
     TINY_F_ZCNEW,
     TINY_F_GC,
     TINY_F_YC,
-    TINY_F_Q,           /* work->q / r / p / d of the last iteration: only     */
-    TINY_F_R,           /* available after tiny_batch_set_option("debug", 1)   */
-    TINY_F_P,
+    TINY_F_Q,           /* work->q / r / p / d of the last iteration: kept by  */
+    TINY_F_R,           /* a solve after tiny_batch_set_option("debug", 1);    */
+    TINY_F_P,           /* settable as inputs of tiny_batch_phase              */
     TINY_F_D,
     TINY_F_VLNEW,       /* work->vlnew / zlnew / gl / yl: static linear-constraint slack + dual   */
     TINY_F_ZLNEW,
@@ -149,6 +150,19 @@ int tiny_batch_solve(TinyBatch* b);
 /* Same launch, asynchronous on the batch's stream; returns TINY_OK after enqueueing. */
 int tiny_batch_solve_async(TinyBatch* b);
 int tiny_batch_synchronize(TinyBatch* b);
+/* ONE phase of the ADMM iteration over the whole batch, on the device records as they are (asynchronous): the
+ * batched form of the phase functions the reference exports (src/tinympc/admm.hpp:12-17).  Reads / writes exactly
+ * the workspace fields the reference function does (x|u, q|r, p|d, the slack and dual families). */
+enum {
+    TINY_PHASE_LINEAR_COST = 1,   /* update_linear_cost     admm.cpp:262-304 */
+    TINY_PHASE_BACKWARD = 2,      /* backward_pass_grad     admm.cpp:13-20   */
+    TINY_PHASE_FORWARD = 3,       /* forward_pass           admm.cpp:25-32   */
+    TINY_PHASE_SLACK = 4,         /* update_slack           admm.cpp:81-211  */
+    TINY_PHASE_DUAL = 5,          /* update_dual            admm.cpp:219-256 */
+    TINY_PHASE_TERMINATION = 6    /* termination_condition  admm.cpp:310-328: the four residuals (always evaluated);
+                                     tiny_batch_get_status' `solved` array then holds the returned bool */
+};
+int tiny_batch_phase(TinyBatch* b, int phase);
 /* solution->iter, solution->solved, work->status, and the four residuals
  * {primal_state, primal_input, dual_state, dual_input} ([batch][4]); any pointer may be NULL. */
 int tiny_batch_get_status(TinyBatch* b, int* iter, int* solved, int* status, double* residuals);
@@ -307,6 +321,21 @@ int tiny_set_default_settings(TinySettings* settings);
 int tiny_set_x0(TinySolver* solver, const TinyVectorPOD* x0);
 int tiny_set_x_ref(TinySolver* solver, const TinyMatrixPOD* x_ref);
 int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref);
+/* admm.hpp:12-17: the individual phases of one ADMM iteration on a solver's workspace.  Each uploads the workspace,
+ * runs the phase on the GPU (tiny_batch_phase with a batch of one) and writes the fields the reference function
+ * writes back into the workspace. */
+void update_linear_cost(TinySolver* solver);
+void backward_pass_grad(TinySolver* solver);
+void forward_pass(TinySolver* solver);
+void update_slack(TinySolver* solver);
+void update_dual(TinySolver* solver);
+bool termination_condition(TinySolver* solver);
+/* admm.hpp:25, :34 -- `tinyVector project_soc(tinyVector s, float mu)` and
+ * `tinyVector project_hyperplane(const tinyVector& z, const tinyVector& a, tinytype b)`: under the Itanium ABI the
+ * Eigen return value is constructed by the callee in caller-provided storage (hidden first argument, returned in
+ * rax) and the by-value Eigen argument arrives as a pointer; the result buffer is malloc'd (Eigen frees it). */
+TinyVectorPOD* project_soc(TinyVectorPOD* result, const TinyVectorPOD* s, float mu);
+TinyVectorPOD* project_hyperplane(TinyVectorPOD* result, const TinyVectorPOD* z, const TinyVectorPOD* a, double b);
 /* NEW: n solvers that share one cache / settings / bounds, solved in ONE launch (gather from and
  * scatter to ordinary TinySolver workspaces).  Returns 0 when all converged, else 1. */
 int tiny_solve_batch(TinySolver** solvers, int n);

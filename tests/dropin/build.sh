@@ -19,8 +19,14 @@ for ex in $EXAMPLES; do
   g++ $CXXFLAGS $INC -o "$OUT/$ex" "$REF/examples/$ex.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
       -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
 done
+# our own caller of the exported phase functions (admm.hpp:12-34), real Eigen types across the boundary
+g++ $CXXFLAGS $INC -o "$OUT/phase_driver" "$HERE/phase_driver.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
+    -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
 wait
 if [ "$1" = "--golden" ]; then
+  g++ $CXXFLAGS $INC -o "$OUT/ref_phase_driver" "$HERE/phase_driver.cpp" "$REF/src/tinympc/admm.cpp" \
+      "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp"
+  (cd "$OUT" && ./ref_phase_driver > "$ROOT/tests/golden/stdout_phase_driver.txt"); rm -f "$OUT/ref_phase_driver"
   for ex in $EXAMPLES; do
     g++ $CXXFLAGS $INC -o "$OUT/ref_$ex" "$REF/examples/$ex.cpp" "$REF/src/tinympc/admm.cpp" \
         "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp" &

@@ -26,3 +26,31 @@ def test_reference_example_stdout_identical(ex):
         gl, ol = gold.splitlines(), got.splitlines()
         diff = [(i, a, b) for i, (a, b) in enumerate(zip(gl, ol)) if a != b][:5]
         pytest.fail(f"{ex}: stdout differs from the reference's ({len(gl)} vs {len(ol)} lines); first diffs: {diff}")
+
+
+def test_phase_functions_called_with_real_eigen_types():
+    """tests/dropin/phase_driver.cpp (our caller, the reference's headers): update_linear_cost ... termination_condition,
+    project_soc and project_hyperplane cross the library boundary with real Eigen objects by value / by reference and an
+    Eigen return value.  Every printed number must equal what the same program prints when linked against the reference
+    (1e-9 of the line's largest magnitude: FMA contraction differs, nothing else may)."""
+    exe = os.path.join(BUILD, "phase_driver")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    gold = open(os.path.join(ROOT, "tests", "golden", "stdout_phase_driver.txt")).read().splitlines()
+    got = p.stdout.splitlines()
+    assert len(got) == len(gold) == 78
+
+    def split(line):
+        words = line.replace("(input kept:", "").replace(")", "").split()
+        nums = [i for i, w in enumerate(words) if w[0] in "-0123456789" and any(c.isdigit() for c in w) and i >= 1]
+        return [w for i, w in enumerate(words) if i not in nums], [float(words[i]) for i in nums]
+
+    for a, b in zip(got, gold):
+        (ta, na), (tb, nb) = split(a), split(b)
+        assert ta == tb and len(na) == len(nb), (a[:80], b[:80])
+        if tb[0] == "project_hyperplane":
+            na, nb = na[:-1], nb[:-1]                     # the trailing residual is rounding noise in both
+        scale = max([abs(v) for v in nb] + [1e-300])
+        assert max([abs(x - y) for x, y in zip(na, nb)] + [0.0]) <= 1e-9 * scale, (a[:100], b[:100])

@@ -1,0 +1,188 @@
+"""The reference also exports the individual phases of one ADMM iteration (src/tinympc/admm.hpp:12-34).  This library
+runs each of them on the GPU: batched (tiny_batch_phase) and through the reference's own symbols on a TinySolver.
+Pinned against the real reference's per-phase known answers (tests/golden/phase_kat.npz, project_soc_kat.npz) and,
+for the linear-constraint families the golden file does not cover, against the oracle's phases."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+sys.path.insert(0, HERE)
+
+import scenarios as sc  # noqa: E402
+from cpu_solvers import OracleSolver, build_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(HERE, "golden")
+RTOL = 1e-9
+PHASES = ("update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual")
+FIELDS = ("x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y", "vcnew", "zcnew", "gc", "yc")
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_batched_phases_match_reference_golden():
+    """tiny_batch_phase, 70 copies of the reference's random rocket workspace (both cones on): after every phase every
+    workspace field equals what the REAL reference left behind, in every copy."""
+    from hip_runner import make_batch
+    ph = np.load(os.path.join(GOLDEN, "phase_kat.npz"))
+    suite = sc.random_state_suite("rocket_landing_20hz", B=1, seed=3, soc=True)
+    B = 70
+    s = make_batch(suite, batch=B)
+    for k in FIELDS + ("Xref", "Uref"):
+        s.set(k, ph["in." + k], broadcast=True)
+    for name in PHASES:
+        s.phase(name)
+        for k in FIELDS:
+            got = s.get(k)
+            assert rel_err(got[0], ph[f"{name}.{k}"]) < RTOL, (name, k)
+            assert np.all(got == got[:1]), (name, k)
+    conv = s.phase("termination_condition")
+    st = s.status()
+    got = [float(conv[0])] + [st[k][0] for k in ("primal_residual_state", "dual_residual_state", "primal_residual_input", "dual_residual_input")]
+    np.testing.assert_allclose(got, ph["termination"], rtol=1e-12)
+    assert np.all(conv == conv[0])
+    s.close()
+
+
+def _pod_solver(L, pod, prob, cfg, keep):
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    L.tiny_setup.argtypes = [C.POINTER(C.POINTER(pod.TinySolver))] + [C.POINTER(pod.Mat)] * 5 + [C.c_double] + [C.c_int] * 4
+    L.tiny_set_bound_constraints.argtypes = [C.POINTER(pod.TinySolver)] + [C.POINTER(pod.Mat)] * 4
+    L.tiny_set_cone_constraints.argtypes = [C.POINTER(pod.TinySolver)] + [C.POINTER(pod.VecXi), C.POINTER(pod.VecXi), C.POINTER(pod.Vec)] * 2
+    ms = [pod.mat(prob["A"]), pod.mat(prob["B"]), pod.mat(prob["f"]), pod.mat(np.diag(prob["Q"])), pod.mat(np.diag(prob["R"]))]
+    keep.append(ms)
+    sp = C.POINTER(pod.TinySolver)()
+    assert L.tiny_setup(C.byref(sp), *[C.byref(m[0]) for m in ms], prob["rho"], nx, nu, N, 0) == 0
+    bs = [pod.mat(cfg[k]) for k in ("x_min", "x_max", "u_min", "u_max")]
+    keep.append(bs)
+    assert L.tiny_set_bound_constraints(sp, *[C.byref(m[0]) for m in bs]) == 0
+    if cfg.get("state_cone") is not None:
+        (ax, qx, cx), (au, qu, cu) = cfg["state_cone"], cfg["input_cone"]
+        cs = [pod.veci(ax), pod.veci(qx), pod.vec(cx), pod.veci(au), pod.veci(qu), pod.vec(cu)]
+        keep.append(cs)
+        assert L.tiny_set_cone_constraints(sp, *[C.byref(m[0]) for m in cs]) == 0    # state triple first (tiny_api.cpp:176)
+    st = sp.contents.settings.contents
+    for k in ("max_iter", "check_termination", "en_state_bound", "en_input_bound", "en_state_soc", "en_input_soc"):
+        setattr(st, k, int(cfg[k]))
+    st.abs_pri_tol, st.abs_dua_tol = cfg["abs_pri_tol"], cfg["abs_dua_tol"]
+    return sp
+
+
+def test_reference_phase_symbols_on_a_solver_struct():
+    """update_linear_cost(TinySolver*) ... termination_condition(TinySolver*) called exactly as a reference caller
+    would (plain-data mirror of the reference structs): fields after each call = the real reference's."""
+    import pod
+    import tinympc_amd as tm
+    L = tm.lib()
+    ph = np.load(os.path.join(GOLDEN, "phase_kat.npz"))
+    suite = sc.random_state_suite("rocket_landing_20hz", B=1, seed=3, soc=True)
+    keep = []
+    sp = _pod_solver(L, pod, suite["problem"], suite["config"], keep)
+    w = sp.contents.work.contents
+    for k in FIELDS + ("Xref", "Uref"):
+        pod.to_np(getattr(w, k))[...] = ph["in." + k]
+    for name in PHASES:
+        fn = getattr(L, name)
+        fn.argtypes, fn.restype = [C.POINTER(pod.TinySolver)], None
+        fn(sp)
+        for k in FIELDS:
+            assert rel_err(pod.to_np(getattr(w, k)), ph[f"{name}.{k}"]) < RTOL, (name, k)
+    L.termination_condition.argtypes, L.termination_condition.restype = [C.POINTER(pod.TinySolver)], C.c_bool
+    sp.contents.settings.contents.check_termination = 1
+    w.iter = 7
+    conv = L.termination_condition(sp)
+    got = [float(conv), w.primal_residual_state, w.dual_residual_state, w.primal_residual_input, w.dual_residual_input]
+    np.testing.assert_allclose(got, ph["termination"], rtol=1e-12)
+    sp.contents.settings.contents.check_termination = 3              # 7 % 3 != 0: no check, residuals untouched (admm.cpp:312)
+    w.primal_residual_state = -1.0
+    assert L.termination_condition(sp) is False and w.primal_residual_state == -1.0
+    L.tiny_destroy.argtypes = [C.POINTER(pod.TinySolver)]
+    L.tiny_destroy(sp)
+
+
+def test_projection_symbols():
+    """project_soc / project_hyperplane with the reference's C++ calling convention (result constructed by the callee
+    in caller storage, Eigen arguments as pointers): known answers of the real reference incl. all three branches."""
+    import pod
+    import tinympc_amd as tm
+    L = tm.lib()
+    kat = np.load(os.path.join(GOLDEN, "project_soc_kat.npz"))
+    L.project_soc.argtypes, L.project_soc.restype = [C.POINTER(pod.Vec), C.POINTER(pod.Vec), C.c_float], C.POINTER(pod.Vec)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for i in range(len(kat["s"])):
+        v, keep = pod.vec(kat["s"][i])
+        out = pod.Vec()
+        r = L.project_soc(C.byref(out), C.byref(v), float(kat["mu"][i]))
+        assert C.addressof(r.contents) == C.addressof(out) and out.rows == 3
+        np.testing.assert_allclose(pod.to_np(out), kat["out"][i], rtol=1e-12, atol=0)
+        libc.free(C.cast(out.data, C.c_void_p))                     # the caller (Eigen) owns and frees the result
+    L.project_hyperplane.argtypes = [C.POINTER(pod.Vec), C.POINTER(pod.Vec), C.POINTER(pod.Vec), C.c_double]
+    L.project_hyperplane.restype = C.POINTER(pod.Vec)
+    rng = np.random.default_rng(4)
+    for n in (1, 3, 12):
+        z, a, b = rng.normal(size=n), rng.normal(size=n), float(rng.normal())
+        vz, k1 = pod.vec(z)
+        va, k2 = pod.vec(a)
+        out = pod.Vec()
+        L.project_hyperplane(C.byref(out), C.byref(vz), C.byref(va), b)
+        want = z - ((a @ z - b) / (a @ a)) * a                      # admm.cpp:70-73
+        np.testing.assert_allclose(pod.to_np(out), want, rtol=1e-12, atol=1e-15)
+        assert abs(a @ pod.to_np(out) - b) < 1e-12
+        libc.free(C.cast(out.data, C.c_void_p))
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: sc.random_linear_suite("quadrotor_20hz", B=3, seed=31),
+    lambda: sc.random_linear_suite("rocket_landing_20hz", B=3, seed=32, soc=True),
+    lambda: sc.random_linear_suite("cartpole", B=3, seed=33, static=False, box=False),
+], ids=["quad_all", "rocket_soc_linear", "cartpole_tv_only"])
+def test_batched_phases_with_linear_constraints_match_oracle(maker):
+    """Static and time-varying half-space slacks in every phase (admm.cpp:137-211, 238-255, 271-302) vs the oracle,
+    per instance, starting from a fully random workspace."""
+    from hip_runner import make_batch
+    assert build_oracle()
+    suite = maker()
+    prob, cfg, cases = suite["problem"], suite["config"], suite["cases"]
+    B = cases["x0"].shape[0]
+    rng = np.random.default_rng(99)
+    fields = ["x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y"]
+    if cfg["en_state_soc"] or cfg["en_input_soc"]:
+        fields += ["vcnew", "zcnew", "gc", "yc"]
+    if cfg.get("en_state_linear") or cfg.get("en_input_linear"):
+        fields += ["vlnew", "zlnew", "gl", "yl"]
+    if cfg.get("en_tv_state_linear") or cfg.get("en_tv_input_linear"):
+        fields += ["vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv"]
+    s = make_batch(suite)
+    oracles = [sc.make_solver(OracleSolver, prob, cfg) for _ in range(B)]
+    init = {}
+    for k in fields + ["Xref", "Uref"]:
+        shape = oracles[0][k].shape
+        init[k] = rng.normal(0, 0.5, (B,) + shape)
+        s.set(k, init[k])
+        for b, o in enumerate(oracles):
+            o[k] = init[k][b]
+    for name in PHASES:
+        s.phase(name)
+        for o in oracles:
+            o.phase(name)
+        for k in fields:
+            got = s.get(k)
+            for b, o in enumerate(oracles):
+                assert rel_err(got[b], o[k]) < RTOL, (name, k, b)
+    conv = s.phase("termination_condition")
+    st = s.status()
+    for b, o in enumerate(oracles):
+        o.set("check_termination", 1)
+        assert bool(o.phase("termination_condition")) == bool(conv[b])
+        for k in ("primal_residual_state", "dual_residual_state", "primal_residual_input", "dual_residual_input"):
+            assert abs(st[k][b] - o.get(k)) <= 1e-12 * max(1.0, abs(o.get(k))), (k, b)
+        o.close()
+    s.close()

@@ -40,12 +40,17 @@ BATCH_SYMBOLS = (
     "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
-    "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path")
+    "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path")
 REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
     "tiny_solve", "solve", "tiny_update_settings", "tiny_set_default_settings", "tiny_set_x0", "tiny_set_x_ref",
-    "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy")
+    "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy",
+    # the phase functions of admm.hpp:12-34
+    "update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual", "termination_condition",
+    "project_soc", "project_hyperplane")
+PHASES = {"update_linear_cost": 1, "backward_pass_grad": 2, "forward_pass": 3, "update_slack": 4, "update_dual": 5,
+          "termination_condition": 6}
 
 
 class TinyMPCError(RuntimeError):
@@ -313,6 +318,13 @@ class TinyBatchSolver:
 
     def solve_async(self):
         self._check(lib().tiny_batch_solve_async(self._h), "solve_async")
+
+    def phase(self, name):
+        """ONE phase of the iteration over the batch (the reference's exported phase functions, admm.hpp:12-17), on
+        the device records as they are.  'termination_condition' returns the per-instance booleans."""
+        self._check(lib().tiny_batch_phase(self._h, PHASES[name]), name)
+        if name == "termination_condition":
+            return self.status()["solved"].astype(bool)
 
     def synchronize(self):
         self._check(lib().tiny_batch_synchronize(self._h), "synchronize")

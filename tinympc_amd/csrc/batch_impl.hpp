@@ -51,7 +51,7 @@ struct TinyBatch {
     int4* d_status = nullptr;
     uint2* d_accum = nullptr;
     double *d_lslack = nullptr, *d_ldual = nullptr, *d_tlslack = nullptr, *d_tldual = nullptr, *d_gtab = nullptr;
-    size_t gtab_doubles = 0, general_lds_limit = 0;
+    size_t gtab_doubles = 0, general_lds_limit = 0, phase_lds_limit = 0;
     std::vector<double> h_gtab;
     tinympc_amd::GeneralArgs gargs;      // table offsets filled by build_general_tables
     bool force_general = false;
@@ -85,4 +85,6 @@ struct TinyBatch {
 namespace tinympc_amd {
 int fail(TinyBatch* b, int code, const char* fmt, ...);
 int launch_solve(TinyBatch* b);
+// project_soc (which = 0) / project_hyperplane (1) of an n-vector in device memory, one GPU thread, synchronous
+int launch_projection(int which, double* v, const double* a, int n, float mu, double b);
 }  // namespace tinympc_amd

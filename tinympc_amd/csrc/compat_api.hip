@@ -188,11 +188,9 @@ bool is_state_field(TinyField f) {
            f == TINY_F_GL_TV;
 }
 
-int solve_group(TinySolver** solvers, int n) {
-    if (!solvers || n <= 0 || !solvers[0]) return TINY_ERR_NULL;
-    TinySolver* s0 = solvers[0];
+// the device context (a TinyBatch of n instances) that backs solver s0; g_mu must be held
+int device_context(TinySolver* s0, int n, TinyBatch** out) {
     const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
-    std::lock_guard<std::mutex> lk(g_mu);
     Ctx& ctx = g_ctx[s0];
     if (ctx.b && ctx.n != n) { tiny_batch_destroy(ctx.b); ctx.b = nullptr; }
     if (!ctx.b) {
@@ -206,7 +204,17 @@ int solve_group(TinySolver** solvers, int n) {
         ctx.n = n;
         tiny_batch_set_option(ctx.b, "debug", 1);
     }
-    TinyBatch* b = ctx.b;
+    *out = ctx.b;
+    return TINY_OK;
+}
+
+int solve_group(TinySolver** solvers, int n) {
+    if (!solvers || n <= 0 || !solvers[0]) return TINY_ERR_NULL;
+    TinySolver* s0 = solvers[0];
+    const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
+    std::lock_guard<std::mutex> lk(g_mu);
+    TinyBatch* b = nullptr;
+    if (int rc = device_context(s0, n, &b)) return rc;
     if (int rc = sync_family(b, s0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
     const size_t ns = (size_t)nx * N, ni = (size_t)nu * (N - 1);
     std::vector<double> buf((size_t)n * ns);
@@ -277,6 +285,75 @@ int solve_group(TinySolver** solvers, int n) {
         else all = 1;
     }
     return all;                                              // 0 converged / 1 max_iter (admm.cpp:441,454)
+}
+
+// One exported phase function of admm.hpp:12-17 on solver s: upload every workspace field the phases read, run the
+// phase on the GPU, write back the fields that phase writes.  Returns < 0 on error, else the phase's boolean.
+int phase_call(TinySolver* s, int phase) {
+    if (!s || !s->work || !s->cache || !s->settings) return -TINY_ERR_NULL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    TinyBatch* b = nullptr;
+    if (int rc = device_context(s, 1, &b)) return -rc;
+    if (int rc = sync_family(b, s)) { fprintf(stderr, "tinympc_amd phase: %s\n", b->err); return -rc; }
+    TinyWorkspace* w = s->work;
+    const TinySettings* st = s->settings;
+    const int nx = w->nx, nu = w->nu, N = w->N;
+    const size_t ns = (size_t)nx * N, ni = (size_t)nu * (N - 1);
+    const bool s_soc = st->en_state_soc && w->numStateCones > 0, i_soc = st->en_input_soc && w->numInputCones > 0;
+    struct Io { TinyField f; TinyMatrixPOD TinyWorkspace::*m; bool on; int writer; };   // writer: the phase that writes it
+    const Io io[] = {
+        {TINY_F_XREF, &TinyWorkspace::Xref, true, 0}, {TINY_F_UREF, &TinyWorkspace::Uref, true, 0},
+        {TINY_F_X, &TinyWorkspace::x, true, PHASE_FORWARD}, {TINY_F_U, &TinyWorkspace::u, true, PHASE_FORWARD},
+        {TINY_F_Q, &TinyWorkspace::q, true, PHASE_LINEAR_COST}, {TINY_F_R, &TinyWorkspace::r, true, PHASE_LINEAR_COST},
+        {TINY_F_P, &TinyWorkspace::p, true, -1}, {TINY_F_D, &TinyWorkspace::d, true, PHASE_BACKWARD},
+        {TINY_F_V, &TinyWorkspace::v, true, 0}, {TINY_F_Z, &TinyWorkspace::z, true, 0},
+        {TINY_F_VNEW, &TinyWorkspace::vnew, true, PHASE_SLACK}, {TINY_F_ZNEW, &TinyWorkspace::znew, true, PHASE_SLACK},
+        {TINY_F_G, &TinyWorkspace::g, true, PHASE_DUAL}, {TINY_F_Y, &TinyWorkspace::y, true, PHASE_DUAL},
+        {TINY_F_VCNEW, &TinyWorkspace::vcnew, s_soc, PHASE_SLACK}, {TINY_F_ZCNEW, &TinyWorkspace::zcnew, i_soc, PHASE_SLACK},
+        {TINY_F_GC, &TinyWorkspace::gc, s_soc, PHASE_DUAL}, {TINY_F_YC, &TinyWorkspace::yc, i_soc, PHASE_DUAL},
+        {TINY_F_VLNEW, &TinyWorkspace::vlnew, st->en_state_linear != 0, PHASE_SLACK}, {TINY_F_ZLNEW, &TinyWorkspace::zlnew, st->en_input_linear != 0, PHASE_SLACK},
+        {TINY_F_GL, &TinyWorkspace::gl, st->en_state_linear != 0, PHASE_DUAL}, {TINY_F_YL, &TinyWorkspace::yl, st->en_input_linear != 0, PHASE_DUAL},
+        {TINY_F_VLNEW_TV, &TinyWorkspace::vlnew_tv, st->en_tv_state_linear != 0, PHASE_SLACK}, {TINY_F_ZLNEW_TV, &TinyWorkspace::zlnew_tv, st->en_tv_input_linear != 0, PHASE_SLACK},
+        {TINY_F_GL_TV, &TinyWorkspace::gl_tv, st->en_tv_state_linear != 0, PHASE_DUAL}, {TINY_F_YL_TV, &TinyWorkspace::yl_tv, st->en_tv_input_linear != 0, PHASE_DUAL}};
+    for (const Io& f : io) {
+        if (!f.on) continue;
+        const TinyMatrixPOD& m = w->*(f.m);
+        const size_t sz = is_state_field(f.f) ? ns : ni;
+        if ((size_t)(m.rows * m.cols) != sz || !m.data) { fprintf(stderr, "tinympc_amd phase: workspace field %d has the wrong size\n", (int)f.f); return -TINY_ERR_DIM; }
+        if (int rc = tiny_batch_set(b, f.f, m.data, TINY_HOST)) { fprintf(stderr, "tinympc_amd phase: %s\n", b->err); return -rc; }
+    }
+    if (int rc = tiny_batch_phase(b, phase)) { fprintf(stderr, "tinympc_amd phase: %s\n", b->err); return -rc; }
+    for (const Io& f : io) {
+        // p is written by update_linear_cost (its last column) and by backward_pass_grad (the others)
+        const bool written = f.on && (f.writer == phase || (f.writer == -1 && (phase == PHASE_LINEAR_COST || phase == PHASE_BACKWARD)));
+        if (!written) continue;
+        if (int rc = tiny_batch_get(b, f.f, (w->*(f.m)).data, TINY_HOST)) { fprintf(stderr, "tinympc_amd phase: %s\n", b->err); return -rc; }
+    }
+    if (phase != PHASE_TERMINATION) return 0;
+    int4 st4;
+    double res[4];
+    if (hipMemcpyAsync(&st4, b->d_status, sizeof(int4), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -TINY_ERR_HIP;
+    if (hipMemcpyAsync(res, b->d_resid, sizeof(res), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -TINY_ERR_HIP;
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return -TINY_ERR_HIP;
+    w->primal_residual_state = res[0]; w->primal_residual_input = res[1];             // admm.cpp:314-317
+    w->dual_residual_state = res[2]; w->dual_residual_input = res[3];
+    return st4.y;
+}
+
+// a 1-thread GPU evaluation of the small projection utilities (no CPU arithmetic in this library)
+int project_on_device(int which, double* v, const double* a, int n, float mu, double bb) {
+    double *dv = nullptr, *da = nullptr;
+    if (hipMalloc(&dv, (size_t)n * sizeof(double)) != hipSuccess) return TINY_ERR_HIP;
+    int rc = TINY_OK;
+    if (hipMemcpy(dv, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = TINY_ERR_HIP;
+    if (!rc && a) {
+        if (hipMalloc(&da, (size_t)n * sizeof(double)) != hipSuccess || hipMemcpy(da, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = TINY_ERR_HIP;
+    }
+    if (!rc) rc = launch_projection(which, dv, da, n, mu, bb);
+    if (!rc && hipMemcpy(v, dv, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = TINY_ERR_HIP;
+    hipFree(dv);
+    if (da) hipFree(da);
+    return rc;
 }
 
 }  // namespace
@@ -513,6 +590,33 @@ int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref) {   // tiny_a
 int solve(TinySolver* solver) { return solve_group(&solver, 1); }          // admm.cpp:331
 int tiny_solve(TinySolver* solver) { return solve(solver); }               // tiny_api.cpp:384-386
 int tiny_solve_batch(TinySolver** solvers, int n) { return solve_group(solvers, n); }
+
+// ---- admm.hpp:12-17: the phases of one iteration, each on the GPU ------------------------------
+void update_linear_cost(TinySolver* solver) { phase_call(solver, PHASE_LINEAR_COST); }      // admm.cpp:262
+void backward_pass_grad(TinySolver* solver) { phase_call(solver, PHASE_BACKWARD); }         // admm.cpp:13
+void forward_pass(TinySolver* solver) { phase_call(solver, PHASE_FORWARD); }                // admm.cpp:25
+void update_slack(TinySolver* solver) { phase_call(solver, PHASE_SLACK); }                  // admm.cpp:81
+void update_dual(TinySolver* solver) { phase_call(solver, PHASE_DUAL); }                    // admm.cpp:219
+bool termination_condition(TinySolver* solver) {                                             // admm.cpp:310
+    if (!solver || !solver->work || !solver->settings) return false;
+    const int ct = solver->settings->check_termination;
+    if (ct == 0 || solver->work->iter % ct != 0) return false;      // :312 (the reference divides by zero for ct == 0)
+    return phase_call(solver, PHASE_TERMINATION) == 1;
+}
+TinyVectorPOD* project_soc(TinyVectorPOD* result, const TinyVectorPOD* s, float mu) {        // admm.cpp:39
+    result->data = nullptr; result->rows = 0;
+    vec_assign(result, s->data, s->rows);
+    if (s->rows > 0 && project_on_device(0, result->data, nullptr, (int)s->rows, mu, 0.0) != TINY_OK)
+        fprintf(stderr, "project_soc: GPU evaluation failed (libtinympc_amd has no CPU path)\n");
+    return result;
+}
+TinyVectorPOD* project_hyperplane(TinyVectorPOD* result, const TinyVectorPOD* z, const TinyVectorPOD* a, double b) {   // admm.cpp:70
+    result->data = nullptr; result->rows = 0;
+    vec_assign(result, z->data, z->rows);
+    if (z->rows > 0 && project_on_device(1, result->data, a->data, (int)z->rows, 0.0f, b) != TINY_OK)
+        fprintf(stderr, "project_hyperplane: GPU evaluation failed (libtinympc_amd has no CPU path)\n");
+    return result;
+}
 
 int tiny_destroy(TinySolver* solver) {
     if (!solver) return TINY_ERR_NULL;

@@ -41,6 +41,16 @@ struct GeneralArgs {
         o_tau, o_tbu;
 };
 
+// phases of admm_phase_kernel (the batched form of the reference's exported phase functions, admm.hpp:12-17)
+enum : int {
+    PHASE_LINEAR_COST = 1,   // update_linear_cost     admm.cpp:262-304
+    PHASE_BACKWARD = 2,      // backward_pass_grad     admm.cpp:13-20
+    PHASE_FORWARD = 3,       // forward_pass           admm.cpp:25-32
+    PHASE_SLACK = 4,         // update_slack           admm.cpp:81-211
+    PHASE_DUAL = 5,          // update_dual            admm.cpp:219-256
+    PHASE_TERMINATION = 6,   // termination_condition  admm.cpp:310-328 (the residual part; status.y = the returned bool)
+};
+
 #ifdef TINYMPC_GENERAL_KERNEL_IMPL   // the kernel body is compiled into batch_api.hip only
 
 __device__ __forceinline__ double wave_max64(double v) {
@@ -74,31 +84,144 @@ __device__ __forceinline__ void halfspace_inplace(double* z, int n, const double
     }
 }
 
+// LDS carve-up shared by the solve kernel and the single-phase kernel
+struct GkLds {
+    double *sMB, *sMF1, *sMF2, *sPT, *sW, *sU, *sPX, *sX, *sQR, *sPD;
+};
+__device__ __forceinline__ GkLds gk_carve(const GeneralArgs& P, double* lds) {
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
+    GkLds L;
+    L.sMB = lds;
+    L.sMF1 = L.sMB + nz * ld;
+    L.sMF2 = L.sMF1 + nz * ld;
+    L.sPT = L.sMF2 + nz * ld;
+    L.sW = L.sPT + nz * ld;        // [nz]  knot vector being multiplied
+    L.sU = L.sW + nz;              // [nu]
+    L.sPX = L.sU + nu;             // [nx]  terminal term -(Xref' Pinf)
+    L.sX = L.sPX + nx;             // [N*nz] x|u trajectory (work->x, work->u)
+    L.sQR = L.sX + N * nz;         // [N*nz] q|r
+    L.sPD = L.sQR + N * nz;        // [N*nz] p|d
+    return L;
+}
+
+// backward_pass_grad (admm.cpp:13-20) on the LDS trajectories: reads q|r and p[:,N-1], writes p and d
+__device__ __forceinline__ void gk_backward(const GeneralArgs& P, const GkLds& L, const int lane) {
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
+    const bool is_state = lane < nx, is_input = lane >= nx && lane < nz;
+    const double* CB = P.gtab + P.o_cb;
+    double *sMB = L.sMB, *sW = L.sW, *sQR = L.sQR, *sPD = L.sPD;
+    if (is_state) sW[lane] = sPD[(N - 1) * nz + lane];
+    for (int i = N - 2; i >= 0; --i) {
+        const int o = i * nz;
+        if (is_input) sW[lane] = sQR[o + lane];                // r_i
+        __syncthreads();
+        double acc = 0.0;
+        if (lane < nz)
+            for (int k = 0; k < nz; ++k) acc = fma(sMB[lane * ld + k], sW[k], acc);
+        __syncthreads();
+        if (is_state) {
+            const double p = sQR[o + lane] + acc + CB[lane];   // q_i + AmBKt p - Kinf' r + APf
+            sPD[o + lane] = p;
+            sW[lane] = p;
+        } else if (is_input) {
+            sPD[o + lane] = acc + CB[lane];                    // d_i = Quu_inv (B' p + r + BPf)
+        }
+    }
+    __syncthreads();
+}
+
+// forward_pass (admm.cpp:25-32): reads x[:,0] and d, writes u and x[:,1:]
+__device__ __forceinline__ void gk_forward(const GeneralArgs& P, const GkLds& L, const int lane) {
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
+    const bool is_state = lane < nx, is_input = lane >= nx && lane < nz;
+    const double* CF = P.gtab + P.o_cf;
+    double *sMF1 = L.sMF1, *sMF2 = L.sMF2, *sW = L.sW, *sU = L.sU, *sX = L.sX, *sPD = L.sPD;
+    if (is_state) sW[lane] = sX[lane];
+    for (int i = 0; i < N - 1; ++i) {
+        const int o = i * nz;
+        __syncthreads();
+        double acc = 0.0;
+        if (lane < nz)
+            for (int k = 0; k < nx; ++k) acc = fma(sMF1[lane * ld + k], sW[k], acc);
+        if (is_input) {
+            const double u = acc - sPD[o + lane];              // -Kinf x_i - d_i
+            sX[o + lane] = u;
+            sU[lane - nx] = u;
+        }
+        __syncthreads();
+        if (is_state) {
+            double xn = acc;
+            for (int m = 0; m < nu; ++m) xn = fma(sMF2[lane * ld + nx + m], sU[m], xn);
+            xn += CF[lane];
+            sX[o + nz + lane] = xn;
+            sW[lane] = xn;
+        }
+    }
+    __syncthreads();
+}
+
+// cone and half-space projections of the refreshed slacks (admm.cpp:112-211): one lane per knot point,
+// constraints applied sequentially
+__device__ __forceinline__ void gk_project(const GeneralArgs& P, const size_t rec, const int lane) {
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu;
+    for (int i = lane; i < N; i += 64) {
+        double* vcol;
+        double zbuf[32];
+        const size_t o = rec + (size_t)i * nz;
+        for (int k = 0; k < P.n_sc; ++k) {
+            vcol = P.cslack + o + (int)P.gtab[P.o_sc + 2 * k];
+            double s3[3] = {vcol[0], vcol[1], vcol[2]};
+            soc3_inplace(s3, P.gtab[P.o_sc + 2 * k + 1]);
+            vcol[0] = s3[0]; vcol[1] = s3[1]; vcol[2] = s3[2];
+        }
+        if (i < N - 1)
+            for (int k = 0; k < P.n_ic; ++k) {
+                vcol = P.cslack + o + nx + (int)P.gtab[P.o_ic + 2 * k];
+                double s3[3] = {vcol[0], vcol[1], vcol[2]};
+                soc3_inplace(s3, P.gtab[P.o_ic + 2 * k + 1]);
+                vcol[0] = s3[0]; vcol[1] = s3[1]; vcol[2] = s3[2];
+            }
+        if (P.lin_s && P.nsl > 0) {
+            for (int c = 0; c < nx; ++c) zbuf[c] = P.lslack[o + c];
+            for (int k = 0; k < P.nsl; ++k) halfspace_inplace(zbuf, nx, P.gtab + P.o_ax + k * nx, P.gtab[P.o_bx + k]);
+            for (int c = 0; c < nx; ++c) P.lslack[o + c] = zbuf[c];
+        }
+        if (P.lin_i && P.nil > 0 && i < N - 1) {
+            for (int c = 0; c < nu; ++c) zbuf[c] = P.lslack[o + nx + c];
+            for (int k = 0; k < P.nil; ++k) halfspace_inplace(zbuf, nu, P.gtab + P.o_au + k * nu, P.gtab[P.o_bu + k]);
+            for (int c = 0; c < nu; ++c) P.lslack[o + nx + c] = zbuf[c];
+        }
+        if (P.tlin_s && P.ntsl > 0) {
+            for (int c = 0; c < nx; ++c) zbuf[c] = P.tlslack[o + c];
+            for (int k = 0; k < P.ntsl; ++k)
+                halfspace_inplace(zbuf, nx, P.gtab + P.o_tax + (size_t)(i * P.ntsl + k) * nx, P.gtab[P.o_tbx + i * P.ntsl + k]);
+            for (int c = 0; c < nx; ++c) P.tlslack[o + c] = zbuf[c];
+        }
+        if (P.tlin_i && P.ntil > 0 && i < N - 1) {
+            for (int c = 0; c < nu; ++c) zbuf[c] = P.tlslack[o + nx + c];
+            for (int k = 0; k < P.ntil; ++k)
+                halfspace_inplace(zbuf, nu, P.gtab + P.o_tau + (size_t)(i * P.ntil + k) * nu, P.gtab[P.o_tbu + i * P.ntil + k]);
+            for (int c = 0; c < nu; ++c) P.tlslack[o + nx + c] = zbuf[c];
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
-    double* sMB = lds;
-    double* sMF1 = sMB + nz * ld;
-    double* sMF2 = sMF1 + nz * ld;
-    double* sPT = sMF2 + nz * ld;
-    double* sW = sPT + nz * ld;        // [nz]  knot vector being multiplied
-    double* sU = sW + nz;              // [nu]
-    double* sPX = sU + nu;             // [nx]  terminal term -(Xref' Pinf)
-    double* sX = sPX + nx;             // [N*nz] x|u trajectory (work->x, work->u)
-    double* sQR = sX + N * nz;         // [N*nz] q|r
-    double* sPD = sQR + N * nz;        // [N*nz] p|d
+    const GkLds L = gk_carve(P, lds);
+    double *sMB = L.sMB, *sMF1 = L.sMF1, *sMF2 = L.sMF2, *sPT = L.sPT, *sPX = L.sPX, *sX = L.sX, *sQR = L.sQR, *sPD = L.sPD;
     for (int e = lane; e < nz * ld; e += 64) {
         sMB[e] = P.gtab[P.o_mb + e]; sMF1[e] = P.gtab[P.o_mf1 + e];
         sMF2[e] = P.gtab[P.o_mf2 + e]; sPT[e] = P.gtab[P.o_pt + e];
     }
-    const double* CB = P.gtab + P.o_cb;
-    const double* CF = P.gtab + P.o_cf;
     const double* QR = P.gtab + P.o_qr;
     const double* LO = P.gtab + P.o_lo;
     const double* HI = P.gtab + P.o_hi;
     const double rho = P.rho;
-    const bool is_state = lane < nx, is_input = lane >= nx && lane < nz;
+    const bool is_state = lane < nx;
     const int rec_n = N * nz;
     __syncthreads();
 
@@ -156,47 +279,9 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
             }
             __syncthreads();
             // ---- backward_pass_grad (admm.cpp:13-20)
-            if (is_state) sW[lane] = sPD[(N - 1) * nz + lane];
-            for (int i = N - 2; i >= 0; --i) {
-                const int o = i * nz;
-                if (is_input) sW[lane] = sQR[o + lane];                // r_i
-                __syncthreads();
-                double acc = 0.0;
-                if (lane < nz)
-                    for (int k = 0; k < nz; ++k) acc = fma(sMB[lane * ld + k], sW[k], acc);
-                __syncthreads();
-                if (is_state) {
-                    const double p = sQR[o + lane] + acc + CB[lane];   // q_i + AmBKt p - Kinf' r + APf
-                    sPD[o + lane] = p;
-                    sW[lane] = p;
-                } else if (is_input) {
-                    sPD[o + lane] = acc + CB[lane];                    // d_i = Quu_inv (B' p + r + BPf)
-                }
-            }
-            __syncthreads();
+            gk_backward(P, L, lane);
             // ---- forward_pass (admm.cpp:25-32)
-            if (is_state) sW[lane] = sX[lane];
-            for (int i = 0; i < N - 1; ++i) {
-                const int o = i * nz;
-                __syncthreads();
-                double acc = 0.0;
-                if (lane < nz)
-                    for (int k = 0; k < nx; ++k) acc = fma(sMF1[lane * ld + k], sW[k], acc);
-                if (is_input) {
-                    const double u = acc - sPD[o + lane];              // -Kinf x_i - d_i
-                    sX[o + lane] = u;
-                    sU[lane - nx] = u;
-                }
-                __syncthreads();
-                if (is_state) {
-                    double xn = acc;
-                    for (int m = 0; m < nu; ++m) xn = fma(sMF2[lane * ld + nx + m], sU[m], xn);
-                    xn += CF[lane];
-                    sX[o + nz + lane] = xn;
-                    sW[lane] = xn;
-                }
-            }
-            __syncthreads();
+            gk_forward(P, L, lane);
             // ---- update_slack (box) + update_dual + residuals (admm.cpp:85-98, 222-225, 314-317)
             double m_ps = 0.0, m_pi = 0.0, m_ds = 0.0, m_di = 0.0;
             for (int e = lane; e < rec_n; e += 64) {
@@ -217,48 +302,8 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
                 if (st ? P.tlin_s : P.tlin_i) P.tlslack[rec + e] = xv + P.tldual[rec + e];
             }
             __syncthreads();
-            // ---- projections: one lane per knot point, constraints applied sequentially (admm.cpp:112-211)
-            for (int i = lane; i < N; i += 64) {
-                double* vcol;
-                double zbuf[32];
-                const size_t o = rec + (size_t)i * nz;
-                for (int k = 0; k < P.n_sc; ++k) {
-                    vcol = P.cslack + o + (int)P.gtab[P.o_sc + 2 * k];
-                    double s3[3] = {vcol[0], vcol[1], vcol[2]};
-                    soc3_inplace(s3, P.gtab[P.o_sc + 2 * k + 1]);
-                    vcol[0] = s3[0]; vcol[1] = s3[1]; vcol[2] = s3[2];
-                }
-                if (i < N - 1)
-                    for (int k = 0; k < P.n_ic; ++k) {
-                        vcol = P.cslack + o + nx + (int)P.gtab[P.o_ic + 2 * k];
-                        double s3[3] = {vcol[0], vcol[1], vcol[2]};
-                        soc3_inplace(s3, P.gtab[P.o_ic + 2 * k + 1]);
-                        vcol[0] = s3[0]; vcol[1] = s3[1]; vcol[2] = s3[2];
-                    }
-                if (P.lin_s && P.nsl > 0) {
-                    for (int c = 0; c < nx; ++c) zbuf[c] = P.lslack[o + c];
-                    for (int k = 0; k < P.nsl; ++k) halfspace_inplace(zbuf, nx, P.gtab + P.o_ax + k * nx, P.gtab[P.o_bx + k]);
-                    for (int c = 0; c < nx; ++c) P.lslack[o + c] = zbuf[c];
-                }
-                if (P.lin_i && P.nil > 0 && i < N - 1) {
-                    for (int c = 0; c < nu; ++c) zbuf[c] = P.lslack[o + nx + c];
-                    for (int k = 0; k < P.nil; ++k) halfspace_inplace(zbuf, nu, P.gtab + P.o_au + k * nu, P.gtab[P.o_bu + k]);
-                    for (int c = 0; c < nu; ++c) P.lslack[o + nx + c] = zbuf[c];
-                }
-                if (P.tlin_s && P.ntsl > 0) {
-                    for (int c = 0; c < nx; ++c) zbuf[c] = P.tlslack[o + c];
-                    for (int k = 0; k < P.ntsl; ++k)
-                        halfspace_inplace(zbuf, nx, P.gtab + P.o_tax + (size_t)(i * P.ntsl + k) * nx, P.gtab[P.o_tbx + i * P.ntsl + k]);
-                    for (int c = 0; c < nx; ++c) P.tlslack[o + c] = zbuf[c];
-                }
-                if (P.tlin_i && P.ntil > 0 && i < N - 1) {
-                    for (int c = 0; c < nu; ++c) zbuf[c] = P.tlslack[o + nx + c];
-                    for (int k = 0; k < P.ntil; ++k)
-                        halfspace_inplace(zbuf, nu, P.gtab + P.o_tau + (size_t)(i * P.ntil + k) * nu, P.gtab[P.o_tbu + i * P.ntil + k]);
-                    for (int c = 0; c < nu; ++c) P.tlslack[o + nx + c] = zbuf[c];
-                }
-            }
-            __syncthreads();
+            // ---- projections (admm.cpp:112-211)
+            gk_project(P, rec, lane);
             // ---- duals of the cone / linear slacks (admm.cpp:228-255)
             if (P.soc_s | P.soc_i | P.lin_s | P.lin_i | P.tlin_s | P.tlin_i) {
                 for (int e = lane; e < rec_n; e += 64) {
@@ -311,6 +356,135 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
         }
         __syncthreads();
     }
+}
+
+
+// ---- one phase of the iteration over the batch: the batched form of the phase functions the reference exports
+// (admm.hpp:12-17).  Works on the HBM records only (x|u = prim, q|r, p|d, the slack / dual families), exactly the
+// workspace fields the reference function reads and writes; one wavefront per instance.
+
+__global__ __launch_bounds__(64) void admm_phase_kernel(const GeneralArgs P, const int phase) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
+    const GkLds L = gk_carve(P, lds);
+    for (int e = lane; e < nz * ld; e += 64) {
+        L.sMB[e] = P.gtab[P.o_mb + e]; L.sMF1[e] = P.gtab[P.o_mf1 + e];
+        L.sMF2[e] = P.gtab[P.o_mf2 + e]; L.sPT[e] = P.gtab[P.o_pt + e];
+    }
+    const double* QR = P.gtab + P.o_qr;
+    const double* LO = P.gtab + P.o_lo;
+    const double* HI = P.gtab + P.o_hi;
+    const double rho = P.rho;
+    const int rec_n = N * nz;
+    __syncthreads();
+    for (int b = blockIdx.x; b < P.batch; b += gridDim.x) {
+        const size_t rec = (size_t)b * rec_n;
+        for (int e = lane; e < rec_n; e += 64) { L.sX[e] = P.prim[rec + e]; L.sQR[e] = P.qr[rec + e]; L.sPD[e] = P.pd[rec + e]; }
+        __syncthreads();
+        if (phase == PHASE_LINEAR_COST) {
+            if (lane < nx) {
+                double acc = 0.0;
+                for (int k = 0; k < nx; ++k) acc = fma(P.ref[rec + (size_t)(N - 1) * nz + k], L.sPT[lane * ld + k], acc);
+                L.sPX[lane] = -acc;                                                               // :292
+            }
+            __syncthreads();
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                const bool st = j < nx;
+                if (!st && i == N - 1) continue;
+                const double vn = P.slack[rec + e];
+                double qv = -(P.ref[rec + e] * QR[j]);                                            // :266 / :279
+                qv -= rho * (vn - P.dual[rec + e]);                                               // :267 / :280
+                double pv = (st && i == N - 1) ? (L.sPX[j] - rho * (vn - P.dual[rec + e])) : 0.0; // :292-293
+                if (st ? P.soc_s : P.soc_i) { const double tt = rho * (P.cslack[rec + e] - P.cdual[rec + e]); qv -= tt; pv -= tt; }
+                if (st ? P.lin_s : P.lin_i) { const double tt = rho * (P.lslack[rec + e] - P.ldual[rec + e]); qv -= tt; pv -= tt; }
+                if (st ? P.tlin_s : P.tlin_i) { const double tt = rho * (P.tlslack[rec + e] - P.tldual[rec + e]); qv -= tt; pv -= tt; }
+                L.sQR[e] = qv;
+                if (st && i == N - 1) L.sPD[e] = pv;
+            }
+            __syncthreads();
+        } else if (phase == PHASE_BACKWARD) {
+            gk_backward(P, L, lane);
+        } else if (phase == PHASE_FORWARD) {
+            gk_forward(P, L, lane);
+        } else if (phase == PHASE_SLACK) {
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                const bool st = j < nx;
+                if (!st && i == N - 1) continue;
+                const double xv = L.sX[e];
+                const double t = xv + P.dual[rec + e];                                            // :85 / :88
+                P.slack[rec + e] = fmin(HI[i * nz + j], fmax(LO[i * nz + j], t));                 // :91-98 (+-inf when disabled)
+                if (st ? P.soc_s : P.soc_i) P.cslack[rec + e] = xv + P.cdual[rec + e];            // :102-109
+                if (st ? P.lin_s : P.lin_i) P.lslack[rec + e] = xv + P.ldual[rec + e];            // :138-145
+                if (st ? P.tlin_s : P.tlin_i) P.tlslack[rec + e] = xv + P.tldual[rec + e];        // :176-183
+            }
+            __syncthreads();
+            gk_project(P, rec, lane);
+        } else if (phase == PHASE_DUAL) {
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                const bool st = j < nx;
+                if (!st && i == N - 1) continue;
+                const double xv = L.sX[e];
+                P.dual[rec + e] = (P.dual[rec + e] + xv) - P.slack[rec + e];                      // :222 / :225
+                if (st ? P.soc_s : P.soc_i) P.cdual[rec + e] = (P.cdual[rec + e] + xv) - P.cslack[rec + e];
+                if (st ? P.lin_s : P.lin_i) P.ldual[rec + e] = (P.ldual[rec + e] + xv) - P.lslack[rec + e];
+                if (st ? P.tlin_s : P.tlin_i) P.tldual[rec + e] = (P.tldual[rec + e] + xv) - P.tlslack[rec + e];
+            }
+            __syncthreads();
+        } else if (phase == PHASE_TERMINATION) {
+            double m_ps = 0.0, m_pi = 0.0, m_ds = 0.0, m_di = 0.0;
+            for (int e = lane; e < rec_n; e += 64) {
+                const int i = e / nz, j = e - i * nz;
+                const bool st = j < nx;
+                if (!st && i == N - 1) continue;
+                const double vn = P.slack[rec + e];
+                const double pr = fabs(L.sX[e] - vn), du = fabs(P.slack_prev[rec + e] - vn);      // :314-317
+                if (st) { m_ps = fmax(m_ps, pr); m_ds = fmax(m_ds, du); }
+                else { m_pi = fmax(m_pi, pr); m_di = fmax(m_di, du); }
+            }
+            const double r_ps = wave_max64(m_ps), r_pi = wave_max64(m_pi);
+            const double r_ds = wave_max64(m_ds) * rho, r_di = wave_max64(m_di) * rho;
+            const bool conv = (r_ps < P.tol_pri) && (r_pi < P.tol_pri) && (r_ds < P.tol_dua) && (r_di < P.tol_dua);
+            if (lane == 0) {
+                int4 st4 = P.status[b];
+                st4.y = conv ? 1 : 0; st4.w = 1;
+                P.status[b] = st4;
+                *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(r_ps, r_pi, r_ds, r_di);
+            }
+        }
+        for (int e = lane; e < rec_n; e += 64) {
+            const int i = e / nz, j = e - i * nz;
+            if (j >= nx && i == N - 1) continue;
+            P.prim[rec + e] = L.sX[e]; P.qr[rec + e] = L.sQR[e]; P.pd[rec + e] = L.sPD[e];
+        }
+        __syncthreads();
+    }
+}
+
+// project_soc (admm.cpp:39-60) / project_hyperplane (:70-73) on one small vector (the exported utility functions)
+__global__ void project_soc_kernel(double* s, const int n, const float mu) {
+    if (threadIdx.x != 0 || n < 1) return;
+    const double u0 = s[n - 1] * (double)mu;                                            // :40
+    double nn = 0.0;
+    for (int c = 0; c < n - 1; ++c) nn = __dadd_rn(nn, __dmul_rn(s[c], s[c]));
+    const float a = (float)sqrt(nn);                                                    // :42
+    if ((double)a <= -u0) { for (int c = 0; c < n; ++c) s[c] = 0.0; }                   // :46
+    else if ((double)a <= u0) {}                                                        // :49
+    else if ((double)a >= fabs(u0)) {                                                   // :52
+        const double scale = 0.5 * (1.0 + u0 / (double)a);
+        for (int c = 0; c < n - 1; ++c) s[c] = scale * s[c];
+        s[n - 1] = scale * (double)(a / mu);
+    } else { for (int c = 0; c < n; ++c) s[c] = 0.0; }
+}
+__global__ void project_hyperplane_kernel(double* z, const double* a, const int n, const double b) {
+    if (threadIdx.x != 0) return;
+    double az = 0.0, aa = 0.0;
+    for (int c = 0; c < n; ++c) { az = __dadd_rn(az, __dmul_rn(a[c], z[c])); aa = __dadd_rn(aa, __dmul_rn(a[c], a[c])); }
+    const double dist = (az - b) / aa;                                                  // :71
+    for (int c = 0; c < n; ++c) z[c] = z[c] - dist * a[c];                              // :72
 }
 
 #endif  // TINYMPC_GENERAL_KERNEL_IMPL
