@@ -266,21 +266,26 @@ __device__ __forceinline__ double grp_max16(double v) {
     return v;
 }
 
-// project_soc (admm.cpp:39-60) for one component of a 3-cone; s0,s1,s2 = the cone's vector,
-// c = which component this lane owns.  mu and the norm are float, a/mu is a float division.
-__device__ __forceinline__ double soc_component(double s0, double s1, double s2, int c, double mu_d) {
-    const float mu = (float)mu_d;
+// project_soc (admm.cpp:39-60) for one component of a 3-cone; s0,s1,s2 = the cone's vector, mine = s[c], the
+// component this lane owns.  mu and the norm are float, a/mu is a float division.  The reference is built without
+// FMA contraction, and `a` is truncated to float before the branch tests, so the sum of squares must not be fused.
+// The two divisions of the "outside" branch are skipped when no lane of the wave is outside its cone.
+__device__ __forceinline__ double soc_component(double s0, double s1, double s2, double mine, int c, float mu) {
+#pragma clang fp contract(off)
     const double u0 = s2 * (double)mu;                                  // :40
-    const float a = (float)sqrt(__dadd_rn(__dmul_rn(s0, s0), __dmul_rn(s1, s1)));   // :42
-    const double mine = (c == 0) ? s0 : ((c == 1) ? s1 : s2);
-    if ((double)a <= -u0) return 0.0;                                   // :46
-    if ((double)a <= u0) return mine;                                   // :49
-    if ((double)a >= fabs(u0)) {                                        // :52
-        const double scale = 0.5 * (1.0 + u0 / (double)a);
-        const double last = (double)(a / mu);
-        return scale * ((c == 2) ? last : mine);
+    const double q0 = s0 * s0, q1 = s1 * s1;
+    const float a = (float)sqrt(q0 + q1);                               // :42
+    const double ad = (double)a;
+    const bool below = ad <= -u0, inside = ad <= u0;                    // :46 | :49
+    const bool outside = !below && !inside && (ad >= fabs(u0));         // :52 (else :58 -> 0)
+    double r = (below || !inside) ? 0.0 : mine;
+    if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {
+        const double scale = 0.5 * (1.0 + u0 / ad);                     // :55
+        const double last = (double)(a / mu);                           // :54
+        const double o = scale * ((c == 2) ? last : mine);
+        r = outside ? o : r;
     }
-    return 0.0;
+    return r;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------
@@ -335,14 +340,17 @@ void admm_solve_kernel(const SolveArgs P) {
     double qr = P.tab[TAB_VEC + VEC_QR * 16 + j];
     const double smask = P.tab[TAB_VEC + VEC_SMASK * 16 + j];
     const double nim = P.tab[TAB_VEC + VEC_NIM * 16 + j];
-    bool soc_lane = false;
+    bool soc_lane = false, proj_lane = false;
     int cone_base = -1, cone_c = 0;
-    double cone_mu = 0.0;
+    float cone_mu = 0.0f;
+    double socmask = 0.0;
     if constexpr (SOC) {
-        soc_lane = P.tab[TAB_VEC + VEC_SOCFLAG * 16 + j] != 0.0;
+        socmask = P.tab[TAB_VEC + VEC_SOCFLAG * 16 + j];               // 1.0 on the rows that carry a cone slack
+        soc_lane = socmask != 0.0;
         cone_base = (int)P.tab[TAB_VEC + VEC_CONE_BASE * 16 + j];
-        cone_mu = P.tab[TAB_VEC + VEC_CONE_MU * 16 + j];
+        cone_mu = (float)P.tab[TAB_VEC + VEC_CONE_MU * 16 + j];        // admm.cpp:39 takes mu as float
         cone_c = (cone_base >= 0) ? (j - cone_base) : 0;
+        proj_lane = soc_lane && cone_base >= 0;
     }
     bool lin_lane = false, tlin_lane = false;
     if constexpr (LS) lin_lane = P.tab[TAB_VEC + VEC_LINFLAG * 16 + j] != 0.0;
@@ -508,14 +516,16 @@ void admm_solve_kernel(const SolveArgs P) {
                         G[s] = t - vn;                      // :222 / :225  g + x - vnew; (g + x) == t bit-for-bit
                         VN[s] = vn;
                         if constexpr (SOC) {
-                            double vc = soc_lane ? (xi + GC[s]) : 0.0;              // :102-109
+                            // vcnew = x + gc on every row of a family whose cone slack is on (:102-109); GC is 0 on the
+                            // other rows, so one FMA against the 0/1 mask does the add and the select
+                            const double tc = fma(xi, socmask, GC[s]);
                             const int base = (cone_base >= 0) ? cone_base : j;
-                            const double s0 = __shfl(vc, base, 16);
-                            const double s1 = __shfl(vc, base + 1, 16);
-                            const double s2 = __shfl(vc, base + 2, 16);
-                            const bool knot_ok = is_state || (s >= 1);
-                            if (cone_base >= 0 && soc_lane && knot_ok) vc = soc_component(s0, s1, s2, cone_c, cone_mu);
-                            GC[s] = soc_lane ? ((GC[s] + xi) - vc) : 0.0;           // :229 / :234
+                            const double s0 = __shfl(tc, base, 16);
+                            const double s1 = __shfl(tc, base + 1, 16);
+                            const double s2 = __shfl(tc, base + 2, 16);
+                            double vc = tc;
+                            if (proj_lane && (is_state || s >= 1)) vc = soc_component(s0, s1, s2, tc, cone_c, cone_mu);   // :112-135
+                            GC[s] = tc - vc;                                        // :229 / :234  (gc + x) - vcnew
                             VC[s] = vc;
                         }
                         // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over

@@ -61,9 +61,11 @@ __device__ __forceinline__ double wave_max64(double v) {
 
 // project_soc (admm.cpp:39-60) on 3 consecutive entries in place
 __device__ __forceinline__ void soc3_inplace(double* s, double mu_d) {
+#pragma clang fp contract(off)
     const float mu = (float)mu_d;
     const double u0 = s[2] * (double)mu;
-    const float a = (float)sqrt(__dadd_rn(__dmul_rn(s[0], s[0]), __dmul_rn(s[1], s[1])));
+    const double q0 = s[0] * s[0], q1 = s[1] * s[1];       // the reference is built without FMA contraction
+    const float a = (float)sqrt(q0 + q1);
     if ((double)a <= -u0) { s[0] = 0.0; s[1] = 0.0; s[2] = 0.0; }
     else if ((double)a <= u0) {}
     else if ((double)a >= fabs(u0)) {
@@ -466,10 +468,11 @@ __global__ __launch_bounds__(64) void admm_phase_kernel(const GeneralArgs P, con
 
 // project_soc (admm.cpp:39-60) / project_hyperplane (:70-73) on one small vector (the exported utility functions)
 __global__ void project_soc_kernel(double* s, const int n, const float mu) {
+#pragma clang fp contract(off)
     if (threadIdx.x != 0 || n < 1) return;
     const double u0 = s[n - 1] * (double)mu;                                            // :40
     double nn = 0.0;
-    for (int c = 0; c < n - 1; ++c) nn = __dadd_rn(nn, __dmul_rn(s[c], s[c]));
+    for (int c = 0; c < n - 1; ++c) { const double q = s[c] * s[c]; nn = nn + q; }
     const float a = (float)sqrt(nn);                                                    // :42
     if ((double)a <= -u0) { for (int c = 0; c < n; ++c) s[c] = 0.0; }                   // :46
     else if ((double)a <= u0) {}                                                        // :49
