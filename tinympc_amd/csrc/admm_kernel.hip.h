@@ -498,7 +498,7 @@ void admm_solve_kernel(const SolveArgs P) {
                         // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
                         const double res = ring_sum2<MODE, NX, NU>(fma(qlo, smask, cb), pcur, mb, qhi, mb + NX);
                         pcur = res;                                                 // p_i | d_i
-                        Dn[i] = res * nim;                                          // -d_i on input lanes, 0 elsewhere
+                        Dn[i] = fma(res, nim, cf);                                  // input lanes: -d_i; state lanes: fdyn (the forward step's constant)
                         if constexpr (DBG) { Qd[i] = qlo; Pd[i] = res; Dd[i + 1] = res; }
                         qhi = qlo;
                     }
@@ -568,8 +568,8 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int i = 0; i < N - 1; ++i) {
                         const double lo_n = sLo[(i + 1) * 16 + j], hi_n = sHi[(i + 1) * 16 + j];
                         __builtin_amdgcn_sched_barrier(0);
-                        const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // A x_i | u_i = -Kinf x_i - d_i
-                        X[i + 1] = ring_short<MODE, NX, NU>(t + cf, t, mf2);        // x_{i+1} = A x_i + f + B u_i | u_i (slot i+1)
+                        const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
+                        X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)
                         slot_update(i, lo_c, hi_c);
                         lo_c = lo_n; hi_c = hi_n;
                     }
