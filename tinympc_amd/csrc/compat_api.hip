@@ -15,10 +15,12 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 
 using namespace tinympc_amd;
 
@@ -93,7 +95,24 @@ std::string fmt(const Mat& m) { return fmt_matrix(m.a.data(), m.r, m.c); }
 Mat to_mat(const TinyMatrixPOD* m) { return Mat((int)m->rows, (int)m->cols, m->data); }
 
 // ---- device contexts for the struct-level solve --------------------------------------------
-struct Ctx { TinyBatch* b = nullptr; int n = 0; };
+struct Ctx {
+    TinyBatch* b = nullptr;
+    int n = 0;
+    // the problem family last uploaded (hash of cache, dynamics, costs, settings, bounds, cones, half-spaces): a solve
+    // whose family is unchanged skips the table rebuild and upload
+    uint64_t family = 0;
+    bool family_valid = false;
+    // one pinned host buffer + one device buffer carry every workspace field of every solver in ONE copy per direction
+    double* h_pin = nullptr;
+    double* d_xfer = nullptr;
+    size_t xfer_doubles = 0;
+};
+void release(Ctx& c) {
+    if (c.b) tiny_batch_destroy(c.b);
+    if (c.h_pin) hipHostFree(c.h_pin);
+    if (c.d_xfer) hipFree(c.d_xfer);
+    c = Ctx();
+}
 std::map<TinySolver*, Ctx> g_ctx;
 std::mutex g_mu;
 
@@ -192,7 +211,7 @@ bool is_state_field(TinyField f) {
 int device_context(TinySolver* s0, int n, TinyBatch** out) {
     const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
     Ctx& ctx = g_ctx[s0];
-    if (ctx.b && ctx.n != n) { tiny_batch_destroy(ctx.b); ctx.b = nullptr; }
+    if (ctx.b && ctx.n != n) release(ctx);
     if (!ctx.b) {
         int rc = raw_batch(&ctx.b, nx, nu, N, n);
         if (rc) {
@@ -208,6 +227,45 @@ int device_context(TinySolver* s0, int n, TinyBatch** out) {
     return TINY_OK;
 }
 
+// host-side gather / scatter over many TinySolver structs is memory-latency bound (thousands of small heap blocks):
+// split the solver range over a few threads when the group is large
+template <class F>
+void parallel_solvers(int n, F&& body) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (n < 512) ? 1 : (int)std::min<unsigned>(16u, std::max(1u, hw / 2));
+    if (nt <= 1) { body(0, n, 0); return; }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int lo = t * per, hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back([&body, lo, hi, t] { body(lo, hi, t); });
+    }
+    for (std::thread& t : th) t.join();
+}
+
+uint64_t fnv(uint64_t h, const void* p, size_t bytes) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+uint64_t family_hash(const TinySolver* s) {
+    const TinyWorkspace* w = s->work;
+    const TinyCache* c = s->cache;
+    uint64_t h = 1469598103934665603ull;
+    auto mat = [&](const TinyMatrixPOD& m) { h = fnv(h, &m.rows, 16); if (m.data) h = fnv(h, m.data, (size_t)(m.rows * m.cols) * 8); };
+    auto vec = [&](const TinyVectorPOD& v) { h = fnv(h, &v.rows, 8); if (v.data) h = fnv(h, v.data, (size_t)v.rows * 8); };
+    auto ivec = [&](const TinyVectorXiPOD& v) { h = fnv(h, &v.rows, 8); if (v.data) h = fnv(h, v.data, (size_t)v.rows * 4); };
+    h = fnv(h, s->settings, sizeof(TinySettings));
+    h = fnv(h, &c->rho, 8);
+    mat(c->Kinf); mat(c->Pinf); mat(c->Quu_inv); mat(c->AmBKt); vec(c->APf); vec(c->BPf);
+    mat(w->Adyn); mat(w->Bdyn); vec(w->fdyn); vec(w->Q); vec(w->R);
+    mat(w->x_min); mat(w->x_max); mat(w->u_min); mat(w->u_max);
+    h = fnv(h, &w->numStateCones, 8); vec(w->cx); vec(w->cu); ivec(w->Acx); ivec(w->Acu); ivec(w->qcx); ivec(w->qcu);
+    h = fnv(h, &w->numStateLinear, 8); mat(w->Alin_x); vec(w->blin_x); mat(w->Alin_u); vec(w->blin_u);
+    h = fnv(h, &w->numtvStateLinear, 8); mat(w->tv_Alin_x); mat(w->tv_blin_x); mat(w->tv_Alin_u); mat(w->tv_blin_u);
+    return h;
+}
+
 int solve_group(TinySolver** solvers, int n) {
     if (!solvers || n <= 0 || !solvers[0]) return TINY_ERR_NULL;
     TinySolver* s0 = solvers[0];
@@ -215,75 +273,121 @@ int solve_group(TinySolver** solvers, int n) {
     std::lock_guard<std::mutex> lk(g_mu);
     TinyBatch* b = nullptr;
     if (int rc = device_context(s0, n, &b)) return rc;
-    if (int rc = sync_family(b, s0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    Ctx& ctx = g_ctx[s0];
+    const uint64_t fam = family_hash(s0);
+    if (!ctx.family_valid || ctx.family != fam) {
+        ctx.family_valid = false;
+        if (int rc = sync_family(b, s0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        ctx.family = fam; ctx.family_valid = true;
+    }
     const size_t ns = (size_t)nx * N, ni = (size_t)nu * (N - 1);
-    std::vector<double> buf((size_t)n * ns);
-    const bool s_soc = s0->settings->en_state_soc && s0->work->numStateCones > 0;
-    const bool i_soc = s0->settings->en_input_soc && s0->work->numInputCones > 0;
-    auto gather = [&](const FieldMap& fm) -> int {
-        const size_t sz = is_state_field(fm.f) ? ns : ni;
+    const TinySettings* st0 = s0->settings;
+    const bool s_soc = st0->en_state_soc && s0->work->numStateCones > 0;
+    const bool i_soc = st0->en_input_soc && s0->work->numInputCones > 0;
+    const bool any_lin = st0->en_state_linear || st0->en_input_linear || st0->en_tv_state_linear || st0->en_tv_input_linear;
+    // transfer plan: which workspace fields go up, which come back (exactly what the reference's solve() reads / writes)
+    std::vector<FieldMap> in(std::begin(kIn), std::end(kIn)), out(std::begin(kOut), std::end(kOut));
+    if (s_soc || i_soc || any_lin)
+        for (const FieldMap& fm : kInSoc)
+            if (!((fm.f == TINY_F_GC || fm.f == TINY_F_YC) && !(s_soc || i_soc))) in.push_back(fm);
+    auto add = [](std::vector<FieldMap>& v, const FieldMap* a, size_t k) { v.insert(v.end(), a, a + k); };
+    if (st0->en_state_linear) { add(in, kInLinS, 1); add(out, kOutLinS, 2); }
+    if (st0->en_input_linear) { add(in, kInLinI, 1); add(out, kOutLinI, 2); }
+    if (st0->en_tv_state_linear) { add(in, kInTvS, 1); add(out, kOutTvS, 2); }
+    if (st0->en_tv_input_linear) { add(in, kInTvI, 1); add(out, kOutTvI, 2); }
+    if (s_soc) add(out, kOutSocS, 2);
+    if (i_soc) add(out, kOutSocI, 2);
+    auto fsize = [&](const FieldMap& fm) { return is_state_field(fm.f) ? ns : ni; };
+    size_t in_doubles = (size_t)n * nx, out_doubles = (size_t)n * 6;      // + x0 | + status (int4 = 2 doubles) + 4 residuals
+    for (const FieldMap& fm : in) in_doubles += (size_t)n * fsize(fm);
+    for (const FieldMap& fm : out) out_doubles += (size_t)n * fsize(fm);
+    const size_t need = std::max(in_doubles, out_doubles);
+    if (ctx.xfer_doubles < need) {
+        if (ctx.h_pin) hipHostFree(ctx.h_pin);
+        if (ctx.d_xfer) hipFree(ctx.d_xfer);
+        ctx.h_pin = nullptr; ctx.d_xfer = nullptr; ctx.xfer_doubles = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx.h_pin), need * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx.d_xfer), need * sizeof(double)) != hipSuccess) return TINY_ERR_HIP;
+        ctx.xfer_doubles = need;
+    }
+    // gather -> one H2D copy -> device-side packs (no host synchronisation until the results are back)
+    const bool trace = getenv("TINYMPC_AMD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    for (const FieldMap& fm : in)
         for (int k = 0; k < n; ++k) {
             const TinyMatrixPOD& m = solvers[k]->work->*(fm.m);
-            if ((size_t)(m.rows * m.cols) != sz) return fail(b, TINY_ERR_DIM, "workspace field %d of solver %d has the wrong size", (int)fm.f, k);
-            memcpy(&buf[k * sz], m.data, sz * sizeof(double));
+            if ((size_t)(m.rows * m.cols) != fsize(fm) || !m.data) return fail(b, TINY_ERR_DIM, "workspace field %d of solver %d has the wrong size", (int)fm.f, k);
         }
-        return tiny_batch_set(b, fm.f, buf.data(), TINY_HOST);
-    };
-    for (const FieldMap& fm : kIn) if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
-    const TinySettings* st0 = s0->settings;
-    const bool any_lin = st0->en_state_linear || st0->en_input_linear || st0->en_tv_state_linear || st0->en_tv_input_linear;
-    if (s_soc || i_soc || any_lin)
-        for (const FieldMap& fm : kInSoc) {
-            if ((fm.f == TINY_F_GC || fm.f == TINY_F_YC) && !(s_soc || i_soc)) continue;
-            if (int rc = gather(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    parallel_solvers(n, [&](int lo, int hi, int) {
+        size_t o = 0;
+        for (const FieldMap& fm : in) {
+            const size_t sz = fsize(fm);
+            for (int k = lo; k < hi; ++k) memcpy(ctx.h_pin + o + k * sz, (solvers[k]->work->*(fm.m)).data, sz * sizeof(double));
+            o += (size_t)n * sz;
         }
-    if (st0->en_state_linear) for (const FieldMap& fm : kInLinS) if (int rc = gather(fm)) return rc;
-    if (st0->en_input_linear) for (const FieldMap& fm : kInLinI) if (int rc = gather(fm)) return rc;
-    if (st0->en_tv_state_linear) for (const FieldMap& fm : kInTvS) if (int rc = gather(fm)) return rc;
-    if (st0->en_tv_input_linear) for (const FieldMap& fm : kInTvI) if (int rc = gather(fm)) return rc;
-    for (int k = 0; k < n; ++k) memcpy(&buf[(size_t)k * nx], solvers[k]->work->x.data, nx * sizeof(double));   // x[:,0] = x0
-    if (int rc = tiny_batch_set(b, TINY_F_X0, buf.data(), TINY_HOST)) return rc;
+        for (int k = lo; k < hi; ++k) memcpy(ctx.h_pin + o + (size_t)k * nx, solvers[k]->work->x.data, nx * sizeof(double));   // x[:,0] = x0
+    });
+    size_t off = 0;
+    for (const FieldMap& fm : in) off += (size_t)n * fsize(fm);
+    const double t1 = now();
+    if (hipMemcpyAsync(ctx.d_xfer, ctx.h_pin, in_doubles * sizeof(double), hipMemcpyHostToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    off = 0;
+    for (const FieldMap& fm : in) {
+        if (int rc = tiny_batch_set(b, fm.f, ctx.d_xfer + off, TINY_DEVICE)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        off += (size_t)n * fsize(fm);
+    }
+    if (int rc = tiny_batch_set(b, TINY_F_X0, ctx.d_xfer + off, TINY_DEVICE)) return rc;
 
     if (int rc = launch_solve(b)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
 
-    auto scatter = [&](const FieldMap& fm) -> int {
-        if (int rc = tiny_batch_get(b, fm.f, buf.data(), TINY_HOST)) return rc;
-        const size_t sz = is_state_field(fm.f) ? ns : ni;
-        for (int k = 0; k < n; ++k) {
-            TinyMatrixPOD& m = solvers[k]->work->*(fm.m);
-            if ((size_t)(m.rows * m.cols) == sz) memcpy(m.data, &buf[k * sz], sz * sizeof(double));
-        }
-        return TINY_OK;
-    };
-    for (const FieldMap& fm : kOut) if (int rc = scatter(fm)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
-    if (s_soc) for (const FieldMap& fm : kOutSocS) if (int rc = scatter(fm)) return rc;
-    if (i_soc) for (const FieldMap& fm : kOutSocI) if (int rc = scatter(fm)) return rc;
-    if (st0->en_state_linear) for (const FieldMap& fm : kOutLinS) if (int rc = scatter(fm)) return rc;
-    if (st0->en_input_linear) for (const FieldMap& fm : kOutLinI) if (int rc = scatter(fm)) return rc;
-    if (st0->en_tv_state_linear) for (const FieldMap& fm : kOutTvS) if (int rc = scatter(fm)) return rc;
-    if (st0->en_tv_input_linear) for (const FieldMap& fm : kOutTvI) if (int rc = scatter(fm)) return rc;
-    std::vector<int4> st(n);
-    std::vector<double> res((size_t)n * 4);
-    if (hipMemcpyAsync(st.data(), b->d_status, n * sizeof(int4), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
-    if (hipMemcpyAsync(res.data(), b->d_resid, n * 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
-    if (hipStreamSynchronize(b->stream) != hipSuccess) return TINY_ERR_HIP;
-    int all = 0;
-    for (int k = 0; k < n; ++k) {
-        TinySolver* s = solvers[k];
-        TinyWorkspace* w = s->work;
-        w->iter = st[k].x;                                   // admm.cpp:337,394
-        w->status = st[k].z;                                 // admm.cpp:336,431
-        if (st[k].w) {                                       // residuals are only written by a check (admm.cpp:312-317)
-            w->primal_residual_state = res[4 * k + 0]; w->primal_residual_input = res[4 * k + 1];
-            w->dual_residual_state = res[4 * k + 2]; w->dual_residual_input = res[4 * k + 3];
-        }
-        s->solution->iter = st[k].x;                         // admm.cpp:434-437 / :450-453
-        s->solution->solved = st[k].y;
-        mat_assign(&s->solution->x, w->vnew.data, w->vnew.rows, w->vnew.cols);
-        mat_assign(&s->solution->u, w->znew.data, w->znew.rows, w->znew.cols);
-        if (st[k].y) std::cout << "Solver converged in " << w->iter << " iterations" << std::endl;   // admm.cpp:439
-        else all = 1;
+    off = 0;
+    for (const FieldMap& fm : out) {
+        if (int rc = tiny_batch_get(b, fm.f, ctx.d_xfer + off, TINY_DEVICE)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        off += (size_t)n * fsize(fm);
     }
+    const size_t off_status = off, off_resid = off + (size_t)n * 2;
+    if (hipMemcpyAsync(ctx.d_xfer + off_status, b->d_status, n * sizeof(int4), hipMemcpyDeviceToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    if (hipMemcpyAsync(ctx.d_xfer + off_resid, b->d_resid, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    if (hipMemcpyAsync(ctx.h_pin, ctx.d_xfer, out_doubles * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    const double t2 = now();
+    if (hipStreamSynchronize(b->stream) != hipSuccess) return TINY_ERR_HIP;
+    const double t3 = now();
+    const int4* st = reinterpret_cast<const int4*>(ctx.h_pin + off_status);
+    const double* res = ctx.h_pin + off_resid;
+    std::vector<std::string> lines(17);                       // "Solver converged ..." lines per thread, printed in solver order
+    std::vector<int> unsolved(17, 0);
+    parallel_solvers(n, [&](int lo, int hi, int t) {
+        size_t o = 0;
+        for (const FieldMap& fm : out) {
+            const size_t sz = fsize(fm);
+            for (int k = lo; k < hi; ++k) {
+                TinyMatrixPOD& m = solvers[k]->work->*(fm.m);
+                if ((size_t)(m.rows * m.cols) == sz) memcpy(m.data, ctx.h_pin + o + k * sz, sz * sizeof(double));
+            }
+            o += (size_t)n * sz;
+        }
+        for (int k = lo; k < hi; ++k) {
+            TinySolver* s = solvers[k];
+            TinyWorkspace* w = s->work;
+            w->iter = st[k].x;                                   // admm.cpp:337,394
+            w->status = st[k].z;                                 // admm.cpp:336,431
+            if (st[k].w) {                                       // residuals are only written by a check (admm.cpp:312-317)
+                w->primal_residual_state = res[4 * k + 0]; w->primal_residual_input = res[4 * k + 1];
+                w->dual_residual_state = res[4 * k + 2]; w->dual_residual_input = res[4 * k + 3];
+            }
+            s->solution->iter = st[k].x;                         // admm.cpp:434-437 / :450-453
+            s->solution->solved = st[k].y;
+            mat_assign(&s->solution->x, w->vnew.data, w->vnew.rows, w->vnew.cols);
+            mat_assign(&s->solution->u, w->znew.data, w->znew.rows, w->znew.cols);
+            if (st[k].y) lines[t] += "Solver converged in " + std::to_string(w->iter) + " iterations\n";   // admm.cpp:439
+            else unsolved[t] = 1;
+        }
+    });
+    int all = 0;
+    for (size_t t = 0; t < lines.size(); ++t) { std::cout << lines[t]; all |= unsolved[t]; }
+    std::cout.flush();
+    if (trace) fprintf(stderr, "tiny_solve trace (us): gather %.0f, enqueue %.0f, wait %.0f, scatter+print %.0f; in %zu B out %zu B\n", t1 - t0, t2 - t1, t3 - t2, now() - t3, in_doubles * 8, out_doubles * 8);
     return all;                                              // 0 converged / 1 max_iter (admm.cpp:441,454)
 }
 
@@ -294,6 +398,7 @@ int phase_call(TinySolver* s, int phase) {
     std::lock_guard<std::mutex> lk(g_mu);
     TinyBatch* b = nullptr;
     if (int rc = device_context(s, 1, &b)) return -rc;
+    g_ctx[s].family_valid = false;                     // the phase path re-uploads the family unconditionally
     if (int rc = sync_family(b, s)) { fprintf(stderr, "tinympc_amd phase: %s\n", b->err); return -rc; }
     TinyWorkspace* w = s->work;
     const TinySettings* st = s->settings;
@@ -623,7 +728,7 @@ int tiny_destroy(TinySolver* solver) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_ctx.find(solver);
-        if (it != g_ctx.end()) { if (it->second.b) tiny_batch_destroy(it->second.b); g_ctx.erase(it); }
+        if (it != g_ctx.end()) { release(it->second); g_ctx.erase(it); }
     }
     // every matrix member is {data*, ...}: walk the structs as arrays of words would be fragile; free by name
     TinyWorkspace* w = solver->work;
