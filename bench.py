@@ -37,6 +37,11 @@ def flops_per_iter(nx, nu, N):
 
 
 def main():
+    # stdout carries exactly ONE line, the result JSON: libraries that chat on fd 1 (RCCL prints a version banner at
+    # communicator creation) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -194,7 +199,8 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     s.close()
     if dist is not None:
         dist.destroy_process_group()
