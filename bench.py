@@ -151,6 +151,30 @@ def main():
     acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]
 
     kern_ms = s.timing_ms()
+    # After the timed region (rank 0 only, untimed): the same episode with ONE launch per MPC step, so that the two
+    # regimes SURVEY.md 8(d) asks for are visible separately -- cold steps (100 ADMM iterations each, FP64 bound) and
+    # steady state (1-2 iterations, every launch loads and stores the records: the real HBM roofline of this path).
+    regimes = None
+    if rank == 0 and T > 1 and args.steps >= 100:
+        with torch.cuda.stream(stream):
+            cold_start()
+            s.set_option("steps_per_launch", 1)
+            s.set_option("timing", 100)
+            for _ in range(100):
+                s.solve_async()
+            s.synchronize()
+            ms = s.timing_ms()
+            s.set_option("steps_per_launch", T)
+        fl1 = flops_per_iter(nx, nu, N)
+        bw = s.algorithmic_bytes(cold=False) * B
+        warm = float(ms[70:].mean()) * 1e-3
+        cold = float(ms[:5].mean()) * 1e-3
+        regimes = {
+            "cold": {"steps": "0-4", "admm_iters_per_solve": 100, "ms_per_launch": cold * 1e3,
+                     "fp64_tflops": 100 * B * fl1 / cold / 1e12, "fp64_frac": 100 * B * fl1 / cold / 1e12 / FP64_PEAK_TFLOPS},
+            "steady_state": {"steps": "70-99", "ms_per_launch": warm * 1e3, "hbm_gbs": bw / warm / 1e9,
+                             "hbm_frac": bw / warm / 1e9 / HBM_PEAK_GBS,
+                             "note": "one launch per MPC step: every launch moves bytes_warm per solve through HBM"}}
     solves = float(world) * B * args.steps
     value = solves / elapsed
     alg_bytes = s.algorithmic_bytes(cold=False) * B * T        # per launch: SURVEY.md 8(d) bytes_warm x solves per launch
@@ -197,6 +221,8 @@ def main():
             "kernel_ms": {"first": float(kern_ms[0]), "last": float(kern_ms[-1]), "sum": float(kern_ms.sum()),
                           "min": float(kern_ms.min())},
         }
+        if regimes is not None:
+            out["regimes"] = regimes
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
