@@ -328,6 +328,28 @@ def test_rocket_soc_full_batch_properties():
     assert out["iter"].min() >= 1 and out["iter"].max() <= 100
 
 
+def test_million_instance_batch():
+    """BASELINE config 5's batch size (2^20 instances, 1.3 GB per record family) in one launch: index arithmetic past
+    2^31 bytes, grid of 262 144 workgroups; 20 fused MPC steps must reproduce the reference's iteration sequence in
+    every instance and leave every instance bit-identical to instance 0."""
+    suite, _ = sc.load_suite(os.path.join(GOLDEN, "hover_warm.npz"))
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    B = 1 << 20
+    s = make_batch(suite, batch=B)
+    s.set_x_ref(np.tile(np.array(extra["hover"]["xref"], dtype=float).reshape(-1, 1), (1, prob["N"])), broadcast=True)
+    s.set_x0(np.array(extra["hover"]["x0"], dtype=float), broadcast=True)
+    s.set_option("steps_per_launch", 20)
+    s.solve_async()
+    st = s.reduce_stats()
+    assert st[7] == float(suite["episode"]["iters"][:20].sum()) * B and st[2] == B
+    it = s.status()["iter"]
+    assert np.all(it == suite["episode"]["iters"][19])
+    for k in ("u", "vnew", "g", "x0"):
+        a = s.get(k)
+        assert np.all(a == a[:1]), k
+    s.close()
+
+
 def test_device_pointer_set_get_roundtrip():
     """TINY_DEVICE flags: a host that already owns HBM buffers (here torch tensors) hands them over / receives
     results without a PCIe round trip; must equal the host-pointer path.  Runs in a fresh interpreter that imports
