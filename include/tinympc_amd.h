@@ -182,7 +182,11 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * register-resident instantiation exists), "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
  * x0 <- A x0 + B u[:,0] + f, solve, ... -- inside ONE launch with the ADMM state held in registers;
  * references stay fixed during the launch), "step_log" (1: keep per-step iteration counts / u0),
- * "reset_duals" (1: g = 0, y = 0 before every solve, examples/quadrotor_tracking.cpp:92-93), "traj_step". */
+ * "reset_duals" (1: g = 0, y = 0 before every solve, examples/quadrotor_tracking.cpp:92-93), "traj_step",
+ * "one_shot" (one-shot / cold solves: the warm-start state is taken as zero -- the state after tiny_setup or
+ * tiny_batch_reset -- WITHOUT being read, and only the results are written: 1 = x|u and vnew|znew (solution->x|u),
+ * 2 = x|u only, the bytes_cold = 8(nx+2S)+44 traffic of a solve that is not going to be warm-started; the other
+ * warm-start records are left as they were.  Register-resident shapes only). */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
 /* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state
@@ -204,7 +208,7 @@ int tiny_batch_supported_dims(int* triples, int capacity);
 int tiny_batch_kernel_path(TinyBatch* b);
 /* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
  * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */
-long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold);
+long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold);   /* cold: 0 bytes_warm, 1 bytes_cold (one_shot = 2), 2 one_shot = 1 */
 
 /* ------------------------------------------------------------------------------------------ */
 /* (B) Reference entry points over plain-data mirrors of the reference structs.

@@ -328,6 +328,33 @@ def test_rocket_soc_full_batch_properties():
     assert out["iter"].min() >= 1 and out["iter"].max() <= 100
 
 
+@pytest.mark.parametrize("name", ["tracking_random", "rocket_random_isoc", "linear_random_all"])
+def test_one_shot_equals_reset_then_solve(name):
+    """one_shot = 1 / 2 (SURVEY 8(d) bytes_cold): the warm-start records are neither read nor (except the results)
+    written; the results must be bit-identical to a solve from the reset state, whatever garbage the records hold."""
+    suite, _ = sc.load_suite(os.path.join(GOLDEN, name + ".npz"))
+    cases = suite["cases"]
+    B = cases["x0"].shape[0]
+    zero = {k: np.zeros_like(v) for k, v in cases.items() if k not in ("x0", "Xref", "Uref")}
+    ref_suite = dict(suite, cases=dict(cases, **zero))
+    ref = run_cases_hip(ref_suite)                                    # warm path from an all-zero state
+    for mode in (1, 2):
+        s = make_batch(suite)
+        rng = np.random.default_rng(mode)
+        for f in ("vnew", "znew", "g", "y", "v", "z", "x", "u"):
+            s.set(f, rng.normal(0, 7.0, cases[f].shape))              # garbage that must not be read
+        s.set_x0(cases["x0"]); s.set("Xref", cases["Xref"]); s.set("Uref", cases["Uref"])
+        s.set_option("one_shot", mode)
+        s.solve()
+        st = s.status()
+        assert np.array_equal(st["iter"], ref["iter"].astype(int)) and np.array_equal(st["solved"], ref["sol_solved"].astype(int))
+        assert np.array_equal(s.get("x"), ref["x"]) and np.array_equal(s.get("u"), ref["u"])
+        if mode == 1:
+            assert np.array_equal(s.get("vnew"), ref["vnew"]) and np.array_equal(s.get("znew"), ref["znew"])
+        assert s.kernel_path() == "regs"
+        s.close()
+
+
 def test_million_instance_batch():
     """BASELINE config 5's batch size (2^20 instances, 1.3 GB per record family) in one launch: index arithmetic past
     2^31 bytes, grid of 262 144 workgroups; 20 fused MPC steps must reproduce the reference's iteration sequence in

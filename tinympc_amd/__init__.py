@@ -385,7 +385,8 @@ class TinyBatchSolver:
         return {0: "regs", 1: "tile", 2: "cover"}[lib().tiny_batch_kernel_path(self._h)]
 
     def algorithmic_bytes(self, cold=False) -> int:
-        return int(lib().tiny_batch_algorithmic_bytes(self._h, 1 if cold else 0))
+        """cold: False / 0 bytes_warm, True / 1 bytes_cold (one_shot = 2), 2 the traffic of one_shot = 1."""
+        return int(lib().tiny_batch_algorithmic_bytes(self._h, int(cold)))
 
 
 def load_problem(name):

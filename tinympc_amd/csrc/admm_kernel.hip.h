@@ -104,6 +104,10 @@ struct SolveArgs {
     // gl_tv|yl_tv and the number of half-spaces applied per knot (max over the state / input families)
     double *lslack, *ldual, *tlslack, *tldual;
     int n_lin, n_tlin;
+    // One-shot solves (SURVEY.md 8(d) bytes_cold): 1 = the warm-start state is taken as zero (the state after
+    // tiny_setup / a reset) without being read.  store_mask: which records the launch writes back -- bit 0 x|u,
+    // bit 1 vnew|znew (= solution->x|u), bit 2 g|y, bit 3 v|z, bit 4 the cone / linear slack and dual records.
+    int cold, store_mask;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -392,24 +396,25 @@ void admm_solve_kernel(const SolveArgs P) {
             for (int s = 0; s < N; ++s) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
+                const bool warm = valid && !P.cold;
                 const double r = valid ? P.ref[off] : 0.0;
-                VN[s] = valid ? P.slack[off] : 0.0;
-                G[s] = valid ? P.dual[off] : 0.0;
-                VP[s] = valid ? P.slack_prev[off] : 0.0;
+                VN[s] = warm ? P.slack[off] : 0.0;
+                G[s] = warm ? P.dual[off] : 0.0;
+                VP[s] = warm ? P.slack_prev[off] : 0.0;
                 QX[s] = -(r * qr);                           // admm.cpp:266 / :279
                 X[s] = 0.0;
                 if (s == N - 1) ref_last = r;
                 if constexpr (SOC) {
-                    VC[s] = (valid && soc_lane) ? P.prim[off] : 0.0;        // admm.cpp:352-357
-                    GC[s] = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                    VC[s] = (warm && soc_lane) ? P.prim[off] : 0.0;         // admm.cpp:352-357
+                    GC[s] = (warm && soc_lane) ? P.cdual[off] : 0.0;
                 }
                 if constexpr (LS) {
-                    VL[s] = (valid && lin_lane) ? P.prim[off] : 0.0;        // admm.cpp:361-365
-                    GL[s] = (valid && lin_lane) ? P.ldual[off] : 0.0;
+                    VL[s] = (warm && lin_lane) ? P.prim[off] : 0.0;         // admm.cpp:361-365
+                    GL[s] = (warm && lin_lane) ? P.ldual[off] : 0.0;
                 }
                 if constexpr (LT) {
-                    VT[s] = (valid && tlin_lane) ? P.prim[off] : 0.0;       // admm.cpp:370-374
-                    GT[s] = (valid && tlin_lane) ? P.tldual[off] : 0.0;
+                    VT[s] = (warm && tlin_lane) ? P.prim[off] : 0.0;        // admm.cpp:370-374
+                    GT[s] = (warm && tlin_lane) ? P.tldual[off] : 0.0;
                 }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
@@ -605,16 +610,15 @@ void admm_solve_kernel(const SolveArgs P) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
                 if (valid) {
-                    P.prim[off] = X[s];
-                    P.slack[off] = VN[s];
-                    P.dual[off] = G[s];
-                    P.slack_prev[off] = VP[s];
+                    if (P.store_mask & 1) P.prim[off] = X[s];
+                    if (P.store_mask & 2) P.slack[off] = VN[s];
+                    if (P.store_mask & 4) P.dual[off] = G[s];
+                    if (P.store_mask & 8) P.slack_prev[off] = VP[s];
                     if constexpr (SOC) {
-                        P.cslack[off] = VC[s];
-                        P.cdual[off] = GC[s];
+                        if (P.store_mask & 16) { P.cslack[off] = VC[s]; P.cdual[off] = GC[s]; }
                     }
-                    if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
-                    if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }
+                    if constexpr (LS) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
+                    if constexpr (LT) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }
                     if constexpr (DBG) {
                         if (P.dbg_qr) {
                             P.dbg_qr[off] = Qd[s];                          // work->q | work->r

@@ -66,6 +66,7 @@ struct TinyBatch {
     bool advance_x0 = false, debug = false;
     int grid_waves_per_cu = 0, dpp_mode = 2, steps_per_launch = 1;
     bool step_log = false, reset_duals = false;
+    int one_shot = 0;                    // 1: cold state assumed, x|u + vnew|znew written; 2: x|u only (bytes_cold of SURVEY.md 8(d))
     double* d_traj = nullptr;
     // heterogeneous problem families: per-instance problem data, caches and lane tables (device)
     bool hetero = false;
