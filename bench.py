@@ -53,6 +53,9 @@ def main():
                     help="closed-loop MPC steps fused into one kernel launch (ADMM state stays in registers); "
                          "0 = auto: the largest divisor of --steps and --warmup that is <= 100; 1 = one launch per step")
     ap.add_argument("--opt", action="append", default=[], help="solver option name=value (experiments)")
+    ap.add_argument("--regimes", action="store_true",
+                    help="after the timed region, replay the episode with one launch per MPC step and report the cold / "
+                         "steady-state regimes separately (adds 100 launches of the same kernel to a profile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -151,11 +154,11 @@ def main():
     acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]
 
     kern_ms = s.timing_ms()
-    # After the timed region (rank 0 only, untimed): the same episode with ONE launch per MPC step, so that the two
+    # --regimes: after the timed region (rank 0 only, untimed): the same episode with ONE launch per MPC step, so that the two
     # regimes SURVEY.md 8(d) asks for are visible separately -- cold steps (100 ADMM iterations each, FP64 bound) and
     # steady state (1-2 iterations, every launch loads and stores the records: the real HBM roofline of this path).
     regimes = None
-    if rank == 0 and T > 1 and args.steps >= 100:
+    if args.regimes and rank == 0 and T > 1 and args.steps >= 100:
         with torch.cuda.stream(stream):
             cold_start()
             s.set_option("steps_per_launch", 1)

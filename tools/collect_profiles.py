@@ -24,7 +24,7 @@ def pmc_per_launch(dirname, counter, kernel="admm_solve_kernel"):
     return (tot / max(len(launches), 1)), len(launches)
 
 
-for name in ("pytest_gpu.txt", "smoke.txt", "bench_default.json", "bench_per_step.json", "bench_torchrun1.json",
+for name in ("pytest_gpu.txt", "smoke.txt", "bench_default.json", "bench_per_step.json", "bench_regimes.json", "bench_torchrun1.json",
              "configs_3_4.json", "phase_clocks.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_{name}"))

@@ -10,6 +10,7 @@ timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pyt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
 timeout 300 python bench.py --steps-per-launch 1 --no-cpu-baseline > $O/bench_per_step.json 2> $O/bench_per_step.err
+timeout 300 python bench.py --regimes --no-cpu-baseline > $O/bench_regimes.json 2> $O/bench_regimes.err
 TINYMPC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 100 --warmup 100 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
 cd /tmp
 for mode in fused step; do
