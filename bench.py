@@ -97,7 +97,7 @@ def main():
     s.set_option("advance_x0", 1)
     s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
     s.set_option("dpp_mode", args.dpp_mode)
-    for kv in args.opt:                              # experiments: --opt dynamic_rows=1
+    for kv in args.opt:                              # experiments: --opt grid_waves_per_cu=8
         k, v = kv.split("=")
         s.set_option(k, int(v))
     T = args.steps_per_launch

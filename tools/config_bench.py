@@ -19,7 +19,7 @@ import tinympc_amd as tm  # noqa: E402
 
 
 def apply_opts(s):
-    """TINYMPC_OPTS="dynamic_rows=1,grid_waves_per_cu=8": solver options for an experiment, applied to every solver here."""
+    """TINYMPC_OPTS="one_shot=2,grid_waves_per_cu=8": solver options for an experiment, applied to every solver here."""
     for kv in filter(None, os.environ.get("TINYMPC_OPTS", "").split(",")):
         k, v = kv.split("=")
         s.set_option(k, int(v))
