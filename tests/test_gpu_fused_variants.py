@@ -1,0 +1,104 @@
+"""Fused closed-loop launches (steps_per_launch = T) on every variant of the register-resident kernel -- cone, static /
+time-varying half-spaces, per-instance problem data, one-shot -- must leave exactly the state T single-step launches
+leave (same kernel code, state held in registers instead of going through HBM between the steps)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+sys.path.insert(0, HERE)
+
+import scenarios as sc  # noqa: E402
+import tinympc_amd as tm  # noqa: E402
+from hip_runner import make_batch  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(HERE, "golden")
+T = 7
+
+
+def closed_loop(make, fields, fused, extra_opts=()):
+    s = make()
+    s.set_option("advance_x0", 1)
+    for k, v in extra_opts:
+        s.set_option(k, v)
+    if fused:
+        s.set_option("steps_per_launch", T)
+        s.solve_async()
+    else:
+        for _ in range(T):
+            s.solve_async()
+    out = {k: s.get(k) for k in fields}
+    out["iter"] = s.status()["iter"]
+    out["acc"] = s.reduce_stats()[7:9]
+    path = s.kernel_path()
+    s.close()
+    return out, path
+
+
+@pytest.mark.parametrize("name,fields", [
+    ("rocket_random_bothsoc", ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc", "x0")),
+    ("linear_random_all", ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vlnew", "zlnew", "gl", "yl", "vlnew_tv", "gl_tv", "x0")),
+    ("linear_random_rocket_soc", ("x", "u", "vnew", "g", "zcnew", "yc", "vlnew", "gl", "zlnew_tv", "yl_tv", "x0")),
+])
+def test_fused_steps_equal_single_step_launches(name, fields):
+    suite, _ = sc.load_suite(os.path.join(GOLDEN, name + ".npz"))
+    cases = suite["cases"]
+
+    def make():
+        s = make_batch(suite, replicate=9)
+        rep = lambda a: np.concatenate([a] * 9, axis=0)
+        s.set_x0(rep(cases["x0"])); s.set("Xref", rep(cases["Xref"])); s.set("Uref", rep(cases["Uref"]))
+        return s
+    a, pa = closed_loop(make, fields, fused=False)
+    b, pb = closed_loop(make, fields, fused=True)
+    assert pa == pb == "regs"
+    assert a["acc"][0] > 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_fused_steps_heterogeneous_families():
+    from test_gpu_hetero import random_family
+    nx, nu, N, B = 12, 4, 10, 13
+    fams = [random_family(nx, nu, N, 70 + 3 * i) for i in range(B)]
+    rng = np.random.default_rng(2)
+    x0 = rng.uniform(-1, 1, (B, nx))
+    Xref = np.repeat(rng.uniform(-0.3, 0.3, (B, nx, 1)), N, axis=2)
+
+    def make():
+        s = tm.TinyBatchSolver.hetero(np.stack([f["A"] for f in fams]), np.stack([f["B"] for f in fams]),
+                                      np.stack([f["f"] for f in fams]), np.stack([f["Q"] for f in fams]),
+                                      np.stack([f["R"] for f in fams]), np.array([f["rho"] for f in fams]), N)
+        s.set_bound_constraints(np.full((nx, 1), -2.0), np.full((nx, 1), 2.0), np.full((nu, 1), -0.4), np.full((nu, 1), 0.4))
+        s.update_settings(max_iter=60)
+        s.set_x0(x0); s.set_x_ref(Xref)
+        return s
+    fields = ("x", "u", "vnew", "znew", "g", "y", "v", "z", "x0")
+    a, _ = closed_loop(make, fields, fused=False)
+    b, _ = closed_loop(make, fields, fused=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_fused_one_shot_episode():
+    """one_shot = 1 with fused steps: the state is cold only at the first step, warm (in registers) afterwards; equals
+    reset + fused launch, and only x|u, vnew|znew and x0 are written."""
+    suite, _ = sc.load_suite(os.path.join(GOLDEN, "tracking_random.npz"))
+    cases = suite["cases"]
+
+    def make(garbage):
+        s = make_batch(suite)
+        if garbage:
+            rng = np.random.default_rng(0)
+            for f in ("vnew", "znew", "g", "y", "v", "z"):
+                s.set(f, rng.normal(0, 3.0, cases[f].shape))
+        s.set_x0(cases["x0"]); s.set("Xref", cases["Xref"]); s.set("Uref", cases["Uref"])
+        return s
+    a, _ = closed_loop(lambda: make(False), ("x", "u", "vnew", "znew", "x0"), fused=True)
+    b, _ = closed_loop(lambda: make(True), ("x", "u", "vnew", "znew", "x0"), fused=True, extra_opts=(("one_shot", 1),))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
