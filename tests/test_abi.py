@@ -171,3 +171,27 @@ def test_headline_kernel_register_budget():
     assert len(head) == 1, [b[0] for b in blocks][:4]
     _, vgpr, agpr, scratch, occ = head[0]
     assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, head[0]
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/tinympc_amd.h is the C ABI: it must compile as C99 (no C++-isms) and a C program must link against the
+    library and get the documented error codes from calls that need no GPU."""
+    src = tmp_path / "c_abi.c"
+    src.write_text('''#include <stdio.h>
+#include "tinympc_amd.h"
+int main(void) {
+    TinySettings st;
+    int dims[64 * 3];
+    if (tiny_batch_solve(0) != TINY_ERR_NULL) return 1;
+    if (tiny_set_default_settings(&st) != 0 || st.max_iter != 1000 || st.check_termination != 1) return 2;   /* tiny_api.cpp:413-441 */
+    if (tiny_batch_supported_dims(dims, 64) < 19) return 3;
+    printf("ok %d\\n", (int)sizeof(TinyWorkspace));
+    return 0;
+}
+''')
+    exe = tmp_path / "c_abi"
+    libdir = os.path.dirname(tm.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.dirname(HEADER), str(src),
+                           "-L", libdir, "-ltinympc_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok 1328", (out.returncode, out.stdout, out.stderr)
