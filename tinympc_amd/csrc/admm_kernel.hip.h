@@ -610,24 +610,26 @@ void admm_solve_kernel(const SolveArgs P) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
                 if (valid) {
-                    if (P.store_mask & 1) P.prim[off] = X[s];
+                    // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
+                    if ((P.store_mask & 1) && (acc_iter > 0 || (s == 0 && is_state))) P.prim[off] = X[s];
                     if (P.store_mask & 2) P.slack[off] = VN[s];
                     if (P.store_mask & 4) P.dual[off] = G[s];
                     if (P.store_mask & 8) P.slack_prev[off] = VP[s];
                     if constexpr (SOC) {
-                        if (P.store_mask & 16) { P.cslack[off] = VC[s]; P.cdual[off] = GC[s]; }
+                        // a family whose cone switch is off keeps its records (admm.cpp:102-109, 228-235)
+                        if (soc_lane && (P.store_mask & 16)) { P.cslack[off] = VC[s]; P.cdual[off] = GC[s]; }
                     }
                     if constexpr (LS) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
                     if constexpr (LT) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }
                     if constexpr (DBG) {
-                        if (P.dbg_qr) {
+                        if (P.dbg_qr && acc_iter > 0) {
                             P.dbg_qr[off] = Qd[s];                          // work->q | work->r
                             P.dbg_pd[off] = is_state ? Pd[s] : Dd[s];       // work->p | work->d
                         }
                     }
                 }
             }
-            if (P.x0_next && is_state) P.x0_next[(size_t)b * NX + j] = X[1];     // x1 = A x0 + B u0 + f
+            if (P.x0_next && acc_iter > 0 && is_state) P.x0_next[(size_t)b * NX + j] = X[1];     // x1 = A x0 + B u0 + f (needs a forward pass)
             const double ps = grp_max16(is_state ? rp : 0.0), pi = grp_max16(is_input ? rp : 0.0);
             const double ds = grp_max16(is_state ? rd : 0.0), di = grp_max16(is_input ? rd : 0.0);
             if (j == 0) {

@@ -342,10 +342,12 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
             const int i = e / nz, j = e - i * nz;
             if (j >= nx && i == N - 1) continue;
             P.prim[rec + e] = sX[e];
-            P.qr[rec + e] = sQR[e];
-            P.pd[rec + e] = sPD[e];
+            if (iter > 0) {                                            // max_iter = 0: q, r, p, d were never computed
+                P.qr[rec + e] = sQR[e];
+                P.pd[rec + e] = sPD[e];
+            }
         }
-        if (P.x0_next && is_state) P.x0_next[(size_t)b * nx + lane] = sX[nz + lane];
+        if (P.x0_next && iter > 0 && is_state) P.x0_next[(size_t)b * nx + lane] = sX[nz + lane];
         if (lane == 0) {
             P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
             *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(r_ps, r_pi, r_ds, r_di);

@@ -194,13 +194,15 @@ void admm_tile_kernel(const SolveArgs P) {
                 const bool valid = is_state || (is_input && g >= 1);
                 const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
                 if (valid) {
-                    P.prim[off] = sX[l * 64 + lane];
+                    // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
+                    if (iter > 0) P.prim[off] = sX[l * 64 + lane];
+                    else if (g == 0 && is_state) P.prim[off] = x0v;
                     P.slack[off] = VN[l];
                     P.dual[off] = G[l];
                     P.slack_prev[off] = VP[l];
                 }
             }
-            if (P.x0_next && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = sX[64 + lane];
+            if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = sX[64 + lane];
             // residual maxima over the instance's lanes (state rows / input rows separately)
             double ps = is_state ? rp : 0.0, pi = is_input ? rp : 0.0, ds = is_state ? rd : 0.0, di = is_input ? rd : 0.0;
 #pragma unroll

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the HIP path against the oracle: random shapes (register, tile and coverage kernels), random
+problem data, random settings (check_termination 0..4, odd max_iter, tolerances, every enable switch, cones, static and
+time-varying half-spaces), random warm states.  Bar: identical iteration counts / solved flags, fields within 1e-9.
+    python tools/fuzz_parity.py [n_trials] [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenarios as sc
+from cpu_solvers import OracleSolver, build_oracle
+from hip_runner import run_cases_hip
+
+SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30),
+          (12, 8, 10), (20, 4, 10), (8, 2, 50), (20, 2, 30), (5, 3, 7), (9, 2, 12), (3, 1, 4), (16, 8, 6), (7, 7, 5)]
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def trial(seed):
+    rng = np.random.default_rng(seed)
+    nx, nu, N = SHAPES[rng.integers(len(SHAPES))]
+    M = rng.standard_normal((nx, nx))
+    A = M * rng.uniform(0.5, 1.02) / np.max(np.abs(np.linalg.eigvals(M)))
+    prob = dict(nx=nx, nu=nu, N=N, rho=float(rng.choice([0.1, 1.0, 5.0, 17.3])), A=A, B=rng.standard_normal((nx, nu)) / np.sqrt(nx),
+                f=rng.normal(0, 0.05, nx) * rng.integers(0, 2), Q=rng.uniform(0.5, 10, nx), R=rng.uniform(0.1, 2, nu))
+    kw = dict(max_iter=int(rng.integers(0, 40)) * int(rng.random() > 0.08), check_termination=int(rng.integers(0, 5)),
+              abs_pri_tol=float(10 ** rng.uniform(-5, -1)), abs_dua_tol=float(10 ** rng.uniform(-5, -1)),
+              en_state_bound=int(rng.integers(0, 2)), en_input_bound=int(rng.integers(0, 2)),
+              x_min=rng.uniform(-2.0, -0.1, (nx, N)), x_max=rng.uniform(0.1, 2.0, (nx, N)),
+              u_min=rng.uniform(-1.0, -0.05, (nu, N - 1)), u_max=rng.uniform(0.05, 1.0, (nu, N - 1)))
+    if nx >= 3 and rng.random() < 0.4:
+        kw.update(en_state_soc=int(rng.integers(0, 2)), en_input_soc=int(rng.integers(0, 2)) if nu >= 3 else 0,
+                  state_cone=([int(rng.integers(0, nx - 2))], [3], [float(rng.uniform(0.2, 1.5))]),
+                  input_cone=([int(rng.integers(0, nu - 2))], [3], [float(rng.uniform(0.2, 1.5))]) if nu >= 3 else ([], [], []))
+    if rng.random() < 0.35:
+        ns, ni = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+        kw.update(en_state_linear=int(rng.integers(0, 2)), en_input_linear=int(rng.integers(0, 2)),
+                  linear=(rng.standard_normal((ns, nx)), rng.uniform(0.1, 1.0, ns), rng.standard_normal((ni, nu)), rng.uniform(0.05, 0.5, ni)))
+    if rng.random() < 0.3:
+        ns, ni = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        kw.update(en_tv_state_linear=int(rng.integers(0, 2)), en_tv_input_linear=int(rng.integers(0, 2)),
+                  tv_linear=(rng.standard_normal((ns * N, nx)), rng.uniform(0.1, 1.0, (ns, N)),
+                             rng.standard_normal((ni * (N - 1), nu)), rng.uniform(0.05, 0.5, (ni, N - 1))))
+    cfg = sc.default_config(prob, **kw)
+    B = int(rng.integers(1, 9))
+    cases = sc.zero_cases(prob, B)
+    warm = rng.random() < 0.6
+    for k, v in cases.items():
+        if k in ("x0", "Xref", "Uref") or warm:
+            cases[k] = rng.normal(0.0, 0.4, v.shape)
+    suite = dict(problem=prob, config=cfg, cases=cases)
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite)
+    desc = f"seed {seed} shape {(nx, nu, N)} B {B} max_iter {kw['max_iter']} ct {kw['check_termination']} flags " + \
+           "".join(str(cfg[k]) for k in ("en_state_bound", "en_input_bound", "en_state_soc", "en_input_soc", "en_state_linear",
+                                          "en_input_linear", "en_tv_state_linear", "en_tv_input_linear"))
+    for k in ("iter", "sol_solved", "status"):
+        if not np.array_equal(out[k].astype(int), ref[k].astype(int)):
+            return f"{desc}: {k} {out[k].astype(int).tolist()} vs {ref[k].astype(int).tolist()}"
+    worst, wk = 0.0, ""
+    for k, v in ref.items():
+        if v.ndim >= 2 and k in out:
+            e = rel_err(out[k], v)
+            if e > worst:
+                worst, wk = e, k
+    if worst > 1e-9:
+        return f"{desc}: worst field error {worst:.3e} in {wk}"
+    return None
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    assert build_oracle()
+    bad = 0
+    for seed in range(s0, s0 + n):
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("seed", seed, flush=True)
+        try:
+            r = trial(seed)
+        except Exception as e:                      # noqa: BLE001
+            r = f"seed {seed}: {type(e).__name__}: {e}"
+        if r:
+            bad += 1
+            print("MISMATCH", r, flush=True)
+    print(f"{n} trials, {bad} mismatches")
+    sys.exit(1 if bad else 0)
