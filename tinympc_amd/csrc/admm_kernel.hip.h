@@ -600,7 +600,9 @@ void admm_solve_kernel(const SolveArgs P) {
                 if (nsteps > 1) {
                     if (P.iter_log && j == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
                     if (P.u0_log && is_input) P.u0_log[((size_t)step * P.batch + b) * NU + (j - NX)] = X[1];
-                    x0v = X[1];                               // plant step x0 <- A x0 + B u_0 + f  (== forward_pass x_1)
+                    // plant step x0 <- A x0 + B u_0 + f (== forward_pass x_1).  Input lanes hold u_0 in slot 1: their
+                    // slot 0 is the neutral dummy and must stay 0, or its "slack" would enter the dual residual
+                    x0v = is_state ? X[1] : 0.0;
                 }
             }
 

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the closed-loop surfaces against the oracle, instance by instance: fused MPC steps
+(steps_per_launch), the plant step, the moving reference window with per-instance offsets, reset_duals, heterogeneous
+problem families and one-shot launches, on random register-resident shapes with random bounds / cones / settings.
+    python tools/fuzz_closed_loop.py [n_trials] [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenarios as sc
+import tinympc_amd as tm
+from cpu_solvers import OracleSolver, build_oracle
+
+SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30)]
+
+
+def family(rng, nx, nu, N):
+    M = rng.standard_normal((nx, nx))
+    A = M * rng.uniform(0.5, 1.0) / np.max(np.abs(np.linalg.eigvals(M)))
+    return dict(nx=nx, nu=nu, N=N, rho=float(rng.choice([0.5, 1.0, 5.0])), A=A, B=rng.standard_normal((nx, nu)) / np.sqrt(nx),
+                f=rng.normal(0, 0.02, nx) * rng.integers(0, 2), Q=rng.uniform(0.5, 10, nx), R=rng.uniform(0.1, 2, nu))
+
+
+def trial(seed):
+    rng = np.random.default_rng(seed)
+    nx, nu, N = SHAPES[rng.integers(len(SHAPES))]
+    B = int(rng.integers(1, 10))
+    hetero = rng.random() < 0.3
+    fams = [family(rng, nx, nu, N) for _ in range(B if hetero else 1)]
+    T = int(rng.integers(1, 9))
+    launches = int(rng.integers(1, 4))
+    use_traj = rng.random() < 0.4
+    reset_duals = bool(use_traj and rng.random() < 0.5)
+    one_shot = 0 if (use_traj or rng.random() < 0.7) else int(rng.integers(1, 3))
+    kw = dict(max_iter=int(rng.integers(1, 30)), check_termination=int(rng.integers(1, 4)),
+              abs_pri_tol=float(10 ** rng.uniform(-4, -1)), abs_dua_tol=float(10 ** rng.uniform(-4, -1)),
+              x_min=rng.uniform(-3.0, -0.5, (nx, N)), x_max=rng.uniform(0.5, 3.0, (nx, N)),
+              u_min=rng.uniform(-1.0, -0.1, (nu, N - 1)), u_max=rng.uniform(0.1, 1.0, (nu, N - 1)))
+    if nx >= 3 and nu >= 3 and rng.random() < 0.4:
+        kw.update(en_state_soc=int(rng.integers(0, 2)), en_input_soc=1,
+                  state_cone=([int(rng.integers(0, nx - 2))], [3], [float(rng.uniform(0.3, 1.2))]),
+                  input_cone=([int(rng.integers(0, nu - 2))], [3], [float(rng.uniform(0.3, 1.2))]))
+    cfg = sc.default_config(fams[0], **kw)
+    x0 = rng.uniform(-0.5, 0.5, (B, nx))
+    Xref = rng.normal(0, 0.2, (B, nx, N))
+    Uref = rng.normal(0, 0.05, (B, nu, N - 1))
+    n_pts = N + T * launches + 3
+    traj = rng.normal(0, 0.3, (n_pts, nx))
+    offs = rng.integers(0, 3, B).astype(np.int32)
+    # ---- HIP
+    if hetero:
+        s = tm.TinyBatchSolver.hetero(*[np.stack([f[k] for f in fams]) for k in ("A", "B", "f", "Q", "R")], np.array([f["rho"] for f in fams]), N)
+    else:
+        s = tm.TinyBatchSolver.from_problem(fams[0], B)
+    s.set_bound_constraints(cfg["x_min"], cfg["x_max"], cfg["u_min"], cfg["u_max"])
+    if cfg["state_cone"] is not None:
+        s.set_cone_constraints(*cfg["state_cone"], *cfg["input_cone"])
+    s.update_settings(cfg["abs_pri_tol"], cfg["abs_dua_tol"], cfg["max_iter"], cfg["check_termination"], 1, 1, cfg["en_state_soc"], cfg["en_input_soc"])
+    s.set_x0(x0); s.set_x_ref(Xref); s.set_u_ref(Uref)
+    if use_traj:
+        s.set_reference_trajectory(traj, offs)
+        s.set_option("reset_duals", int(reset_duals))
+    s.set_option("advance_x0", 1)
+    s.set_option("steps_per_launch", T)
+    s.set_option("step_log", 1)
+    s.set_option("one_shot", one_shot)
+    its = []
+    for _ in range(launches):
+        s.solve_async()
+        if T > 1:
+            its.append(np.abs(s.step_log(T)[0]))
+        else:
+            its.append(s.status()["iter"][None, :].copy())
+    its = np.concatenate(its)                                  # [steps, B]
+    got = dict(x0=s.get("x0"), x=s.get("x"), u=s.get("u"))
+    if one_shot != 2:
+        got["vnew"] = s.get("vnew")
+    if one_shot == 0:
+        got.update(g=s.get("g"), v=s.get("v"))
+    path = s.kernel_path()
+    s.close()
+    desc = f"seed {seed} shape {(nx, nu, N)} B {B} T {T}x{launches} hetero {hetero} traj {use_traj}/{reset_duals} one_shot {one_shot} soc {cfg['en_state_soc']}{cfg['en_input_soc']} [{path}]"
+    # ---- oracle, one instance at a time
+    steps = T * launches
+    for b in range(B):
+        fam = fams[b if hetero else 0]
+        o = sc.make_solver(OracleSolver, fam, cfg)
+        o["Xref"] = Xref[b]; o["Uref"] = Uref[b]
+        xb = x0[b].copy()
+        for k in range(steps):
+            if one_shot and k % T == 0:                         # every launch starts from the cold state
+                for fld in ("vnew", "znew", "g", "y", "v", "z", "x", "u", "vcnew", "zcnew", "gc", "yc"):
+                    o[fld] = np.zeros_like(o[fld])
+            if use_traj:
+                idx = np.minimum(np.arange(N) + k + offs[b], n_pts - 1)
+                o["Xref"] = traj[idx].T
+                if reset_duals:
+                    o["g"] = np.zeros((nx, N)); o["y"] = np.zeros((nu, N - 1))
+            o["x"][:, 0] = xb
+            o.solve()
+            oit = int(o.get("sol_iter"))
+            if oit != int(its[k, b]):
+                o.close()
+                return f"{desc}: instance {b} step {k}: iterations {int(its[k, b])} vs oracle {oit}"
+            xb = fam["A"] @ xb + fam["B"] @ o["u"][:, 0] + fam["f"]
+        ref = dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"])
+        for k, v in got.items():
+            e = float(np.max(np.abs(v[b] - ref[k])) / max(np.max(np.abs(ref[k])), 1e-300))
+            if e > 1e-7:                                       # differences compound through the plant over the steps
+                o.close()
+                return f"{desc}: instance {b}: {k} off by {e:.2e}"
+        o.close()
+    return None
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    assert build_oracle()
+    bad = 0
+    for seed in range(s0, s0 + n):
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("seed", seed, flush=True)
+        try:
+            r = trial(seed)
+        except Exception as e:                      # noqa: BLE001
+            r = f"seed {seed}: {type(e).__name__}: {e}"
+        if r:
+            bad += 1
+            print("MISMATCH", r, flush=True)
+    print(f"{n} trials, {bad} mismatches")
+    sys.exit(1 if bad else 0)
