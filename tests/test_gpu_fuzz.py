@@ -76,3 +76,14 @@ def test_fuzz_closed_loop_vs_oracle(first):
     assert build_oracle()
     bad = [r for r in (fuzz_closed_loop.trial(seed) for seed in range(first, first + 100)) if r]
     assert not bad, bad[:5]
+
+
+def test_fuzz_reference_entry_points_vs_oracle(capfd):
+    """tools/fuzz_compat.py: sequences of tiny_solve calls on one plain-data TinySolver with bounds, cones, half-spaces,
+    settings and the workspace poked between the calls (the family hash must notice every change)."""
+    import fuzz_compat
+    from cpu_solvers import build_oracle
+    assert build_oracle()
+    bad = [r for r in (fuzz_compat.trial(seed) for seed in range(1, 81)) if r]
+    capfd.readouterr()                            # drop the "Solver converged in N iterations" lines
+    assert not bad, bad[:5]

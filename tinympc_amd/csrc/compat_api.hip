@@ -361,7 +361,10 @@ int solve_group(TinySolver** solvers, int n) {
         size_t o = 0;
         for (const FieldMap& fm : out) {
             const size_t sz = fsize(fm);
+            // max_iter = 0 (no iteration ran): the reference leaves x, u, q, r, p, d as they were
+            const bool sweep_output = fm.f == TINY_F_X || fm.f == TINY_F_U || (fm.f >= TINY_F_Q && fm.f <= TINY_F_D);
             for (int k = lo; k < hi; ++k) {
+                if (sweep_output && st[k].x == 0) continue;
                 TinyMatrixPOD& m = solvers[k]->work->*(fm.m);
                 if ((size_t)(m.rows * m.cols) == sz) memcpy(m.data, ctx.h_pin + o + k * sz, sz * sizeof(double));
             }
