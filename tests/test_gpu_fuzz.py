@@ -87,3 +87,65 @@ def test_fuzz_reference_entry_points_vs_oracle(capfd):
     bad = [r for r in (fuzz_compat.trial(seed) for seed in range(1, 81)) if r]
     capfd.readouterr()                            # drop the "Solver converged in N iterations" lines
     assert not bad, bad[:5]
+
+
+def test_large_solver_group_through_the_threaded_gather(capfd):
+    """tiny_solve_batch on 700 TinySolvers (>= 512: the gather / scatter over the host structs is split over threads):
+    every solver gets its own warm state and reference; 25 of them are checked against the oracle, all for bookkeeping."""
+    import ctypes as C
+    import pod
+    import scenarios as sc
+    import tinympc_amd as tm
+    import fuzz_compat
+    from cpu_solvers import OracleSolver
+    L = tm.lib()
+    fuzz_compat.proto(L)
+    L.tiny_solve_batch.argtypes = [C.POINTER(C.POINTER(pod.TinySolver)), C.c_int]
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    n = 700
+    rng = np.random.default_rng(77)
+    keep, arr = [], (C.POINTER(pod.TinySolver) * n)()
+    bounds = [np.full((nx, N), -5.0), np.full((nx, N), 5.0), np.full((nu, N - 1), -0.5), np.full((nu, N - 1), 0.5)]
+    state = []
+    for k in range(n):
+        ms = [pod.mat(prob["A"]), pod.mat(prob["B"]), pod.mat(prob["f"]), pod.mat(np.diag(prob["Q"])), pod.mat(np.diag(prob["R"]))]
+        pb = [pod.mat(a) for a in bounds]
+        keep += [ms, pb]
+        sp = C.POINTER(pod.TinySolver)()
+        assert L.tiny_setup(C.byref(sp), *[C.byref(m[0]) for m in ms], prob["rho"], nx, nu, N, 0) == 0
+        assert L.tiny_set_bound_constraints(sp, *[C.byref(m[0]) for m in pb]) == 0
+        sp.contents.settings.contents.max_iter = 40
+        w = sp.contents.work.contents
+        st = {f: rng.normal(0, 0.2, pod.to_np(getattr(w, f)).shape) for f in ("Xref", "Uref", "vnew", "znew", "g", "y", "v", "z")}
+        st["x0"] = rng.uniform(-0.5, 0.5, nx)
+        for f, a in st.items():
+            if f == "x0":
+                pod.to_np(w.x)[:, 0] = a
+            else:
+                pod.to_np(getattr(w, f))[...] = a
+        state.append(st)
+        arr[k] = sp
+    rc = L.tiny_solve_batch(arr, n)
+    capfd.readouterr()
+    cfg = sc.default_config(prob, max_iter=40, x_min=bounds[0], x_max=bounds[1], u_min=bounds[2], u_max=bounds[3])
+    o = sc.make_solver(OracleSolver, prob, cfg)
+    unsolved = 0
+    for k in range(n):
+        s = arr[k].contents
+        unsolved += 1 - s.solution.contents.solved
+        if k % 28 == 0:
+            for f, a in state[k].items():
+                if f == "x0":
+                    o["x"][:, 0] = a
+                else:
+                    o[f] = a
+            o.solve()
+            w = s.work.contents
+            assert w.iter == int(o.get("iter")) and s.solution.contents.solved == int(o.get("sol_solved")), k
+            for f in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "q", "r", "p", "d"):
+                assert np.max(np.abs(pod.to_np(getattr(w, f)) - o[f])) <= 1e-9 * max(1.0, np.max(np.abs(o[f]))), (k, f)
+    assert rc == int(unsolved > 0)
+    o.close()
+    for k in range(n):
+        L.tiny_destroy(arr[k])

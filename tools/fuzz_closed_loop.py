@@ -12,6 +12,8 @@ import tinympc_amd as tm
 from cpu_solvers import OracleSolver, build_oracle
 
 SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30)]
+# tile / coverage kernel shapes: one MPC step per launch (plant step on device), shared problem data
+SLOW_SHAPES = [(12, 8, 10), (20, 4, 10), (8, 2, 50), (5, 3, 7), (20, 2, 30), (9, 2, 12)]
 
 
 def family(rng, nx, nu, N):
@@ -23,15 +25,16 @@ def family(rng, nx, nu, N):
 
 def trial(seed):
     rng = np.random.default_rng(seed)
-    nx, nu, N = SHAPES[rng.integers(len(SHAPES))]
+    slow = rng.random() < 0.25
+    nx, nu, N = SLOW_SHAPES[rng.integers(len(SLOW_SHAPES))] if slow else SHAPES[rng.integers(len(SHAPES))]
     B = int(rng.integers(1, 10))
-    hetero = rng.random() < 0.3
+    hetero = (not slow) and rng.random() < 0.3
     fams = [family(rng, nx, nu, N) for _ in range(B if hetero else 1)]
-    T = int(rng.integers(1, 9))
-    launches = int(rng.integers(1, 4))
-    use_traj = rng.random() < 0.4
+    T = 1 if slow else int(rng.integers(1, 9))
+    launches = int(rng.integers(1, 4)) * (3 if slow else 1)
+    use_traj = (not slow) and rng.random() < 0.4
     reset_duals = bool(use_traj and rng.random() < 0.5)
-    one_shot = 0 if (use_traj or rng.random() < 0.7) else int(rng.integers(1, 3))
+    one_shot = 0 if (slow or use_traj or rng.random() < 0.7) else int(rng.integers(1, 3))
     kw = dict(max_iter=int(rng.integers(1, 30)), check_termination=int(rng.integers(1, 4)),
               abs_pri_tol=float(10 ** rng.uniform(-4, -1)), abs_dua_tol=float(10 ** rng.uniform(-4, -1)),
               x_min=rng.uniform(-3.0, -0.5, (nx, N)), x_max=rng.uniform(0.5, 3.0, (nx, N)),
