@@ -149,3 +149,12 @@ def test_large_solver_group_through_the_threaded_gather(capfd):
     o.close()
     for k in range(n):
         L.tiny_destroy(arr[k])
+
+
+def test_fuzz_phase_functions_vs_oracle():
+    """tiny_batch_phase (the reference's exported phase functions) on random shapes / families / workspaces."""
+    import fuzz_parity
+    from cpu_solvers import build_oracle
+    assert build_oracle()
+    bad = [r for r in (fuzz_parity.phase_trial(seed) for seed in range(1, 101)) if r]
+    assert not bad, bad[:5]

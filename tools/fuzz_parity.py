@@ -19,7 +19,7 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def trial(seed):
+def random_suite(seed):
     rng = np.random.default_rng(seed)
     nx, nu, N = SHAPES[rng.integers(len(SHAPES))]
     M = rng.standard_normal((nx, nx))
@@ -51,7 +51,13 @@ def trial(seed):
     for k, v in cases.items():
         if k in ("x0", "Xref", "Uref") or warm:
             cases[k] = rng.normal(0.0, 0.4, v.shape)
-    suite = dict(problem=prob, config=cfg, cases=cases)
+    return dict(problem=prob, config=cfg, cases=cases), kw
+
+
+def trial(seed):
+    suite, kw = random_suite(seed)
+    prob, cfg, cases = suite["problem"], suite["config"], suite["cases"]
+    nx, nu, N, B = prob["nx"], prob["nu"], prob["N"], cases["x0"].shape[0]
     ref = sc.run_cases(OracleSolver, suite)
     out = run_cases_hip(suite)
     desc = f"seed {seed} shape {(nx, nu, N)} B {B} max_iter {kw['max_iter']} ct {kw['check_termination']} flags " + \
@@ -71,7 +77,62 @@ def trial(seed):
     return None
 
 
+PHASES = ("update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual")
+
+
+def phase_trial(seed):
+    """The exported phase functions (tiny_batch_phase) one after the other on a fully random workspace."""
+    from hip_runner import make_batch
+    suite, kw = random_suite(seed)
+    prob, cfg, cases = suite["problem"], suite["config"], suite["cases"]
+    B = cases["x0"].shape[0]
+    rng = np.random.default_rng(seed + 77777)
+    fields = ["x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y"]
+    if (cfg["en_state_soc"] and cfg["state_cone"] is not None and len(cfg["state_cone"][0])) or \
+       (cfg["en_input_soc"] and cfg["input_cone"] is not None and len(cfg["input_cone"][0])):
+        fields += ["vcnew", "zcnew", "gc", "yc"]
+    if cfg["en_state_linear"] or cfg["en_input_linear"]:
+        fields += ["vlnew", "zlnew", "gl", "yl"]
+    if cfg["en_tv_state_linear"] or cfg["en_tv_input_linear"]:
+        fields += ["vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv"]
+    s = make_batch(suite)
+    oracles = [sc.make_solver(OracleSolver, prob, cfg) for _ in range(B)]
+    desc = f"seed {seed} shape {(prob['nx'], prob['nu'], prob['N'])} B {B}"
+    try:
+        for k in fields + ["Xref", "Uref"]:
+            a = rng.normal(0, 0.5, (B,) + oracles[0][k].shape)
+            s.set(k, a)
+            for b, o in enumerate(oracles):
+                o[k] = a[b]
+        for name in PHASES:
+            s.phase(name)
+            for o in oracles:
+                o.phase(name)
+            for k in fields:
+                got = s.get(k)
+                for b, o in enumerate(oracles):
+                    e = rel_err(got[b], o[k])
+                    if e > 1e-9:
+                        return f"{desc}: after {name}: {k}[{b}] off by {e:.2e}"
+        conv = s.phase("termination_condition")
+        st = s.status()
+        for b, o in enumerate(oracles):
+            o.set("check_termination", 1)
+            if bool(o.phase("termination_condition")) != bool(conv[b]):
+                return f"{desc}: termination_condition[{b}] differs"
+            for k in ("primal_residual_state", "dual_residual_state", "primal_residual_input", "dual_residual_input"):
+                if abs(st[k][b] - o.get(k)) > 1e-9 * max(1.0, abs(o.get(k))):
+                    return f"{desc}: {k}[{b}] {st[k][b]} vs {o.get(k)}"
+    finally:
+        s.close()
+        for o in oracles:
+            o.close()
+    return None
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "phases":
+        trial = phase_trial
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     assert build_oracle()
