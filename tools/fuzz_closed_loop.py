@@ -67,14 +67,20 @@ def trial(seed):
     s.set_option("steps_per_launch", T)
     s.set_option("step_log", 1)
     s.set_option("one_shot", one_shot)
-    its = []
+    its, n_solved = [], 0
     for _ in range(launches):
         s.solve_async()
         if T > 1:
-            its.append(np.abs(s.step_log(T)[0]))
+            raw = s.step_log(T)[0]
+            its.append(np.abs(raw))
+            n_solved += int((raw > 0).sum())
         else:
-            its.append(s.status()["iter"][None, :].copy())
+            st_ = s.status()
+            its.append(st_["iter"][None, :].copy())
+            n_solved += int(st_["solved"].sum())
     its = np.concatenate(its)                                  # [steps, B]
+    stats = s.reduce_stats()
+    last = s.status()
     got = dict(x0=s.get("x0"), x=s.get("x"), u=s.get("u"))
     if one_shot != 2:
         got["vnew"] = s.get("vnew")
@@ -83,6 +89,10 @@ def trial(seed):
     path = s.kernel_path()
     s.close()
     desc = f"seed {seed} shape {(nx, nu, N)} B {B} T {T}x{launches} hetero {hetero} traj {use_traj}/{reset_duals} one_shot {one_shot} soc {cfg['en_state_soc']}{cfg['en_input_soc']} [{path}]"
+    # device-side statistics (the buffer of the RCCL all-reduce): sums over the batch / accumulated since the reset
+    if not (stats[0] == last["iter"].sum() and stats[1] == last["solved"].sum() and stats[2] == B and
+            stats[7] == its.sum() and stats[8] == n_solved):
+        return f"{desc}: reduce_stats {stats.tolist()} vs iter sum {last['iter'].sum()} / accumulated {its.sum()} / solved {n_solved}"
     # ---- oracle, one instance at a time
     steps = T * launches
     for b in range(B):
