@@ -158,3 +158,13 @@ def test_fuzz_phase_functions_vs_oracle():
     assert build_oracle()
     bad = [r for r in (fuzz_parity.phase_trial(seed) for seed in range(1, 101)) if r]
     assert not bad, bad[:5]
+
+
+def test_fuzz_api_state_machine_vs_oracle():
+    """tools/fuzz_api_sequence.py: random operation sequences on one TinyBatch (constraints, settings, field writes,
+    reset, solves, kernel-path switches) mirrored on per-instance oracles."""
+    import fuzz_api_sequence
+    from cpu_solvers import build_oracle
+    assert build_oracle()
+    bad = [r for r in (fuzz_api_sequence.trial(seed) for seed in range(1, 121)) if r]
+    assert not bad, bad[:5]
