@@ -167,3 +167,20 @@ def test_edge_max_iter_zero_and_check_termination():
 def test_oracle_matches_live_reference(maker):
     suite = maker()
     assert_outputs_match(sc.run_cases(OracleSolver, suite), sc.run_cases(RefSolver, suite), RTOL, "live")
+
+
+def test_oracle_matches_live_reference_on_the_fuzzed_space():
+    """The random configurations the GPU fuzzers draw (tools/fuzz_parity.random_suite: every switch, cones, static and
+    time-varying half-spaces, check_termination 1..4, warm states, 18 shapes) through the REAL reference (oracle/_ref)
+    and the oracle: same iteration counts, fields within 1e-9.  Build container only."""
+    import sys
+    from cpu_solvers import RefSolver, have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref is built only where /root/reference exists")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from fuzz_parity import random_suite
+    for seed in range(1, 81):
+        suite, _ = random_suite(seed)
+        if suite["config"]["check_termination"] == 0:
+            continue                                  # the reference divides by zero (admm.cpp:312)
+        assert_outputs_match(sc.run_cases(OracleSolver, suite), sc.run_cases(RefSolver, suite), RTOL, f"fuzz seed {seed}")
