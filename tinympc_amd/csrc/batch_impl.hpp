@@ -29,7 +29,7 @@ struct TinyBatch {
     const tinympc_amd::TileEntry* tile = nullptr;      // tile_kernel.hip.h instantiation for this shape, if any
     double* d_ttab = nullptr;
     std::vector<double> h_ttab;
-    bool no_tile = false;
+    bool no_tile = false, prefer_tile = false;   // prefer_tile: take the tile kernel even where a one-row instantiation exists
     // host copies of the problem family
     tinympc_amd::Mat A, B, f;
     std::vector<double> Qw, Rw;                    // work->Q, work->R (user + rho)

@@ -54,8 +54,14 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
     return acc;
 }
 
+// two waves per SIMD when the five L-long arrays + the matrix rows fit 256 VGPRs
+constexpr int tile_waves_per_simd(int nx, int nu, int n, int r) {
+    return (2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 276) ? 2 : 1;   // measured: (12,8,30) at 274 gains, (20,2,30) at 282 loses to spills
+}
+
 template <int NX, int NU, int N, int W, int R>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(tile_waves_per_simd(NX, NU, N, R), tile_waves_per_simd(NX, NU, N, R))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
     static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4), "tile shape");

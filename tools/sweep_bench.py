@@ -21,6 +21,8 @@ import tinympc_amd as tm  # noqa: E402
 def run_cell(nx, nu, N, B, reps):
     prob, rng = tm.random_problem(nx, nu, N)
     s = tm.TinyBatchSolver.from_problem(prob, B)
+    for kv in filter(None, os.environ.get("TINYMPC_OPTS", "").split(",")):       # experiments: prefer_tile=1 ...
+        s.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     s.set_bound_constraints(np.full((nx, 1), -1e17), np.full((nx, 1), 1e17), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
     s.update_settings(max_iter=500)
     x0 = rng.uniform(-1, 1, (B, nx))
