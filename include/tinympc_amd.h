@@ -178,6 +178,7 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * the examples' closed loop, examples/quadrotor_hovering.cpp:92), "debug" (1: keep q,r,p,d),
  * "grid_waves_per_cu" (persistent-grid size, 0 = one wave per tile), "dpp_mode" (2 [default] fused
  * v_fmac_f64_dpp on one accumulator chain, 0 the same on two chains, 1 v_mov_dpp + v_fma), "timing" (n: record HIP events for the next n solves),
+ * "prefer_tile" / "no_tile" (experiments: take / avoid the tile kernel where a choice exists),
  * "force_general" (1: use the coverage kernel even when a
  * register-resident instantiation exists), "steps_per_launch" (T >= 1: every solve call runs T closed-loop MPC steps -- solve, plant step
  * x0 <- A x0 + B u[:,0] + f, solve, ... -- inside ONE launch with the ADMM state held in registers;
