@@ -202,10 +202,12 @@ int tiny_batch_get_step_log(TinyBatch* b, int* iters, double* u0, int steps);
 /* kernel durations (ms) of the solves recorded since "timing" was set; returns the count */
 int tiny_batch_get_timing(TinyBatch* b, float* ms, int capacity);
 const char* tiny_batch_last_error(TinyBatch* b);
-/* registered (nx,nu,N) kernel instantiations: writes up to capacity triples, returns the count */
+/* (nx,nu,N) kernel instantiations compiled into the library: writes up to capacity triples, returns the count */
 int tiny_batch_supported_dims(int* triples, int capacity);
 /* which kernel the next solve runs: 0 one-row register-resident kernel (admm_kernel.hip.h), 1 tile kernel
- * (tile_kernel.hip.h: wide / long shapes, W x R DPP rows per instance), 2 coverage kernel (general_kernel.hip.h) */
+ * (tile_kernel.hip.h: wide / long shapes, W x R DPP rows per instance), 2 coverage kernel (general_kernel.hip.h),
+ * 3 / 4 the one-row / tile kernel instantiated at run time with hipRTC for a shape outside kernel_dims.txt / tile_dims.txt
+ * (first use costs about a second; option "no_jit" = 1 keeps such shapes on the coverage kernel) */
 int tiny_batch_kernel_path(TinyBatch* b);
 /* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
  * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */

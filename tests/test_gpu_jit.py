@@ -1,0 +1,110 @@
+"""Shapes outside kernel_dims.txt: the one-row register kernel is instantiated at run time with hipRTC (csrc/jit.hip)
+instead of falling back to the coverage kernel.  Same parity bar, same features (cone, half-spaces, fused steps,
+heterogeneous data)."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+sys.path.insert(0, HERE)
+
+import scenarios as sc  # noqa: E402
+import tinympc_amd as tm  # noqa: E402
+from cpu_solvers import OracleSolver  # noqa: E402
+from hip_runner import make_batch, run_cases_hip  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("dims", [(5, 3, 7), (9, 2, 12), (3, 1, 4), (7, 7, 5), (10, 6, 20)])
+def test_uninstantiated_shape_runs_the_register_kernel(dims):
+    suite = sc.sweep_suite(*dims, B=9, max_iter=120)
+    assert dims not in tm.supported_dims()
+    s = make_batch(suite)
+    assert s.kernel_path() == "jit"
+    s.set_option("no_jit", 1)
+    assert s.kernel_path() == "cover"
+    s.close()
+    out, ref = run_cases_hip(suite), sc.run_cases(OracleSolver, suite)
+    assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        assert rel_err(out[k], ref[k]) < RTOL, k
+    cov = run_cases_hip(suite, options={"no_jit": 1})
+    for k in ("x", "u", "vnew", "g", "v"):
+        assert rel_err(cov[k], ref[k]) < RTOL, k
+
+
+def test_jit_shape_with_cone_halfspaces_and_fused_steps():
+    nx, nu, N = 7, 4, 9
+    prob = sc.sweep_suite(nx, nu, N, B=1)["problem"]
+    rng = np.random.default_rng(5)
+    cfg = sc.default_config(prob, max_iter=40, en_state_soc=1, en_input_soc=1, u_min=-0.5, u_max=0.5,
+                            state_cone=([2], [3], [0.7]), input_cone=([1], [3], [0.5]), en_state_linear=1, en_tv_input_linear=1,
+                            linear=(rng.standard_normal((2, nx)), rng.uniform(0.2, 1.0, 2), np.zeros((0, nu)), np.zeros(0)),
+                            tv_linear=(np.zeros((0, nx)), np.zeros((0, N)), rng.standard_normal((N - 1, nu)), rng.uniform(0.1, 0.5, (1, N - 1))))
+    cases = sc.zero_cases(prob, 6)
+    for k, v in cases.items():
+        cases[k] = rng.normal(0, 0.3, v.shape)
+    suite = dict(problem=prob, config=cfg, cases=cases)
+    s = make_batch(suite)
+    assert s.kernel_path() == "jit"
+    s.close()
+    out, ref = run_cases_hip(suite), sc.run_cases(OracleSolver, suite)
+    assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "vcnew", "zcnew", "gc", "yc", "vlnew", "gl", "zlnew_tv", "yl_tv"):
+        assert rel_err(out[k], ref[k]) < RTOL, k
+    # fused closed loop == separate launches, on the run-time instantiated kernel
+    res = []
+    for T in (1, 5):
+        f = make_batch(suite)
+        f.set_x0(cases["x0"]); f.set("Xref", cases["Xref"]); f.set("Uref", cases["Uref"])
+        f.set_option("advance_x0", 1); f.set_option("steps_per_launch", T)
+        for _ in range(5 // T):
+            f.solve_async()
+        res.append({k: f.get(k) for k in ("x", "u", "vnew", "g", "zcnew", "yc", "vlnew", "x0")})
+        f.close()
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_jit_is_much_faster_than_the_coverage_kernel():
+    suite = sc.sweep_suite(5, 3, 7, B=1)
+    prob = suite["problem"]
+    B = 32768
+    rng = np.random.default_rng(1)
+    t = {}
+    for name, opt in (("jit", 0), ("cover", 1)):
+        s = tm.TinyBatchSolver.from_problem(prob, B)
+        s.set_bound_constraints(np.full((5, 1), -1e17), np.full((5, 1), 1e17), np.full((3, 1), -0.5), np.full((3, 1), 0.5))
+        s.update_settings(max_iter=50, check_termination=0)
+        s.set_option("no_jit", opt)
+        s.set_x0(rng.uniform(-1, 1, (B, 5)))
+        s.solve()                                   # includes the one-off compilation
+        s.set_option("timing", 1)
+        s.solve_async()
+        t[name] = float(s.timing_ms()[0])
+        assert s.kernel_path() == name
+        s.close()
+    print(f"(5,3,7) x {B}, 50 iterations: jit {t['jit']:.3f} ms, coverage {t['cover']:.3f} ms")
+    assert t["jit"] * 10 < t["cover"]
+
+
+@pytest.mark.parametrize("dims,path", [((16, 8, 6), "tile-jit"), ((6, 2, 60), "tile-jit"), ((20, 6, 24), "tile-jit"), ((10, 2, 40), "tile-jit")])
+def test_uninstantiated_wide_or_long_shape_runs_the_tile_kernel(dims, path):
+    suite = sc.sweep_suite(*dims, B=7, max_iter=150)
+    s = make_batch(suite)
+    assert s.kernel_path() == path
+    s.close()
+    out, ref = run_cases_hip(suite), sc.run_cases(OracleSolver, suite)
+    assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        assert rel_err(out[k], ref[k]) < RTOL, k

@@ -382,7 +382,7 @@ class TinyBatchSolver:
         return it, u0
 
     def kernel_path(self) -> str:
-        return {0: "regs", 1: "tile", 2: "cover"}[lib().tiny_batch_kernel_path(self._h)]
+        return {0: "regs", 1: "tile", 2: "cover", 3: "jit", 4: "tile-jit"}[lib().tiny_batch_kernel_path(self._h)]
 
     def algorithmic_bytes(self, cold=False) -> int:
         """cold: False / 0 bytes_warm, True / 1 bytes_cold (one_shot = 2), 2 the traffic of one_shot = 1."""

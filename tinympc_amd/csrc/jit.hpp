@@ -1,0 +1,45 @@
+// jit.hpp -- run-time instantiation of the register-resident kernel (admm_kernel.hip.h) for (nx, nu, N) shapes that
+// are not in kernel_dims.txt.  The kernel header is embedded in the library at build time (_gen/kernel_src.inc) and
+// compiled for gfx950 with hipRTC on first use (about a second per variant, cached per process); libhiprtc is
+// dlopen'ed so that the library loads without it -- then such shapes simply stay on the coverage kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+
+namespace tinympc_amd {
+
+struct JitKey {
+    int nx, nu, N, soc, dbg, mode, lin, het;
+    bool operator<(const JitKey& o) const {
+        const int a[8] = {nx, nu, N, soc, dbg, mode, lin, het}, b[8] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het};
+        for (int i = 0; i < 8; ++i)
+            if (a[i] != b[i]) return a[i] < b[i];
+        return false;
+    }
+};
+
+// Does the one-row kernel hold this shape at all (one instance per 16-lane row, N-long arrays in <= 512 registers)?
+inline bool jit_shape_fits(int nx, int nu, int N, bool soc) {
+    return nx >= 1 && nu >= 1 && nx + nu <= 16 && N >= 2 && 2 * ((soc ? 8 : 6) * N + 2 * (nx + nu) + 8) + 40 <= 512;
+}
+
+// The compiled kernel, or nullptr (reason in *err).  Thread-safe; failures are remembered.
+hipFunction_t jit_solve_kernel(const JitKey& key, std::string* err);
+
+// Tile kernel (tile_kernel.hip.h) for wide (16 < nx+nu <= 32) and / or long shapes: W rows across the knot vector, R rows
+// along the horizon.  Picks the smallest R in {1, 2, 4} with W*R in {1, 2, 4}, N % R == 0, arrays within 512 registers
+// and the per-wave bound / trajectory tables within the static LDS limit; false if there is none.
+inline bool jit_tile_shape(int nx, int nu, int N, int* W, int* R) {
+    const int nz = nx + nu;
+    if (nx < 1 || nu < 1 || nz > 32 || N < 2) return false;
+    const int w = nz > 16 ? 2 : 1;
+    for (int r = 1; r <= 4 / w; r *= 2) {
+        if (N % r) continue;
+        const long lds = 2L * N * 16 * w * 8 + (long)(N / r) * 64 * 8;
+        if (2 * (5 * (N / r) + 2 * nz) + 44 <= 512 && lds <= 60 * 1024) { *W = w; *R = r; return true; }
+    }
+    return false;
+}
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, std::string* err);
+
+}  // namespace tinympc_amd

@@ -11,9 +11,10 @@ import scenarios as sc
 import tinympc_amd as tm
 from cpu_solvers import OracleSolver, build_oracle
 
-SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30)]
+SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30),
+          (5, 3, 7), (9, 2, 12), (3, 1, 4), (7, 7, 5)]          # the last four: instantiated at run time (jit.hpp)
 # tile / coverage kernel shapes: one MPC step per launch (plant step on device), shared problem data
-SLOW_SHAPES = [(12, 8, 10), (20, 4, 10), (8, 2, 50), (5, 3, 7), (20, 2, 30), (9, 2, 12)]
+SLOW_SHAPES = [(12, 8, 10), (20, 4, 10), (8, 2, 50), (20, 2, 30), (16, 8, 6), (6, 2, 60)]
 
 
 def family(rng, nx, nu, N):
