@@ -101,8 +101,11 @@ Entry build(const std::string& name_s, const bool tile) {
 
 static hipFunction_t get(const std::string& name, const bool tile, std::string* err) {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_cache.find(name);
-    if (it == g_cache.end()) it = g_cache.emplace(name, build(name, tile)).first;
+    int dev = 0;
+    (void)hipGetDevice(&dev);                            // a module belongs to the device it was loaded on
+    const std::string key = name + "@" + std::to_string(dev);
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) it = g_cache.emplace(key, build(name, tile)).first;
     if (!it->second.fn && err) *err = it->second.err;
     return it->second.fn;
 }
