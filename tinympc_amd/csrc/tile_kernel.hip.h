@@ -12,7 +12,7 @@
 //     cross-row shuffle per phase; every element-wise phase runs on all rows at once.
 // A whole wavefront's 128 KB of registers can therefore hold ONE large instance (e.g. nx=20, nu=8, N=50:
 // W=2, R=2) or two / four smaller ones.  Same arithmetic, slot convention (input lanes keep knot i in slot i+1),
-// HBM records and parity tests as the one-row kernel; box constraints, one MPC step per launch.
+// HBM records and parity tests as the one-row kernel; box constraints, fused closed-loop MPC steps.
 #pragma once
 #include "admm_kernel.hip.h"
 
@@ -116,7 +116,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 Dn[l] = 0.0;
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
-            const double x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
+            double x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
             {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
                 double pt[NX];
 #pragma unroll
@@ -125,8 +125,12 @@ void admm_tile_kernel(const SolveArgs P) {
                 if (hrow == R - 1 && is_state) QX[L - 1] = -xp;
             }
 
-            int iter = 0, solved = 0, checked = 0, countdown = P.check_termination;
+            int iter = 0, solved = 0, checked = 0, countdown = 0;
+            unsigned acc_iter = 0, acc_solved = 0;
             double rp = 0.0, rd = 0.0;
+            const int nsteps = P.steps > 1 ? P.steps : 1;
+            for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch (as admm_kernel.hip.h)
+            iter = 0; solved = 0; countdown = P.check_termination;
             for (int it = 0; it < P.max_iter; ++it) {
                 // ---- backward_pass_grad (admm.cpp:13-20): the horizon rows take turns, last row first
                 double pcur = 0.0, qhi = 0.0;
@@ -193,6 +197,15 @@ void admm_tile_kernel(const SolveArgs P) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) VP[l] = VN[l];
             }
+            acc_iter += (unsigned)iter;
+            acc_solved += (unsigned)solved;
+            if (nsteps > 1) {
+                if (P.iter_log && sub == 0 && j16 == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
+                if (P.u0_log && hrow == 0 && is_input && iter > 0) P.u0_log[((size_t)step * P.batch + b) * NU + (jj - NX)] = sX[64 + lane];
+                // plant step x0 <- A x0 + B u_0 + f = the forward pass' x_1 (slot 1 of the first horizon row; L >= 2)
+                if (iter > 0) x0v = (hrow == 0 && is_state) ? sX[64 + lane] : 0.0;
+            }
+            }
 
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -221,8 +234,8 @@ void admm_tile_kernel(const SolveArgs P) {
                 *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(ps, pi, ds, di);
                 if (P.accum) {
                     uint2 ac = P.accum[b];
-                    ac.x += (unsigned)iter;
-                    ac.y += (unsigned)solved;
+                    ac.x += acc_iter;
+                    ac.y += acc_solved;
                     P.accum[b] = ac;
                 }
             }

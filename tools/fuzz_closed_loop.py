@@ -13,7 +13,7 @@ from cpu_solvers import OracleSolver, build_oracle
 
 SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30),
           (5, 3, 7), (9, 2, 12), (3, 1, 4), (7, 7, 5)]          # the last four: instantiated at run time (jit.hpp)
-# tile / coverage kernel shapes: one MPC step per launch (plant step on device), shared problem data
+# tile kernel shapes (compiled in or instantiated at run time), shared problem data; with cones: the coverage kernel
 SLOW_SHAPES = [(12, 8, 10), (20, 4, 10), (8, 2, 50), (20, 2, 30), (16, 8, 6), (6, 2, 60)]
 
 
@@ -31,8 +31,9 @@ def trial(seed):
     B = int(rng.integers(1, 10))
     hetero = (not slow) and rng.random() < 0.3
     fams = [family(rng, nx, nu, N) for _ in range(B if hetero else 1)]
-    T = 1 if slow else int(rng.integers(1, 9))
-    launches = int(rng.integers(1, 4)) * (3 if slow else 1)
+    slow_cones = slow and rng.random() < 0.3           # cones on a wide / long shape: coverage kernel, one step per launch
+    T = 1 if slow_cones else int(rng.integers(1, 9))
+    launches = int(rng.integers(1, 4)) * (3 if slow_cones else 1)
     use_traj = (not slow) and rng.random() < 0.4
     reset_duals = bool(use_traj and rng.random() < 0.5)
     one_shot = 0 if (slow or use_traj or rng.random() < 0.7) else int(rng.integers(1, 3))
@@ -40,7 +41,7 @@ def trial(seed):
               abs_pri_tol=float(10 ** rng.uniform(-4, -1)), abs_dua_tol=float(10 ** rng.uniform(-4, -1)),
               x_min=rng.uniform(-3.0, -0.5, (nx, N)), x_max=rng.uniform(0.5, 3.0, (nx, N)),
               u_min=rng.uniform(-1.0, -0.1, (nu, N - 1)), u_max=rng.uniform(0.1, 1.0, (nu, N - 1)))
-    if nx >= 3 and nu >= 3 and rng.random() < 0.4:
+    if nx >= 3 and nu >= 3 and (slow_cones or (not slow and rng.random() < 0.4)):
         kw.update(en_state_soc=int(rng.integers(0, 2)), en_input_soc=1,
                   state_cone=([int(rng.integers(0, nx - 2))], [3], [float(rng.uniform(0.3, 1.2))]),
                   input_cone=([int(rng.integers(0, nu - 2))], [3], [float(rng.uniform(0.3, 1.2))]))
