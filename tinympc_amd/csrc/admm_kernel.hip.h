@@ -487,7 +487,9 @@ void admm_solve_kernel(const SolveArgs P) {
                         qhi = t;
                         if constexpr (DBG) {
                             double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
-                            if constexpr (SOC) ql = fma(-rho, VC[N - 1] - GC[N - 1], ql);
+                            if constexpr (SOC) ql = fma(-rho, VC[N - 1] - GC[N - 1], ql);   // :269
+                            if constexpr (LS) ql = fma(-rho, VL[N - 1] - GL[N - 1], ql);    // :272
+                            if constexpr (LT) ql = fma(-rho, VT[N - 1] - GT[N - 1], ql);    // :275
                             Qd[N - 1] = is_state ? ql : t;
                             Pd[N - 1] = t;
                         }

@@ -134,10 +134,14 @@ def linear_example(B=65536, tv=False):
             s.update_settings(max_iter=100, en_state_bound=0, en_input_bound=0, en_state_linear=1, en_input_linear=1)
         s.set_option("force_general", force)
         s.set_x_ref(Xref[:Bk])
-        s.set_x0(x0[:Bk])
-        s.set_option("timing", 1)
-        s.solve_async()
-        ms = float(s.timing_ms()[0])
+        ms = None
+        for _ in range(2):                       # the first launch of a kernel also loads its code object
+            s.reset()
+            s.set_x0(x0[:Bk])
+            s.set_option("timing", 1)
+            s.solve_async()
+            t_ = float(s.timing_ms()[0])
+            ms = t_ if ms is None else min(ms, t_)
         st = s.reduce_stats()
         out[name] = dict(kernel=s.kernel_path(), batch=Bk, kernel_ms=ms, solves_per_s=Bk / (ms * 1e-3),
                          admm_iters_per_s=st[0] / (ms * 1e-3), iters_per_solve=st[0] / Bk)

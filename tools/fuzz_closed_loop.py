@@ -45,6 +45,16 @@ def trial(seed):
         kw.update(en_state_soc=int(rng.integers(0, 2)), en_input_soc=1,
                   state_cone=([int(rng.integers(0, nx - 2))], [3], [float(rng.uniform(0.3, 1.2))]),
                   input_cone=([int(rng.integers(0, nu - 2))], [3], [float(rng.uniform(0.3, 1.2))]))
+    if not slow and rng.random() < 0.3:                 # static half-spaces (register-resident LIN variants, also with hetero)
+        ns, ni = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+        kw.update(en_state_linear=int(rng.integers(0, 2)), en_input_linear=1,
+                  linear=(rng.standard_normal((ns, nx)), rng.uniform(0.2, 1.0, ns), rng.standard_normal((ni, nu)), rng.uniform(0.1, 0.5, ni)))
+    if not slow and rng.random() < 0.2:
+        ns, ni = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        kw.update(en_tv_state_linear=1, en_tv_input_linear=int(rng.integers(0, 2)),
+                  tv_linear=(rng.standard_normal((ns * N, nx)), rng.uniform(0.2, 1.0, (ns, N)),
+                             rng.standard_normal((ni * (N - 1), nu)), rng.uniform(0.1, 0.5, (ni, N - 1))))
+    debug = (not slow) and rng.random() < 0.25
     cfg = sc.default_config(fams[0], **kw)
     x0 = rng.uniform(-0.5, 0.5, (B, nx))
     Xref = rng.normal(0, 0.2, (B, nx, N))
@@ -60,7 +70,13 @@ def trial(seed):
     s.set_bound_constraints(cfg["x_min"], cfg["x_max"], cfg["u_min"], cfg["u_max"])
     if cfg["state_cone"] is not None:
         s.set_cone_constraints(*cfg["state_cone"], *cfg["input_cone"])
-    s.update_settings(cfg["abs_pri_tol"], cfg["abs_dua_tol"], cfg["max_iter"], cfg["check_termination"], 1, 1, cfg["en_state_soc"], cfg["en_input_soc"])
+    if cfg["linear"] is not None:
+        s.set_linear_constraints(*cfg["linear"])
+    if cfg["tv_linear"] is not None:
+        s.set_tv_linear_constraints(*cfg["tv_linear"])
+    s.update_settings(cfg["abs_pri_tol"], cfg["abs_dua_tol"], cfg["max_iter"], cfg["check_termination"], 1, 1, cfg["en_state_soc"], cfg["en_input_soc"],
+                      cfg["en_state_linear"], cfg["en_input_linear"], cfg["en_tv_state_linear"], cfg["en_tv_input_linear"])
+    s.set_option("debug", int(debug))
     s.set_x0(x0); s.set_x_ref(Xref); s.set_u_ref(Uref)
     if use_traj:
         s.set_reference_trajectory(traj, offs)
@@ -88,9 +104,11 @@ def trial(seed):
         got["vnew"] = s.get("vnew")
     if one_shot == 0:
         got.update(g=s.get("g"), v=s.get("v"))
+    if debug and one_shot == 0:
+        got.update(q=s.get("q"), r=s.get("r"), p=s.get("p"), d=s.get("d"))
     path = s.kernel_path()
     s.close()
-    desc = f"seed {seed} shape {(nx, nu, N)} B {B} T {T}x{launches} hetero {hetero} traj {use_traj}/{reset_duals} one_shot {one_shot} soc {cfg['en_state_soc']}{cfg['en_input_soc']} [{path}]"
+    desc = f"seed {seed} shape {(nx, nu, N)} B {B} T {T}x{launches} hetero {hetero} traj {use_traj}/{reset_duals} one_shot {one_shot} lin {cfg['en_state_linear']}{cfg['en_input_linear']}{cfg['en_tv_state_linear']}{cfg['en_tv_input_linear']} dbg {int(debug)} soc {cfg['en_state_soc']}{cfg['en_input_soc']} [{path}]"
     # device-side statistics (the buffer of the RCCL all-reduce): sums over the batch / accumulated since the reset
     if not (stats[0] == last["iter"].sum() and stats[1] == last["solved"].sum() and stats[2] == B and
             stats[7] == its.sum() and stats[8] == n_solved):
@@ -104,7 +122,8 @@ def trial(seed):
         xb = x0[b].copy()
         for k in range(steps):
             if one_shot and k % T == 0:                         # every launch starts from the cold state
-                for fld in ("vnew", "znew", "g", "y", "v", "z", "x", "u", "vcnew", "zcnew", "gc", "yc"):
+                for fld in ("vnew", "znew", "g", "y", "v", "z", "x", "u", "vcnew", "zcnew", "gc", "yc", "vlnew", "zlnew", "gl", "yl",
+                            "vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv"):
                     o[fld] = np.zeros_like(o[fld])
             if use_traj:
                 idx = np.minimum(np.arange(N) + k + offs[b], n_pts - 1)
@@ -118,7 +137,7 @@ def trial(seed):
                 o.close()
                 return f"{desc}: instance {b} step {k}: iterations {int(its[k, b])} vs oracle {oit}"
             xb = fam["A"] @ xb + fam["B"] @ o["u"][:, 0] + fam["f"]
-        ref = dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"])
+        ref = dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"], q=o["q"], r=o["r"], p=o["p"], d=o["d"])
         for k, v in got.items():
             e = float(np.max(np.abs(v[b] - ref[k])) / max(np.max(np.abs(ref[k])), 1e-300))
             if e > 1e-7:                                       # differences compound through the plant over the steps
