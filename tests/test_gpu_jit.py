@@ -108,3 +108,25 @@ def test_uninstantiated_wide_or_long_shape_runs_the_tile_kernel(dims, path):
     assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
     for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
         assert rel_err(out[k], ref[k]) < RTOL, k
+
+
+def test_up_to_eight_halfspaces_stay_register_resident():
+    """4 half-spaces per knot and family are compiled in; 5..8 get the KMAX = 8 variant at run time; 9 go to the coverage
+    kernel.  Same results either way."""
+    prob, _ = sc.load_problem("quadrotor_20hz")
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(12)
+    for ns, want in ((4, "regs"), (7, "regs"), (9, "cover")):
+        cfg = sc.default_config(prob, max_iter=30, en_state_linear=1, en_input_linear=1, u_min=-0.5, u_max=0.5,
+                                linear=(rng.standard_normal((ns, nx)), rng.uniform(0.3, 1.0, ns), rng.standard_normal((2, nu)), rng.uniform(0.2, 0.6, 2)))
+        cases = sc.zero_cases(prob, 5)
+        for k in ("x0", "Xref", "Uref"):
+            cases[k] = rng.normal(0, 0.3, cases[k].shape)
+        suite = dict(problem=prob, config=cfg, cases=cases)
+        s = make_batch(suite)
+        assert s.kernel_path() == want, (ns, s.kernel_path())
+        s.close()
+        out, ref = run_cases_hip(suite), sc.run_cases(OracleSolver, suite)
+        assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int)), ns
+        for k in ("x", "u", "vnew", "vlnew", "zlnew", "gl", "yl"):
+            assert rel_err(out[k], ref[k]) < RTOL, (ns, k)

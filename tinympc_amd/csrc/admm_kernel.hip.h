@@ -64,10 +64,10 @@ enum : int {
 // [constraint k < LIN_KMAX][16 lanes]: the coefficient of this lane's row (state lanes: Alin_x[k][j], input lanes:
 // Alin_u[k][j-nx]), the offset b_k and ||a_k||^2 of this lane's family (b = +inf where there is no constraint k).
 // The time-varying tables carry one such block per slot (input lanes shifted by one knot, like the bounds).
-enum : int { LIN_KMAX = 4 };
+enum : int { LIN_KMAX = 4, LIN_KMAX_BIG = 8 };       // half-spaces per knot and family: compiled-in variants / run-time instantiated ones
 static inline int tab_lin_offset(int N) { return TAB_BOUNDS + 2 * N * 16; }
-static inline int tab_tlin_offset(int N) { return tab_lin_offset(N) + 3 * LIN_KMAX * 16; }
-static inline int tab_doubles(int N) { return tab_tlin_offset(N) + 3 * N * LIN_KMAX * 16; }
+static inline int tab_tlin_offset(int N, int kmax = LIN_KMAX) { return tab_lin_offset(N) + 3 * kmax * 16; }
+static inline int tab_doubles(int N, int kmax = LIN_KMAX) { return tab_tlin_offset(N, kmax) + 3 * N * kmax * 16; }
 
 struct SolveArgs {
     const double* tab;        // tab_doubles(N) doubles
@@ -305,7 +305,7 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
 
 // LIN: bit 0 = static half-spaces (admm.cpp:137-173), bit 1 = time-varying ones (:176-211); 0 = neither
 // HET: per-instance problem data (riccati_kernel.hip.h): the matrix rows are re-loaded for every instance
-template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false>
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(LIN ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC), LIN ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC))))
 void admm_solve_kernel(const SolveArgs P) {
@@ -322,10 +322,10 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sPt[NX * 16];
     __shared__ double sLo[N * 16];
     __shared__ double sHi[N * 16];
-    __shared__ double sLin[LS ? 3 * LIN_KMAX * 16 : 1];
-    __shared__ double sTLin[LT ? 3 * N * LIN_KMAX * 16 : 1];
-    if constexpr (LS) for (int e = lane; e < 3 * LIN_KMAX * 16; e += 64) sLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + e];
-    if constexpr (LT) for (int e = lane; e < 3 * N * LIN_KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * LIN_KMAX * 16 + e];
+    __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
+    __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
+    if constexpr (LS) for (int e = lane; e < 3 * KMAX * 16; e += 64) sLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + e];
+    if constexpr (LT) for (int e = lane; e < 3 * N * KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * KMAX * 16 + e];
     for (int e = lane; e < NX * 16; e += 64) sPt[e] = P.tab[TAB_PT + e];
     for (int e = lane; e < N * 16; e += 64) {
         sLo[e] = P.tab[TAB_BOUNDS + e];
@@ -541,8 +541,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         auto halfspaces = [&](double z, const double* tabk, const int nk) {
                             for (int k = 0; k < nk; ++k) {
                                 const double a = tabk[k * 16 + j];
-                                const double bk = tabk[LIN_KMAX * 16 + k * 16 + j];
-                                const double nn = tabk[2 * LIN_KMAX * 16 + k * 16 + j];
+                                const double bk = tabk[KMAX * 16 + k * 16 + j];
+                                const double nn = tabk[2 * KMAX * 16 + k * 16 + j];
                                 const double prod = a * z;
                                 double cs = 0.0, ci = 0.0;
                                 ring1<0, NX>(cs, prod, ones);
@@ -562,7 +562,7 @@ void admm_solve_kernel(const SolveArgs P) {
                         if constexpr (LT) {
                             const bool on = tlin_lane && (is_state || s >= 1);
                             double vt = on ? (xi + GT[s]) : 0.0;                    // :177 / :182
-                            vt = halfspaces(vt, sTLin + s * 3 * LIN_KMAX * 16, P.n_tlin);
+                            vt = halfspaces(vt, sTLin + s * 3 * KMAX * 16, P.n_tlin);
                             GT[s] = on ? ((GT[s] + xi) - vt) : 0.0;                 // :249 / :254
                             VT[s] = on ? vt : 0.0;
                         }

@@ -112,8 +112,8 @@ static hipFunction_t get(const std::string& name, const bool tile, std::string* 
 
 hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
     char name[256];
-    snprintf(name, sizeof(name), "tinympc_amd::admm_solve_kernel<%d, %d, %d, %s, %s, %d, %d, %s>", k.nx, k.nu, k.N,
-             k.soc ? "true" : "false", k.dbg ? "true" : "false", k.mode, k.lin, k.het ? "true" : "false");
+    snprintf(name, sizeof(name), "tinympc_amd::admm_solve_kernel<%d, %d, %d, %s, %s, %d, %d, %s, %d>", k.nx, k.nu, k.N,
+             k.soc ? "true" : "false", k.dbg ? "true" : "false", k.mode, k.lin, k.het ? "true" : "false", k.kmax);
     return get(name, false, err);
 }
 

@@ -9,10 +9,10 @@
 namespace tinympc_amd {
 
 struct JitKey {
-    int nx, nu, N, soc, dbg, mode, lin, het;
+    int nx, nu, N, soc, dbg, mode, lin, het, kmax;
     bool operator<(const JitKey& o) const {
-        const int a[8] = {nx, nu, N, soc, dbg, mode, lin, het}, b[8] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het};
-        for (int i = 0; i < 8; ++i)
+        const int a[9] = {nx, nu, N, soc, dbg, mode, lin, het, kmax}, b[9] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het, o.kmax};
+        for (int i = 0; i < 9; ++i)
             if (a[i] != b[i]) return a[i] < b[i];
         return false;
     }

@@ -36,11 +36,11 @@ def random_suite(seed):
                   state_cone=([int(rng.integers(0, nx - 2))], [3], [float(rng.uniform(0.2, 1.5))]),
                   input_cone=([int(rng.integers(0, nu - 2))], [3], [float(rng.uniform(0.2, 1.5))]) if nu >= 3 else ([], [], []))
     if rng.random() < 0.35:
-        ns, ni = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+        ns, ni = int(rng.integers(0, 10)), int(rng.integers(0, 7))      # <= 4: compiled-in LIN variants, <= 8: run-time ones, more: coverage
         kw.update(en_state_linear=int(rng.integers(0, 2)), en_input_linear=int(rng.integers(0, 2)),
                   linear=(rng.standard_normal((ns, nx)), rng.uniform(0.1, 1.0, ns), rng.standard_normal((ni, nu)), rng.uniform(0.05, 0.5, ni)))
     if rng.random() < 0.3:
-        ns, ni = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        ns, ni = int(rng.integers(0, 7)), int(rng.integers(0, 4))
         kw.update(en_tv_state_linear=int(rng.integers(0, 2)), en_tv_input_linear=int(rng.integers(0, 2)),
                   tv_linear=(rng.standard_normal((ns * N, nx)), rng.uniform(0.1, 1.0, (ns, N)),
                              rng.standard_normal((ni * (N - 1), nu)), rng.uniform(0.05, 0.5, (ni, N - 1))))
