@@ -140,7 +140,7 @@ def trial(seed):
         ref = dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"], q=o["q"], r=o["r"], p=o["p"], d=o["d"])
         for k, v in got.items():
             e = float(np.max(np.abs(v[b] - ref[k])) / max(np.max(np.abs(ref[k])), 1e-300))
-            if e > 1e-7:                                       # differences compound through the plant over the steps
+            if e > 1e-6:                                       # per-solve differences (1e-13) compound through the plant and the float-truncated cone
                 o.close()
                 return f"{desc}: instance {b}: {k} off by {e:.2e}"
         o.close()
