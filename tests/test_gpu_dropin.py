@@ -54,3 +54,14 @@ def test_phase_functions_called_with_real_eigen_types():
             na, nb = na[:-1], nb[:-1]                     # the trailing residual is rounding noise in both
         scale = max([abs(v) for v in nb] + [1e-300])
         assert max([abs(x - y) for x, y in zip(na, nb)] + [0.0]) <= 1e-9 * scale, (a[:100], b[:100])
+
+
+def test_plain_c_example_of_the_batched_abi():
+    """examples/batched_double_integrator.c (C99, built by __graft_entry__.build()): 4 096 double integrators, 60 fused
+    closed-loop MPC steps; every instance ends at the origin."""
+    exe = os.path.join(ROOT, "examples", "_build", "batched_double_integrator")
+    if not os.path.exists(exe):
+        pytest.skip("examples/_build is produced by __graft_entry__.build()")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.stdout, p.stderr[-500:])
+    assert "4096 instances x 60 MPC steps" in p.stdout and "kernel path 0" in p.stdout
