@@ -130,3 +130,29 @@ def test_up_to_eight_halfspaces_stay_register_resident():
         assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int)), ns
         for k in ("x", "u", "vnew", "vlnew", "zlnew", "gl", "yl"):
             assert rel_err(out[k], ref[k]) < RTOL, (ns, k)
+
+
+@pytest.mark.parametrize("dims,cone_rows,path", [((20, 4, 10), 3, "tile"), ((16, 8, 6), 15, "tile-jit"), ((8, 3, 50), 2, "tile")])
+def test_cones_on_wide_and_long_shapes_run_the_tile_kernel(dims, cone_rows, path):
+    """The tile kernel's cone variant (run-time instantiated only): a state cone starting at row `cone_rows` (for
+    (16,8,6) it straddles the two 16-lane rows of the tile: rows 15, 16, 17) and an input cone."""
+    nx, nu, N = dims
+    prob = sc.sweep_suite(*dims, B=1)["problem"]
+    rng = np.random.default_rng(21)
+    cfg = sc.default_config(prob, max_iter=60, en_state_soc=1, en_input_soc=1, u_min=-0.5, u_max=0.5,
+                            state_cone=([cone_rows if cone_rows + 3 <= nx else 0], [3], [0.6]), input_cone=([0], [3], [0.8]))
+    cases = sc.zero_cases(prob, 6)
+    for k, v in cases.items():
+        cases[k] = rng.normal(0, 0.3, v.shape)
+    suite = dict(problem=prob, config=cfg, cases=cases)
+    s = make_batch(suite)
+    got = s.kernel_path()
+    s.close()
+    if dims == (8, 3, 50):
+        assert got in ("tile", "tile-jit")
+    else:
+        assert got == path
+    out, ref = run_cases_hip(suite), sc.run_cases(OracleSolver, suite)
+    assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "vcnew", "zcnew", "gc", "yc"):
+        assert rel_err(out[k], ref[k]) < RTOL, k

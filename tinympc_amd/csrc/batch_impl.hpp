@@ -31,7 +31,7 @@ struct TinyBatch {
     double* d_ttab = nullptr;
     std::vector<double> h_ttab;
     tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
-    bool tile_is_jit = false;
+    bool tile_is_jit = false, tile_soc_failed = false;
     bool no_jit = false, jit_failed = false, variant_jit_failed = false;     // run-time instantiation of the one-row kernel for shapes outside kernel_dims.txt (jit.hpp)
     bool no_tile = false, prefer_tile = false;   // prefer_tile: take the tile kernel even where a one-row instantiation exists
     // host copies of the problem family

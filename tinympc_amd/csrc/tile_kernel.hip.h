@@ -59,9 +59,11 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r) {
     return (2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 276) ? 2 : 1;   // measured: (12,8,30) at 274 gains, (20,2,30) at 282 loses to spills
 }
 
-template <int NX, int NU, int N, int W, int R>
+// SOC: second-order-cone slacks (admm.cpp:102-135, 228-235) -- two more L-long arrays; this variant is never compiled in,
+// it is instantiated at run time (jit.hpp) when a wide / long shape has a cone switched on.
+template <int NX, int NU, int N, int W, int R, bool SOC = false>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(tile_waves_per_simd(NX, NU, N, R), tile_waves_per_simd(NX, NU, N, R))))
+__attribute__((amdgpu_waves_per_eu(SOC ? 1 : tile_waves_per_simd(NX, NU, N, R), SOC ? 1 : tile_waves_per_simd(NX, NU, N, R))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
     static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4), "tile shape");
@@ -90,6 +92,19 @@ void admm_tile_kernel(const SolveArgs P) {
     const double qr = P.tab[T::VEC + VEC_QR * LW + jj];
     const double smask = P.tab[T::VEC + VEC_SMASK * LW + jj];
     const double nim = P.tab[T::VEC + VEC_NIM * LW + jj];
+    double socmask = 0.0, cone_mu_d = 0.0;
+    int cone_base = -1;
+    if constexpr (SOC) {
+        socmask = P.tab[T::VEC + VEC_SOCFLAG * LW + jj];               // 1.0 on the rows of a family whose cone slack is on
+        cone_base = (int)P.tab[T::VEC + VEC_CONE_BASE * LW + jj];      // first ROW of this row's cone, or -1
+        cone_mu_d = P.tab[T::VEC + VEC_CONE_MU * LW + jj];
+    }
+    const bool soc_lane = socmask != 0.0, proj_lane = soc_lane && cone_base >= 0;
+    const int cone_c = proj_lane ? jj - cone_base : 0;
+    const float cone_mu = (float)cone_mu_d;                            // admm.cpp:39 takes mu as float
+    // lane that holds knot-vector row r of THIS instance and horizon row (the cone may straddle the two W rows)
+    const int group_lane0 = ((lane >> 4) - wrow) * 16;
+    auto lane_of_row = [&](const int r) { return group_lane0 + (r >> 4) * 16 + (r & 15); };
     const double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -102,6 +117,7 @@ void admm_tile_kernel(const SolveArgs P) {
         if (b < P.batch) {
             const int g0 = hrow * L;                                   // first global slot of this row
             double G[L], VN[L], VP[L], QX[L], Dn[L];
+            double VC[SOC ? L : 1], GC[SOC ? L : 1];
             double ref_last = 0.0;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -114,6 +130,10 @@ void admm_tile_kernel(const SolveArgs P) {
                 VP[l] = valid ? P.slack_prev[off] : 0.0;
                 QX[l] = -(r * qr);
                 Dn[l] = 0.0;
+                if constexpr (SOC) {
+                    VC[l] = (valid && soc_lane) ? P.prim[off] : 0.0;                    // vcnew = x, zcnew = u (admm.cpp:352-357)
+                    GC[l] = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                }
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
             double x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
@@ -131,6 +151,13 @@ void admm_tile_kernel(const SolveArgs P) {
             const int nsteps = P.steps > 1 ? P.steps : 1;
             for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch (as admm_kernel.hip.h)
             iter = 0; solved = 0; countdown = P.check_termination;
+            if constexpr (SOC) {
+                if (step > 0) {                                        // vcnew = x, zcnew = u of the previous solve
+#pragma unroll
+                    for (int l = 0; l < L; ++l) VC[l] = soc_lane ? sX[l * 64 + lane] : 0.0;
+                }
+                if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
+            }
             for (int it = 0; it < P.max_iter; ++it) {
                 // ---- backward_pass_grad (admm.cpp:13-20): the horizon rows take turns, last row first
                 double pcur = 0.0, qhi = 0.0;
@@ -143,7 +170,8 @@ void admm_tile_kernel(const SolveArgs P) {
                     if (hrow == ph) {
 #pragma unroll
                         for (int l = L - 1; l >= 0; --l) {
-                            const double qlo = fma(-rho, VN[l] - G[l], QX[l]);          // admm.cpp:267 | :280 | :293
+                            double qlo = fma(-rho, VN[l] - G[l], QX[l]);                // admm.cpp:267 | :280 | :293
+                            if constexpr (SOC) qlo = fma(-rho, VC[l] - GC[l], qlo);     // :269 | :282 | :295
                             if (ph == R - 1 && l == L - 1) {
                                 pcur = qlo;                                             // p_{N-1}
                             } else {
@@ -179,6 +207,16 @@ void admm_tile_kernel(const SolveArgs P) {
                             dmax = fmax(dmax, fabs(VP[l] - vn));
                             G[l] = tt - vn;
                             VN[l] = vn;
+                            if constexpr (SOC) {
+                                const double tc = fma(xi, socmask, GC[l]);              // x + gc on the cone-slack rows, else 0
+                                const int base = proj_lane ? cone_base : jj;
+                                const double s0 = __shfl(tc, lane_of_row(base)), s1 = __shfl(tc, lane_of_row(base + 1)),
+                                             s2 = __shfl(tc, lane_of_row(base + 2));
+                                double vc = tc;
+                                if (proj_lane && (is_state || g >= 1)) vc = soc_component(s0, s1, s2, tc, cone_c, cone_mu);   // :112-135
+                                GC[l] = tc - vc;                                        // :229 / :234
+                                VC[l] = vc;
+                            }
                         }
                     }
                 }
@@ -219,6 +257,7 @@ void admm_tile_kernel(const SolveArgs P) {
                     P.slack[off] = VN[l];
                     P.dual[off] = G[l];
                     P.slack_prev[off] = VP[l];
+                    if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
                 }
             }
             if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = sX[64 + lane];

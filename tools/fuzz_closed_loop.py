@@ -13,7 +13,7 @@ from cpu_solvers import OracleSolver, build_oracle
 
 SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (8, 4, 30), (4, 2, 30),
           (5, 3, 7), (9, 2, 12), (3, 1, 4), (7, 7, 5)]          # the last four: instantiated at run time (jit.hpp)
-# tile kernel shapes (compiled in or instantiated at run time), shared problem data; with cones: the coverage kernel
+# tile kernel shapes (compiled in or instantiated at run time), shared problem data
 SLOW_SHAPES = [(12, 8, 10), (20, 4, 10), (8, 2, 50), (20, 2, 30), (16, 8, 6), (6, 2, 60)]
 
 
@@ -31,9 +31,9 @@ def trial(seed):
     B = int(rng.integers(1, 10))
     hetero = (not slow) and rng.random() < 0.3
     fams = [family(rng, nx, nu, N) for _ in range(B if hetero else 1)]
-    slow_cones = slow and rng.random() < 0.3           # cones on a wide / long shape: coverage kernel, one step per launch
-    T = 1 if slow_cones else int(rng.integers(1, 9))
-    launches = int(rng.integers(1, 4)) * (3 if slow_cones else 1)
+    slow_cones = slow and rng.random() < 0.4           # cones on a wide / long shape: the tile kernel's SOC variant
+    T = int(rng.integers(1, 9))
+    launches = int(rng.integers(1, 4))
     use_traj = (not slow) and rng.random() < 0.4
     reset_duals = bool(use_traj and rng.random() < 0.5)
     one_shot = 0 if (slow or use_traj or rng.random() < 0.7) else int(rng.integers(1, 3))
