@@ -156,3 +156,30 @@ def test_cones_on_wide_and_long_shapes_run_the_tile_kernel(dims, cone_rows, path
     assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
     for k in ("x", "u", "vnew", "znew", "g", "y", "vcnew", "zcnew", "gc", "yc"):
         assert rel_err(out[k], ref[k]) < RTOL, k
+
+
+@pytest.mark.parametrize("dims", [(20, 4, 10), (16, 8, 6), (8, 2, 50)])
+def test_halfspaces_and_cones_on_wide_and_long_shapes_run_the_tile_kernel(dims):
+    """Static + time-varying half-spaces (and a cone) on tile shapes: the tile kernel's LIN x SOC variants, run-time
+    instantiated; 6 static state half-spaces exercise the KMAX = 8 tables."""
+    nx, nu, N = dims
+    prob = sc.sweep_suite(*dims, B=1)["problem"]
+    rng = np.random.default_rng(33)
+    tv_ok = N <= 20                                              # the per-knot table must fit the wave's LDS
+    ns = 4 if dims == (20, 4, 10) else 6                         # (20,4,10): KMAX = 8 per-knot tables of a 32-lane tile exceed it
+    cfg = sc.default_config(prob, max_iter=40, en_state_soc=1, u_min=-0.5, u_max=0.5, state_cone=([1], [3], [0.6]), input_cone=([], [], []),
+                            en_state_linear=1, en_input_linear=1, en_tv_state_linear=int(tv_ok), en_tv_input_linear=int(tv_ok),
+                            linear=(rng.standard_normal((ns, nx)), rng.uniform(0.3, 1.0, ns), rng.standard_normal((2, nu)), rng.uniform(0.2, 0.6, 2)),
+                            tv_linear=(rng.standard_normal((2 * N, nx)), rng.uniform(0.3, 1.0, (2, N)), rng.standard_normal((N - 1, nu)), rng.uniform(0.2, 0.6, (1, N - 1))))
+    cases = sc.zero_cases(prob, 5)
+    for k, v in cases.items():
+        cases[k] = rng.normal(0, 0.3, v.shape)
+    suite = dict(problem=prob, config=cfg, cases=cases)
+    s = make_batch(suite)
+    assert s.kernel_path() in ("tile", "tile-jit"), s.kernel_path()
+    s.close()
+    out, ref = run_cases_hip(suite), sc.run_cases(OracleSolver, suite)
+    assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    fields = ["x", "u", "vnew", "znew", "g", "y", "vcnew", "gc", "vlnew", "zlnew", "gl", "yl"] + (["vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv"] if tv_ok else [])
+    for k in fields:
+        assert rel_err(out[k], ref[k]) < RTOL, k

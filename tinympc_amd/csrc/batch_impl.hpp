@@ -29,6 +29,7 @@ struct TinyBatch {
     const tinympc_amd::KernelEntry* kernel = nullptr;
     const tinympc_amd::TileEntry* tile = nullptr;      // tile_kernel.hip.h instantiation for this shape, if any
     double* d_ttab = nullptr;
+    size_t ttab_doubles = 0;
     std::vector<double> h_ttab;
     tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
     bool tile_is_jit = false, tile_soc_failed = false;

@@ -117,9 +117,9 @@ hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
     return get(name, false, err);
 }
 
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, std::string* err) {
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, int lin, int kmax, std::string* err) {
     char name[256];
-    snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %s>", nx, nu, N, W, R, soc ? "true" : "false");
+    snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", nx, nu, N, W, R, soc ? "true" : "false", lin, kmax);
     return get(name, true, err);
 }
 

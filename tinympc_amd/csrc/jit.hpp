@@ -40,6 +40,6 @@ inline bool jit_tile_shape(int nx, int nu, int N, int* W, int* R) {
     }
     return false;
 }
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, std::string* err);
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, int lin, int kmax, std::string* err);
 
 }  // namespace tinympc_amd

@@ -23,7 +23,10 @@ template <int W>
 struct TileTab {
     static constexpr int LW = 16 * W;
     static constexpr int MB = 0, MF1 = 32 * LW, MF2 = 64 * LW, PT = 96 * LW, VEC = 128 * LW, BOUNDS = 128 * LW + 16 * LW;
-    static int doubles(int N) { return BOUNDS + 2 * N * LW; }
+    // half-space tables of the LIN variants behind the bounds: static [3][kmax][LW], then per slot [N][3][kmax][LW]
+    static constexpr int lin_offset(int N) { return BOUNDS + 2 * N * LW; }
+    static constexpr int tlin_offset(int N, int kmax) { return lin_offset(N) + 3 * kmax * LW; }
+    static constexpr int doubles(int N, int kmax = LIN_KMAX) { return tlin_offset(N, kmax) + 3 * N * kmax * LW; }
 };
 
 // (a, b) = (values of the even DPP row, values of the odd DPP row) of each 32-lane half, visible in both rows
@@ -61,10 +64,13 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r) {
 
 // SOC: second-order-cone slacks (admm.cpp:102-135, 228-235) -- two more L-long arrays; this variant is never compiled in,
 // it is instantiated at run time (jit.hpp) when a wide / long shape has a cone switched on.
-template <int NX, int NU, int N, int W, int R, bool SOC = false>
+// LIN (bit 0 static, bit 1 time-varying half-spaces, admm.cpp:137-211) / KMAX as in admm_kernel.hip.h: two more L-long
+// arrays per family; a'z is the lane-local product summed over the tile's rows by the same FMA chain against ones.
+template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(SOC ? 1 : tile_waves_per_simd(NX, NU, N, R), SOC ? 1 : tile_waves_per_simd(NX, NU, N, R))))
+__attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R))))
 void admm_tile_kernel(const SolveArgs P) {
+    constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
     static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4), "tile shape");
     using T = TileTab<W>;
@@ -80,6 +86,10 @@ void admm_tile_kernel(const SolveArgs P) {
         sLo[e] = P.tab[T::BOUNDS + e];
         sHi[e] = P.tab[T::BOUNDS + N * LW + e];
     }
+    __shared__ double sLin[LS ? 3 * KMAX * LW : 1];
+    __shared__ double sTLin[LT ? 3 * N * KMAX * LW : 1];
+    if constexpr (LS) for (int e = lane; e < 3 * KMAX * LW; e += 64) sLin[e] = P.tab[T::lin_offset(N) + e];
+    if constexpr (LT) for (int e = lane; e < 3 * N * KMAX * LW; e += 64) sTLin[e] = P.tab[T::tlin_offset(N, KMAX) + e];
     double mb[NZ], mf1[NX], mf2[NU];
 #pragma unroll
     for (int k = 0; k < NZ; ++k) mb[k] = P.tab[T::MB + k * LW + jj];
@@ -99,6 +109,12 @@ void admm_tile_kernel(const SolveArgs P) {
         cone_base = (int)P.tab[T::VEC + VEC_CONE_BASE * LW + jj];      // first ROW of this row's cone, or -1
         cone_mu_d = P.tab[T::VEC + VEC_CONE_MU * LW + jj];
     }
+    bool lin_lane = false, tlin_lane = false;
+    if constexpr (LS) lin_lane = P.tab[T::VEC + VEC_LINFLAG * LW + jj] != 0.0;
+    if constexpr (LT) tlin_lane = P.tab[T::VEC + VEC_TLINFLAG * LW + jj] != 0.0;
+    double ones[LIN ? NZ : 1];
+#pragma unroll
+    for (int k = 0; k < (LIN ? NZ : 1); ++k) ones[k] = 1.0;
     const bool soc_lane = socmask != 0.0, proj_lane = soc_lane && cone_base >= 0;
     const int cone_c = proj_lane ? jj - cone_base : 0;
     const float cone_mu = (float)cone_mu_d;                            // admm.cpp:39 takes mu as float
@@ -118,6 +134,7 @@ void admm_tile_kernel(const SolveArgs P) {
             const int g0 = hrow * L;                                   // first global slot of this row
             double G[L], VN[L], VP[L], QX[L], Dn[L];
             double VC[SOC ? L : 1], GC[SOC ? L : 1];
+            double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
             double ref_last = 0.0;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -134,6 +151,8 @@ void admm_tile_kernel(const SolveArgs P) {
                     VC[l] = (valid && soc_lane) ? P.prim[off] : 0.0;                    // vcnew = x, zcnew = u (admm.cpp:352-357)
                     GC[l] = (valid && soc_lane) ? P.cdual[off] : 0.0;
                 }
+                if constexpr (LS) { VL[l] = (valid && lin_lane) ? P.prim[off] : 0.0; GL[l] = (valid && lin_lane) ? P.ldual[off] : 0.0; }     // :361-365
+                if constexpr (LT) { VT[l] = (valid && tlin_lane) ? P.prim[off] : 0.0; GT[l] = (valid && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
             double x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
@@ -158,6 +177,20 @@ void admm_tile_kernel(const SolveArgs P) {
                 }
                 if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
             }
+            if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
+                if (step > 0) {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) VL[l] = lin_lane ? sX[l * 64 + lane] : 0.0;
+                }
+                if (hrow == 0 && is_state && lin_lane) VL[0] = x0v;
+            }
+            if constexpr (LT) {                                        // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
+                if (step > 0) {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) VT[l] = tlin_lane ? sX[l * 64 + lane] : 0.0;
+                }
+                if (hrow == 0 && is_state && tlin_lane) VT[0] = x0v;
+            }
             for (int it = 0; it < P.max_iter; ++it) {
                 // ---- backward_pass_grad (admm.cpp:13-20): the horizon rows take turns, last row first
                 double pcur = 0.0, qhi = 0.0;
@@ -172,6 +205,8 @@ void admm_tile_kernel(const SolveArgs P) {
                         for (int l = L - 1; l >= 0; --l) {
                             double qlo = fma(-rho, VN[l] - G[l], QX[l]);                // admm.cpp:267 | :280 | :293
                             if constexpr (SOC) qlo = fma(-rho, VC[l] - GC[l], qlo);     // :269 | :282 | :295
+                            if constexpr (LS) qlo = fma(-rho, VL[l] - GL[l], qlo);      // :272 | :285 | :298
+                            if constexpr (LT) qlo = fma(-rho, VT[l] - GT[l], qlo);      // :275 | :288 | :301
                             if (ph == R - 1 && l == L - 1) {
                                 pcur = qlo;                                             // p_{N-1}
                             } else {
@@ -217,6 +252,36 @@ void admm_tile_kernel(const SolveArgs P) {
                                 GC[l] = tc - vc;                                        // :229 / :234
                                 VC[l] = vc;
                             }
+                            if constexpr (LIN != 0) {
+                                // half-spaces applied one after the other, only when violated (admm.cpp:148-173, 186-211)
+                                auto halfspaces = [&](double z, const double* tabk, const int nk) {
+                                    for (int k = 0; k < nk; ++k) {
+                                        const double a = tabk[k * LW + jj];
+                                        const double bk = tabk[KMAX * LW + k * LW + jj];
+                                        const double nn = tabk[2 * KMAX * LW + k * LW + jj];
+                                        const double prod = a * z;
+                                        const double cs = tile_matvec<W, 0, NX>(0.0, prod, ones);
+                                        const double ci = tile_matvec<W, NX, NZ>(0.0, prod, ones + NX);
+                                        const double cv = is_state ? cs : ci;
+                                        if (cv > bk) z = z - ((cv - bk) / nn) * a;
+                                    }
+                                    return z;
+                                };
+                                if constexpr (LS) {
+                                    const bool on = lin_lane && (is_state || g >= 1);
+                                    double vl = on ? (xi + GL[l]) : 0.0;                // :139 / :144
+                                    vl = halfspaces(vl, sLin, P.n_lin);
+                                    GL[l] = on ? ((GL[l] + xi) - vl) : 0.0;             // :239 / :244
+                                    VL[l] = on ? vl : 0.0;
+                                }
+                                if constexpr (LT) {
+                                    const bool on = tlin_lane && (is_state || g >= 1);
+                                    double vt = on ? (xi + GT[l]) : 0.0;                // :177 / :182
+                                    vt = halfspaces(vt, sTLin + g * 3 * KMAX * LW, P.n_tlin);
+                                    GT[l] = on ? ((GT[l] + xi) - vt) : 0.0;             // :249 / :254
+                                    VT[l] = on ? vt : 0.0;
+                                }
+                            }
                         }
                     }
                 }
@@ -258,6 +323,8 @@ void admm_tile_kernel(const SolveArgs P) {
                     P.dual[off] = G[l];
                     P.slack_prev[off] = VP[l];
                     if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
+                    if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
+                    if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
                 }
             }
             if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = sX[64 + lane];
