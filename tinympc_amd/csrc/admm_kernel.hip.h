@@ -27,10 +27,13 @@
 //     nx+nu, so a DPP row reads/writes one contiguous (nx+nu)*8-byte segment per knot point
 //     (128 B for the quadrotor) and consecutive instances are contiguous: every byte of every
 //     touched cache line is used.
-//   * One workgroup = one wavefront (no __syncthreads anywhere); waves are persistent and walk
-//     tiles of 4 instances with a grid stride, so the per-wave table prologue amortises.
-//     Groups that converge early are masked off by EXEC (per-row exit), the wave leaves the
-//     iteration loop when its last row has converged.
+//   * One workgroup = one wavefront (no __syncthreads anywhere) = by default one tile of 4 instances, so that the hardware
+//     dispatcher balances tiles with different iteration counts (with a capped grid the waves walk the tiles with a grid
+//     stride instead).  Rows that converge early are masked off by EXEC (per-row exit), the wave leaves the iteration loop
+//     when its last row has converged.
+//   * Template variants: SOC (second-order-cone slacks), DBG (keep q, r, p, d), MODE (how the row broadcast is issued),
+//     LIN / KMAX (static / time-varying half-spaces), HET (per-instance problem data).  kernel_dims.txt lists the shapes
+//     compiled into the library; every other shape / variant is instantiated at run time from this very header (jit.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
