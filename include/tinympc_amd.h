@@ -209,6 +209,16 @@ int tiny_batch_supported_dims(int* triples, int capacity);
  * 3 / 4 the one-row / tile kernel instantiated at run time with hipRTC for a shape outside kernel_dims.txt / tile_dims.txt
  * (first use costs about a second; option "no_jit" = 1 keeps such shapes on the coverage kernel) */
 int tiny_batch_kernel_path(TinyBatch* b);
+/* Run-time instantiated kernels and the disk cache.  With the environment variable TINYMPC_AMD_JIT_CACHE=<directory> the
+ * compiled code objects are kept in that directory (one file per instantiation, keyed by the kernel sources, the compile
+ * options and the hipRTC version; written atomically, so the ranks of a job may share it) and later processes load them
+ * instead of compiling.  tiny_jit_compile() compiles one instantiation by its C++ name, e.g.
+ * "tinympc_amd::admm_solve_kernel<5, 3, 7, false, false, 0, 0, false, 4>", without loading it: it needs no GPU, so an image
+ * build can fill the directory.  tiny_jit_used() lists the names this process instantiated so far (newline separated) --
+ * what to feed tiny_jit_compile() elsewhere.  Returns the code-object size in bytes (> 0; *from_disk = 1 if it was found in
+ * the directory), or TINY_ERR_HIP with the reason in msg. */
+long tiny_jit_compile(const char* instantiation, int* from_disk, char* msg, int msg_len);
+int tiny_jit_used(char* out, int out_len);                   /* returns the number of names; out may be NULL */
 /* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
  * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */
 long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold);   /* cold: 0 bytes_warm, 1 bytes_cold (one_shot = 2), 2 one_shot = 1 */

@@ -183,3 +183,38 @@ def test_halfspaces_and_cones_on_wide_and_long_shapes_run_the_tile_kernel(dims):
     fields = ["x", "u", "vnew", "znew", "g", "y", "vcnew", "gc", "vlnew", "zlnew", "gl", "yl"] + (["vlnew_tv", "zlnew_tv", "gl_tv", "yl_tv"] if tv_ok else [])
     for k in fields:
         assert rel_err(out[k], ref[k]) < RTOL, k
+
+
+DISK_CHILD = r'''
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle")); sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+import scenarios as sc
+import tinympc_amd as tm
+from hip_runner import run_cases_hip
+suite = sc.sweep_suite(6, 3, 8, B=9, max_iter=60)
+t = time.time()
+out = run_cases_hip(suite)
+print(json.dumps({"s": time.time() - t, "x": out["x"].ravel().tolist(), "iter": out["iter"].astype(int).tolist(), "used": tm.jit_used()}))
+'''
+
+
+def test_disk_cache_serves_a_second_process(tmp_path):
+    """TINYMPC_AMD_JIT_CACHE: the second process loads the code object the first one compiled -- same results, no compile."""
+    import json
+    import subprocess
+    env = dict(os.environ, TINYMPC_AMD_JIT_CACHE=str(tmp_path))
+    runs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, "-c", DISK_CHILD, os.path.join(HERE, "..")], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert len(os.listdir(tmp_path)) == 1 and len(runs[0]["used"]) == 1 and runs[0]["used"] == runs[1]["used"]
+    assert runs[0]["x"] == runs[1]["x"] and runs[0]["iter"] == runs[1]["iter"]
+    n, hit = None, None
+    os.environ["TINYMPC_AMD_JIT_CACHE"] = str(tmp_path)
+    try:
+        n, hit = tm.jit_compile(runs[0]["used"][0])
+    finally:
+        del os.environ["TINYMPC_AMD_JIT_CACHE"]
+    assert hit and n > 1000

@@ -1,45 +1,14 @@
 """CPU: the kernel variants that are never compiled into the library (they are instantiated with hipRTC on first use,
-csrc/jit.hip) must at least COMPILE for gfx950 -- hipRTC needs no GPU.  Catches a header edit that breaks a run-time-only
-variant before any GPU box sees it."""
+csrc/jit.hip) must at least COMPILE for gfx950 -- hipRTC needs no GPU.  Goes through the library's own tiny_jit_compile(), so
+the embedded copy of the kernel headers is what gets compiled: catches a header edit that breaks a run-time-only variant
+before any GPU box sees it.  Also covers the on-disk cache of the code objects (TINYMPC_AMD_JIT_CACHE)."""
 import os
-import shutil
 import subprocess
+import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "tinympc_amd", "csrc")
-
-HARNESS = r'''
-#include <hip/hiprtc.h>
-#include <cstdio>
-#include <fstream>
-#include <sstream>
-#include <string>
-static std::string rd(const std::string& p) { std::ifstream f(p); std::stringstream ss; ss << f.rdbuf(); return ss.str(); }
-int main(int argc, char** argv) {
-    const std::string dir = argv[1];
-    std::string hdr = rd(dir + "/admm_kernel.hip.h"), th = rd(dir + "/tile_kernel.hip.h");
-    for (const char* inc : {"#include <hip/hip_runtime.h>", "#include <stdint.h>"}) { size_t p = hdr.find(inc); if (p != std::string::npos) hdr.replace(p, std::string(inc).size(), ""); }
-    const char* hn[] = {"admm_kernel.hip.h", "tile_kernel.hip.h"};
-    const char* hs[] = {hdr.c_str(), th.c_str()};
-    int bad = 0;
-    for (int i = 2; i < argc; ++i) {
-        hiprtcProgram prog;
-        hiprtcCreateProgram(&prog, "#include \"tile_kernel.hip.h\"\n", "jit.hip", 2, hs, hn);
-        hiprtcAddNameExpression(prog, argv[i]);
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-        const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
-        if (r != HIPRTC_SUCCESS) {
-            size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, 0); hiprtcGetProgramLog(prog, &log[0]);
-            std::printf("FAILED %s\n%s\n", argv[i], log.substr(0, 1500).c_str());
-            ++bad;
-        } else std::printf("ok %s\n", argv[i]);
-        hiprtcDestroyProgram(&prog);
-    }
-    return bad;
-}
-'''
 
 VARIANTS = [
     "tinympc_amd::admm_solve_kernel<5, 3, 7, false, false, 2, 0, false, 4>",       # an unseen shape
@@ -51,14 +20,73 @@ VARIANTS = [
     "tinympc_amd::admm_tile_kernel<8, 2, 50, 1, 2, false, 1, 4>",                   # static half-spaces on a long horizon
 ]
 
+CHILD = r'''
+import json, sys, time
+sys.path.insert(0, sys.argv[1])
+import tinympc_amd as tm
+out = []
+for name in sys.argv[2:]:
+    t = time.time()
+    try:
+        n, hit = tm.jit_compile(name)
+        out.append({"name": name, "bytes": n, "hit": hit, "s": time.time() - t})
+    except RuntimeError as e:
+        out.append({"name": name, "error": str(e)[:1500]})
+print(json.dumps({"results": out, "used": tm.jit_used()}))
+'''
 
-def test_runtime_only_kernel_variants_compile(tmp_path):
-    if not (os.path.exists("/opt/rocm/include/hip/hiprtc.h") and shutil.which("g++")):
-        pytest.skip("hipRTC development files not installed")
-    src = tmp_path / "rtc.cpp"
-    src.write_text(HARNESS)
-    exe = tmp_path / "rtc"
-    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-L/opt/rocm/lib", "-lhiprtc",
-                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
-    p = subprocess.run([str(exe), CSRC] + VARIANTS, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-3000:]
+
+def _compile(names, cache_dir=None):
+    env = dict(os.environ)
+    env.pop("TINYMPC_AMD_JIT_CACHE", None)
+    if cache_dir is not None:
+        env["TINYMPC_AMD_JIT_CACHE"] = str(cache_dir)
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT] + list(names), capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def _need_hiprtc():
+    if not any(os.path.exists(p) for p in ("/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7")):
+        pytest.skip("libhiprtc not installed")
+
+
+def test_runtime_only_kernel_variants_compile():
+    _need_hiprtc()
+    r = _compile(VARIANTS)
+    bad = [x for x in r["results"] if "error" in x]
+    assert not bad, bad
+    assert all(x["bytes"] > 1000 and not x["hit"] for x in r["results"])
+    assert sorted(r["used"]) == sorted(VARIANTS)
+
+
+def test_a_name_that_is_not_a_kernel_is_refused():
+    r = _compile(["tinympc_amd::something_else<1>", "tinympc_amd::admm_solve_kernel<5, 3, 7, nonsense>"])
+    assert all("error" in x for x in r["results"]), r
+    assert r["used"] == []
+
+
+def test_disk_cache_of_code_objects(tmp_path):
+    _need_hiprtc()
+    name = VARIANTS[0]
+    first = _compile([name], tmp_path)["results"][0]
+    files = sorted(os.listdir(tmp_path))
+    assert not first["hit"] and len(files) == 1 and files[0].startswith("tinympc_amd_") and files[0].endswith(".co")
+    second = _compile([name], tmp_path)["results"][0]                     # a new process: loaded, not compiled
+    assert second["hit"] and second["bytes"] == first["bytes"] and second["s"] < 0.5 * first["s"] + 0.2
+    # a damaged file is not trusted: it is recompiled and replaced
+    path = os.path.join(tmp_path, files[0])
+    blob = bytearray(open(path, "rb").read())
+    blob[len(blob) // 2] ^= 0xFF
+    open(path, "wb").write(bytes(blob))
+    third = _compile([name], tmp_path)["results"][0]
+    assert not third["hit"] and third["bytes"] == first["bytes"]
+    assert _compile([name], tmp_path)["results"][0]["hit"]
+    assert sorted(os.listdir(tmp_path)) == files                           # no temporary files left behind
+    # another instantiation gets its own file
+    _compile([VARIANTS[4]], tmp_path)
+    assert len(os.listdir(tmp_path)) == 2
+    # an unwritable / missing directory only costs the caching
+    r = _compile([name], os.path.join(tmp_path, "does", "not", "exist"))["results"][0]
+    assert "error" not in r and not r["hit"]

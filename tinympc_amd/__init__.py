@@ -40,7 +40,8 @@ BATCH_SYMBOLS = (
     "tiny_batch_update_settings", "tiny_batch_get_cache", "tiny_batch_set",
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
-    "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path")
+    "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
+    "tiny_jit_compile", "tiny_jit_used")
 REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
@@ -107,6 +108,9 @@ def lib():
         L.tiny_batch_kernel_path.argtypes = [C.c_void_p]
         L.tiny_batch_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int]
         L.tiny_batch_algorithmic_bytes.restype = C.c_long
+        L.tiny_jit_compile.argtypes = [C.c_char_p, _ip, C.c_char_p, C.c_int]
+        L.tiny_jit_compile.restype = C.c_long
+        L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -119,6 +123,25 @@ def supported_dims():
     buf = (C.c_int * (3 * 256))()
     n = lib().tiny_batch_supported_dims(buf, 256)
     return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
+
+
+def jit_compile(instantiation: str):
+    """Compile one run-time instantiated kernel by its C++ name without loading it (needs no GPU); with the environment
+    variable TINYMPC_AMD_JIT_CACHE=<directory> the code object is looked up / kept there.  Returns (bytes, from_disk)."""
+    msg = C.create_string_buffer(2048)
+    hit = C.c_int(0)
+    n = lib().tiny_jit_compile(instantiation.encode(), C.byref(hit), msg, len(msg))
+    if n <= 0:
+        raise RuntimeError(msg.value.decode(errors="replace") or f"tiny_jit_compile failed ({n})")
+    return int(n), bool(hit.value)
+
+
+def jit_used():
+    """C++ names of the kernels this process instantiated at run time so far (what to feed jit_compile elsewhere)."""
+    n = lib().tiny_jit_used(None, 0)
+    buf = C.create_string_buffer(512 * max(n, 1))
+    lib().tiny_jit_used(buf, len(buf))
+    return [l for l in buf.value.decode().split("\n") if l]
 
 
 def _f64(a):

@@ -2,8 +2,12 @@
 #include "jit.hpp"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -26,6 +30,7 @@ struct Rtc {
     int (*code_size)(Program, size_t*) = nullptr;
     int (*code)(Program, char*) = nullptr;
     int (*destroy)(Program*) = nullptr;
+    int (*version)(int*, int*) = nullptr;
     bool ok = false;
 };
 
@@ -48,19 +53,80 @@ Rtc& rtc() {
     r.code_size = reinterpret_cast<decltype(r.code_size)>(sym("hiprtcGetCodeSize"));
     r.code = reinterpret_cast<decltype(r.code)>(sym("hiprtcGetCode"));
     r.destroy = reinterpret_cast<decltype(r.destroy)>(sym("hiprtcDestroyProgram"));
+    r.version = reinterpret_cast<decltype(r.version)>(sym("hiprtcVersion"));
     r.ok = r.create && r.add_name && r.compile && r.log_size && r.log && r.lowered && r.code_size && r.code && r.destroy;
     return r;
 }
 
+// ---- compiled code objects: per process by instantiation name, optionally on disk ---------------------------------
+struct Code { std::vector<char> blob; std::string lowered, err; bool from_disk = false; };
 struct Entry { hipFunction_t fn = nullptr; std::string err; };
-std::map<std::string, Entry> g_cache;                   // by instantiation name
+std::map<std::string, Code> g_code;                     // by instantiation name
+std::map<std::string, Entry> g_cache;                   // by instantiation name @ device (a module belongs to one device)
 std::mutex g_mu;
 
-Entry build(const std::string& name_s, const bool tile) {
-    Entry e;
+uint64_t fnv(uint64_t h, const void* p, size_t n) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+const char* const kOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+const char kMagic[8] = {'T', 'M', 'P', 'C', 'J', 'I', 'T', '1'};
+
+// TINYMPC_AMD_JIT_CACHE=<directory>: file of one instantiation = hash of (both kernel headers, name, options, hipRTC version)
+std::string disk_path(const std::string& name) {
+    const char* dir = getenv("TINYMPC_AMD_JIT_CACHE");
+    if (!dir || !*dir) return "";
+    uint64_t h = 1469598103934665603ull;
+    h = fnv(h, kAdmmKernelSrc, sizeof(kAdmmKernelSrc));
+    h = fnv(h, kTileKernelSrc, sizeof(kTileKernelSrc));
+    h = fnv(h, name.data(), name.size());
+    for (const char* o : kOpts) h = fnv(h, o, strlen(o));
+    int ver[2] = {0, 0};
+    if (rtc().version) rtc().version(&ver[0], &ver[1]);
+    h = fnv(h, ver, sizeof(ver));
+    char file[40];
+    snprintf(file, sizeof(file), "/tinympc_amd_%016llx.co", (unsigned long long)h);
+    return std::string(dir) + file;
+}
+
+// file = magic | u32 len(lowered) | u64 len(code) | lowered | code | u64 fnv(code); anything unexpected = not cached
+bool disk_load(const std::string& path, Code* c) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[8];
+    uint32_t nl = 0;
+    uint64_t nc = 0, sum = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, kMagic, 8) && fread(&nl, 4, 1, f) == 1 && fread(&nc, 8, 1, f) == 1 &&
+              nl > 0 && nl < 4096 && nc > 0 && nc < (64u << 20);
+    if (ok) {
+        c->lowered.resize(nl);
+        c->blob.resize(nc);
+        ok = fread(&c->lowered[0], 1, nl, f) == nl && fread(c->blob.data(), 1, nc, f) == nc && fread(&sum, 8, 1, f) == 1 &&
+             sum == fnv(1469598103934665603ull, c->blob.data(), nc);
+    }
+    fclose(f);
+    if (!ok) { c->lowered.clear(); c->blob.clear(); }
+    return ok;
+}
+void disk_store(const std::string& path, const Code& c) {                // best effort; rename makes it atomic for concurrent ranks
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint32_t nl = (uint32_t)c.lowered.size();
+    const uint64_t nc = c.blob.size(), sum = fnv(1469598103934665603ull, c.blob.data(), c.blob.size());
+    const bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&nl, 4, 1, f) == 1 && fwrite(&nc, 8, 1, f) == 1 && fwrite(c.lowered.data(), 1, nl, f) == nl &&
+                    fwrite(c.blob.data(), 1, nc, f) == nc && fwrite(&sum, 8, 1, f) == 1;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
+Code compile(const std::string& name_s, const bool tile) {
+    Code c;
     const char* name = name_s.c_str();
+    const std::string path = disk_path(name_s);
+    if (!path.empty() && disk_load(path, &c)) { c.from_disk = true; return c; }
     Rtc& R = rtc();
-    if (!R.ok) { e.err = "libhiprtc is not available"; return e; }
+    if (!R.ok) { c.err = "libhiprtc is not available"; return c; }
     // hipRTC brings its own runtime header: the two system includes of the kernel header are dropped
     std::string hdr(kAdmmKernelSrc);
     for (const char* inc : {"#include <hip/hip_runtime.h>", "#include <stdint.h>"}) {
@@ -71,29 +137,42 @@ Entry build(const std::string& name_s, const bool tile) {
     const char* hn[] = {"admm_kernel.hip.h", "tile_kernel.hip.h"};
     const char* hs[] = {hdr.c_str(), kTileKernelSrc};
     Rtc::Program prog = nullptr;
-    if (R.create(&prog, src.c_str(), "tinympc_amd_jit.hip", 2, hs, hn) != 0) { e.err = "hiprtcCreateProgram failed"; return e; }
+    if (R.create(&prog, src.c_str(), "tinympc_amd_jit.hip", 2, hs, hn) != 0) { c.err = "hiprtcCreateProgram failed"; return c; }
     R.add_name(prog, name);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const int rc = R.compile(prog, 3, opts);
+    const int rc = R.compile(prog, 3, kOpts);
     if (rc != 0) {
         size_t n = 0;
         R.log_size(prog, &n);
         std::string log(n, '\0');
         if (n) R.log(prog, &log[0]);
-        e.err = "hipRTC compilation of " + std::string(name) + " failed: " + log.substr(0, 400);
+        c.err = "hipRTC compilation of " + std::string(name) + " failed: " + log.substr(0, 400);
         R.destroy(&prog);
-        return e;
+        return c;
     }
     const char* low = nullptr;
     size_t cs = 0;
-    if (R.lowered(prog, name, &low) != 0 || R.code_size(prog, &cs) != 0 || cs == 0) { e.err = "hipRTC produced no code"; R.destroy(&prog); return e; }
-    std::vector<char> code(cs);
-    R.code(prog, code.data());
-    const std::string lowered(low);
+    if (R.lowered(prog, name, &low) != 0 || R.code_size(prog, &cs) != 0 || cs == 0) { c.err = "hipRTC produced no code"; R.destroy(&prog); return c; }
+    c.blob.resize(cs);
+    R.code(prog, c.blob.data());
+    c.lowered = low;
     R.destroy(&prog);
+    if (!path.empty()) disk_store(path, c);
+    return c;
+}
+
+const Code& code_for(const std::string& name, const bool tile) {          // g_mu held
+    auto it = g_code.find(name);
+    if (it == g_code.end()) it = g_code.emplace(name, compile(name, tile)).first;
+    return it->second;
+}
+
+Entry build(const std::string& name, const bool tile) {
+    Entry e;
+    const Code& c = code_for(name, tile);
+    if (c.blob.empty()) { e.err = c.err; return e; }
     hipModule_t mod = nullptr;
-    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); e.err = "hipModuleLoadData failed"; return e; }
-    if (hipModuleGetFunction(&e.fn, mod, lowered.c_str()) != hipSuccess) { (void)hipGetLastError(); e.fn = nullptr; e.err = "kernel symbol not found in the compiled module"; }
+    if (hipModuleLoadData(&mod, c.blob.data()) != hipSuccess) { (void)hipGetLastError(); e.err = "hipModuleLoadData failed"; return e; }
+    if (hipModuleGetFunction(&e.fn, mod, c.lowered.c_str()) != hipSuccess) { (void)hipGetLastError(); e.fn = nullptr; e.err = "kernel symbol not found in the compiled module"; }
     return e;                                            // the module stays loaded for the life of the process
 }
 
@@ -102,12 +181,34 @@ Entry build(const std::string& name_s, const bool tile) {
 static hipFunction_t get(const std::string& name, const bool tile, std::string* err) {
     std::lock_guard<std::mutex> lk(g_mu);
     int dev = 0;
-    (void)hipGetDevice(&dev);                            // a module belongs to the device it was loaded on
+    (void)hipGetDevice(&dev);
     const std::string key = name + "@" + std::to_string(dev);
     auto it = g_cache.find(key);
     if (it == g_cache.end()) it = g_cache.emplace(key, build(name, tile)).first;
     if (!it->second.fn && err) *err = it->second.err;
     return it->second.fn;
+}
+
+long jit_compile_only(const char* instantiation, int* from_disk, std::string* err) {
+    const std::string name(instantiation ? instantiation : "");
+    const bool tile = name.find("admm_tile_kernel<") != std::string::npos;
+    if (!tile && name.find("admm_solve_kernel<") == std::string::npos) { if (err) *err = "not an instantiation of admm_solve_kernel / admm_tile_kernel"; return -1; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    const Code& c = code_for(name, tile);
+    if (from_disk) *from_disk = c.from_disk ? 1 : 0;
+    if (c.blob.empty()) { if (err) *err = c.err; return -1; }
+    return (long)c.blob.size();
+}
+
+int jit_used_names(std::string* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (const auto& kv : g_code) {
+        if (kv.second.blob.empty()) continue;
+        if (out) { *out += kv.first; *out += '\n'; }
+        ++n;
+    }
+    return n;
 }
 
 hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {

@@ -1,6 +1,7 @@
 // jit.hpp -- run-time instantiation of the register-resident kernel (admm_kernel.hip.h) for (nx, nu, N) shapes that
 // are not in kernel_dims.txt.  The kernel header is embedded in the library at build time (_gen/kernel_src.inc) and
-// compiled for gfx950 with hipRTC on first use (about a second per variant, cached per process); libhiprtc is
+// compiled for gfx950 with hipRTC on first use (seconds per variant; cached per process, and across processes in the
+// directory TINYMPC_AMD_JIT_CACHE names, if set); libhiprtc is
 // dlopen'ed so that the library loads without it -- then such shapes simply stay on the coverage kernel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -41,5 +42,12 @@ inline bool jit_tile_shape(int nx, int nu, int N, int* W, int* R) {
     return false;
 }
 hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, int lin, int kmax, std::string* err);
+
+// Compile one instantiation ("tinympc_amd::admm_solve_kernel<...>" / "tinympc_amd::admm_tile_kernel<...>") without loading
+// it -- needs no GPU.  With TINYMPC_AMD_JIT_CACHE=<directory> set the code object is looked up / kept there (one file per
+// instantiation, keyed by the kernel sources, the options and the hipRTC version; written atomically).  Returns the code
+// size in bytes, -1 on failure (*err); *from_disk = 1 when nothing had to be compiled.
+long jit_compile_only(const char* instantiation, int* from_disk, std::string* err);
+int jit_used_names(std::string* out);       // the instantiations compiled / loaded so far, one per line; returns their number
 
 }  // namespace tinympc_amd
