@@ -110,13 +110,13 @@ def test_uninstantiated_wide_or_long_shape_runs_the_tile_kernel(dims, path):
         assert rel_err(out[k], ref[k]) < RTOL, k
 
 
-def test_up_to_eight_halfspaces_stay_register_resident():
-    """4 half-spaces per knot and family are compiled in; 5..8 get the KMAX = 8 variant at run time; 9 go to the coverage
-    kernel.  Same results either way."""
+def test_many_halfspaces_stay_register_resident():
+    """4 half-spaces per knot and family are compiled in; more get the KMAX = 8 / 16 / 32 variant at run time; 33 go to the
+    coverage kernel.  Same results either way."""
     prob, _ = sc.load_problem("quadrotor_20hz")
     nx, nu, N = prob["nx"], prob["nu"], prob["N"]
     rng = np.random.default_rng(12)
-    for ns, want in ((4, "regs"), (7, "regs"), (9, "cover")):
+    for ns, want in ((4, "regs"), (7, "regs"), (9, "regs"), (20, "regs"), (33, "cover")):
         cfg = sc.default_config(prob, max_iter=30, en_state_linear=1, en_input_linear=1, u_min=-0.5, u_max=0.5,
                                 linear=(rng.standard_normal((ns, nx)), rng.uniform(0.3, 1.0, ns), rng.standard_normal((2, nu)), rng.uniform(0.2, 0.6, 2)))
         cases = sc.zero_cases(prob, 5)

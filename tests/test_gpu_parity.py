@@ -177,6 +177,26 @@ def test_edge_cases():
     assert_match(run_cases_hip(one), sc.run_cases(OracleSolver, one), RTOL, "B=1")
 
 
+@pytest.mark.parametrize("options", [{}, {"prefer_tile": 1}, {"force_general": 1}])
+def test_non_finite_instance_stays_in_its_row(options):
+    """An instance fed NaN / Inf shares its wave with three healthy ones: it must terminate (iteration cap at the latest)
+    and the neighbours' results must be bit-identical to a run without it -- on all three kernels."""
+    suite = sc.tracking_random_suite(B=9)
+    suite["config"]["max_iter"] = 60
+    clean = run_cases_hip(suite, options=options)
+    bad = {k: v.copy() for k, v in suite["cases"].items()}
+    bad["x0"][1, 0] = np.nan
+    bad["x0"][6, 2] = np.inf
+    bad["Xref"][4] = np.nan
+    dirty = run_cases_hip(dict(suite, cases=bad), options=options)
+    healthy = [0, 2, 3, 5, 7, 8]
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        assert np.array_equal(dirty[k][healthy], clean[k][healthy]), k
+    assert np.array_equal(dirty["iter"][healthy], clean["iter"][healthy])
+    assert np.all(dirty["iter"][[1, 4, 6]] <= 60) and np.all(np.isin(dirty["status"][[1, 4, 6]], (1, 11)))
+    assert np.isnan(dirty["x"][1]).any() and np.isnan(dirty["x"][4]).any()
+
+
 def test_hover_closed_loop_full_batch():
     """BASELINE config 2 at full size: 65 536 identical quadrotor-hover instances, 100 closed-loop MPC
     steps on device (advance_x0).  Properties: every instance reproduces the reference's golden

@@ -67,7 +67,7 @@ enum : int {
 // [constraint k < LIN_KMAX][16 lanes]: the coefficient of this lane's row (state lanes: Alin_x[k][j], input lanes:
 // Alin_u[k][j-nx]), the offset b_k and ||a_k||^2 of this lane's family (b = +inf where there is no constraint k).
 // The time-varying tables carry one such block per slot (input lanes shifted by one knot, like the bounds).
-enum : int { LIN_KMAX = 4, LIN_KMAX_BIG = 8 };       // half-spaces per knot and family: compiled-in variants / run-time instantiated ones
+enum : int { LIN_KMAX = 4, LIN_KMAX_BIG = 32 };      // half-spaces per knot and family: compiled-in variants / largest run-time instantiated one
 static inline int tab_lin_offset(int N) { return TAB_BOUNDS + 2 * N * 16; }
 static inline int tab_tlin_offset(int N, int kmax = LIN_KMAX) { return tab_lin_offset(N) + 3 * kmax * 16; }
 static inline int tab_doubles(int N, int kmax = LIN_KMAX) { return tab_tlin_offset(N, kmax) + 3 * N * kmax * 16; }

@@ -50,6 +50,7 @@ struct TinyBatch {
     // device state (KPI records, see admm_kernel.hip.h)
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    size_t d_tab_doubles = 0;                    // capacity of d_tab (grows with the half-space table stride)
     double *d_tab = nullptr, *d_x0 = nullptr, *d_ref = nullptr, *d_prim = nullptr, *d_slack = nullptr,
            *d_dual = nullptr, *d_slack_prev = nullptr, *d_cslack = nullptr, *d_cdual = nullptr, *d_resid = nullptr,
            *d_stage = nullptr, *d_stats = nullptr, *d_dbg_qr = nullptr, *d_dbg_pd = nullptr;
