@@ -187,7 +187,14 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * "one_shot" (one-shot / cold solves: the warm-start state is taken as zero -- the state after tiny_setup or
  * tiny_batch_reset -- WITHOUT being read, and only the results are written: 1 = x|u and vnew|znew (solution->x|u),
  * 2 = x|u only, the bytes_cold = 8(nx+2S)+44 traffic of a solve that is not going to be warm-started; the other
- * warm-start records are left as they were.  Register-resident shapes only). */
+ * warm-start records are left as they were.  Register-resident shapes only),
+ * "repack_after" (K > 0: split solve for batches whose iteration counts diverge -- the launch stops at iteration K, the
+ * instances still open are listed by the kernel itself and carried on to 2K, 4K, ... max_iter by follow-up launches, four
+ * open instances per wave at every stage, so that a slow instance no longer holds a wave by itself.  Results are
+ * bit-identical to the unsplit solve; K is rounded down to a multiple of check_termination.  Worth it for cold solves
+ * with a tail of slow instances (config 3: -16 %), not for warm MPC steps (every stage is a launch).  One-row kernel,
+ * single-step launches without "advance_x0" / "one_shot"; ignored elsewhere.  "repack_growth" (default 2) and
+ * "repack_waves_per_cu" (default 8) tune the stage schedule and the grid of the follow-up launches). */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
 /* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state

@@ -1,0 +1,134 @@
+"""Split solves (option "repack_after" = K): the first launch stops at iteration K, the instances that have not converged
+are compacted and carried on to 2K, 4K, ... max_iter by further launches, four per wave again at every stage.  Everything a solve leaves behind must be
+bit-identical to the unsplit solve -- which is itself held to the oracle / the golden fixtures elsewhere."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+sys.path.insert(0, HERE)
+
+import scenarios as sc  # noqa: E402
+import tinympc_amd as tm  # noqa: E402
+from cpu_solvers import OracleSolver  # noqa: E402
+from hip_runner import make_batch, run_cases_hip  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def same(a, b, what):
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (what, k)
+        else:
+            assert a[k] == b[k], (what, k)
+
+
+@pytest.mark.parametrize("name,caps", [("tracking_random", (1, 8, 9, 13, 50)), ("rocket_random_isoc", (5, 27, 36)),
+                                        ("rocket_random_bothsoc", (20,)), ("linear_random_all", (7, 28)),
+                                        ("linear_random_tv_only", (11,)), ("random_state_quad", (3, 10)),
+                                        ("sweep_4_2_10", (6,)), ("sweep_12_2_10", (9,))])
+def test_split_solve_is_bit_identical(name, caps):
+    suite, ref = sc.load_suite(os.path.join(GOLDEN, name + ".npz"))
+    whole = run_cases_hip(suite, debug=True)
+    assert np.array_equal(whole["iter"].astype(int), ref["iter"].astype(int))
+    for cap in caps:
+        same(whole, run_cases_hip(suite, debug=True, options={"repack_after": cap}), (name, cap))
+    same(run_cases_hip(suite), run_cases_hip(suite, options={"repack_after": caps[0]}), (name, "no debug"))
+
+
+def test_split_solve_with_a_coarse_termination_check():
+    """check_termination = 5: the cap is rounded down to a multiple of it so that the countdown stays in phase."""
+    suite = sc.tracking_random_suite(B=13)
+    suite["config"]["check_termination"] = 5
+    whole = run_cases_hip(suite)
+    assert np.all(whole["iter"] % 5 == 0) and len(set(whole["iter"].tolist())) > 1
+    for cap in (4, 5, 12, 17):
+        same(whole, run_cases_hip(suite, options={"repack_after": cap}), cap)
+    suite["config"]["check_termination"] = 0            # never checked: every instance runs to max_iter through both launches
+    suite["config"]["max_iter"] = 30
+    same(run_cases_hip(suite), run_cases_hip(suite, options={"repack_after": 11}), "no termination check")
+
+
+def test_split_solve_large_divergent_batch_and_statistics():
+    """BASELINE config 3 shape of problem: many cold solves with a long tail of iteration counts; the compacted list spans many
+    waves, the accumulated statistics must not count anything twice."""
+    base = sc.tracking_random_suite(B=512, seed=99)
+    reps = 16
+    suite = dict(base, cases={k: np.concatenate([v] * reps, axis=0) for k, v in base["cases"].items()})
+
+    def run(opts):
+        s = make_batch(suite)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_x0(suite["cases"]["x0"])
+        for f in ("Xref", "Uref"):
+            s.set(f, suite["cases"][f])
+        s.solve()
+        out = dict(x=s.get("x"), u=s.get("u"), vnew=s.get("vnew"), g=s.get("g"), v=s.get("v"), y=s.get("y"), stats=np.asarray(s.reduce_stats()))
+        out.update({k: np.asarray(v) for k, v in s.status().items()})
+        s.close()
+        return out
+
+    whole = run({})
+    assert whole["iter"].max() > 2 * np.median(whole["iter"])
+    for cap in (10, 24):
+        same(whole, run({"repack_after": cap}), cap)
+    ref = sc.run_cases(OracleSolver, dict(base, cases={k: v[:32] for k, v in base["cases"].items()}))
+    assert np.array_equal(whole["iter"][:32].astype(int), ref["iter"].astype(int))
+
+
+def test_split_solve_keeps_heterogeneous_and_windowed_solves_intact():
+    """Per-instance problem data (tables indexed by instance) and the tracking window with per-solve dual reset go through
+    the compacted launch too."""
+    prob, extra = sc.load_problem("quadrotor_20hz")
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(8)
+    B = 10
+    # heterogeneous: rho and Q differ per instance
+    Q = np.tile(np.asarray(prob["Q"], dtype=np.float64).ravel(), (B, 1)) * rng.uniform(0.5, 2.0, (B, 1))
+    rho = rng.uniform(1.0, 8.0, B)
+    x0 = rng.normal(0, 0.3, (B, nx))
+
+    def het(opts):
+        s = tm.TinyBatchSolver.hetero(np.stack([prob["A"]] * B), np.stack([prob["B"]] * B), None, Q,
+                                      np.tile(np.asarray(prob["R"], dtype=np.float64).ravel(), (B, 1)), rho, N)
+        s.set_bound_constraints(np.full((nx, N), -5.0), np.full((nx, N), 5.0), np.full((nu, N - 1), -0.5), np.full((nu, N - 1), 0.5))
+        s.update_settings(1e-4, 1e-4, 80, 1, 1, 1, 0, 0)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_x0(x0)
+        s.solve()
+        out = dict(x=s.get("x"), u=s.get("u"), g=s.get("g"), iter=np.asarray(s.status()["iter"]))
+        s.close()
+        return out
+
+    whole = het({})
+    assert len(set(whole["iter"].tolist())) > 1
+    same(whole, het({"repack_after": int(np.median(whole["iter"]))}), "hetero")
+
+    suite = sc.tracking_random_suite(B=12)
+    traj = np.array(extra["y_axis_line"], dtype=np.float64)
+
+    def windowed(opts):
+        s = make_batch(suite)
+        s.set_reference_trajectory(traj)
+        s.set_option("reset_duals", 1)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_x0(suite["cases"]["x0"])
+        s.set("g", np.ones_like(suite["cases"]["g"]))
+        outs = []
+        for _ in range(3):
+            s.solve()
+            outs.append(dict(x=s.get("x"), g=s.get("g"), iter=np.asarray(s.status()["iter"])))
+        s.close()
+        return outs
+
+    a, b = windowed({}), windowed({"repack_after": 6})
+    for i in range(3):
+        same(a[i], b[i], ("window", i))

@@ -111,6 +111,17 @@ struct SolveArgs {
     // tiny_setup / a reset) without being read.  store_mask: which records the launch writes back -- bit 0 x|u,
     // bit 1 vnew|znew (= solution->x|u), bit 2 g|y, bit 3 v|z, bit 4 the cone / linear slack and dual records.
     int cold, store_mask;
+    // Resumed solves (batch_api.hip "repack_after"): an earlier launch capped at iter_base iterations has stored the ADMM
+    // state of the instances that did not converge; index[0 .. *count) lists them and this launch carries on from
+    // iteration iter_base with four of them per wave again.  The cone / half-space slacks are then read from their own records
+    // instead of being initialised from x (admm.cpp:352-374 runs once per solve).  index == nullptr: a plain launch.
+    // next_index != nullptr: this launch is itself capped below the solver's max_iter, and lists the instances it leaves
+    // open for the next stage (one atomic per wave that has any; the order in the list is irrelevant to the results).
+    const int* index;
+    const int* count;
+    int iter_base;
+    int* next_index;
+    int* next_count;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -369,10 +380,13 @@ void admm_solve_kernel(const SolveArgs P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
 
-    const int ntiles = (P.batch + 3) >> 2;
+    const int ninst = P.index ? *P.count : P.batch;
+    const int ntiles = (ninst + 3) >> 2;
+    const bool resumed = P.index != nullptr;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile * 4 + grp;
-        if (b < P.batch) {
+        const int slot = tile * 4 + grp;
+        if (slot < ninst) {
+            const int b = resumed ? P.index[slot] : slot;
             const double* het = nullptr;
             if constexpr (HET) {                               // this instance's own cache (A, B, Q, R, rho differ per instance)
                 het = P.het_tabs + (size_t)b * TAB_BOUNDS;
@@ -408,15 +422,15 @@ void admm_solve_kernel(const SolveArgs P) {
                 X[s] = 0.0;
                 if (s == N - 1) ref_last = r;
                 if constexpr (SOC) {
-                    VC[s] = (warm && soc_lane) ? P.prim[off] : 0.0;         // admm.cpp:352-357
+                    VC[s] = (warm && soc_lane) ? (resumed ? P.cslack : P.prim)[off] : 0.0;         // admm.cpp:352-357
                     GC[s] = (warm && soc_lane) ? P.cdual[off] : 0.0;
                 }
                 if constexpr (LS) {
-                    VL[s] = (warm && lin_lane) ? P.prim[off] : 0.0;         // admm.cpp:361-365
+                    VL[s] = (warm && lin_lane) ? (resumed ? P.lslack : P.prim)[off] : 0.0;         // admm.cpp:361-365
                     GL[s] = (warm && lin_lane) ? P.ldual[off] : 0.0;
                 }
                 if constexpr (LT) {
-                    VT[s] = (warm && tlin_lane) ? P.prim[off] : 0.0;        // admm.cpp:370-374
+                    VT[s] = (warm && tlin_lane) ? (resumed ? P.tlslack : P.prim)[off] : 0.0;       // admm.cpp:370-374
                     GT[s] = (warm && tlin_lane) ? P.tldual[off] : 0.0;
                 }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
@@ -460,7 +474,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     if (step > 0) {                            // vcnew = x, zcnew = u of the previous solve (admm.cpp:352-357)
 #pragma unroll
                         for (int s = 0; s < N; ++s) VC[s] = soc_lane ? X[s] : 0.0;
-                    } else if (is_state && soc_lane) {
+                    } else if (is_state && soc_lane && !resumed) {
                         VC[0] = x0v;
                     }
                 }
@@ -468,17 +482,19 @@ void admm_solve_kernel(const SolveArgs P) {
                     if (step > 0) {
 #pragma unroll
                         for (int s = 0; s < N; ++s) VL[s] = lin_lane ? X[s] : 0.0;
-                    } else if (is_state && lin_lane) VL[0] = x0v;
+                    } else if (is_state && lin_lane && !resumed) VL[0] = x0v;
                 }
                 if constexpr (LT) {                            // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
                     if (step > 0) {
 #pragma unroll
                         for (int s = 0; s < N; ++s) VT[s] = tlin_lane ? X[s] : 0.0;
-                    } else if (is_state && tlin_lane) VT[0] = x0v;
+                    } else if (is_state && tlin_lane && !resumed) VT[0] = x0v;
                 }
-                iter = 0; solved = 0;
+                const int iter0 = resumed ? P.iter_base : 0;   // (a multiple of check_termination: the countdown restarts in phase)
+                iter = iter0; solved = 0;
+                if (resumed && P.check_termination > 0) checked = 1;
                 int countdown = P.check_termination;
-                for (int it = 0; it < P.max_iter; ++it) {
+                for (int it = iter0; it < P.max_iter; ++it) {
                     // ---- update_linear_cost (lane-local) fused into the backward sweep.
                     // qv(s): state lanes q_s (s = N-1: the terminal p), input lanes r_{s-1}.
                     double qhi;
@@ -600,7 +616,7 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                     for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446
                 }
-                acc_iter += (unsigned)iter;
+                acc_iter += (unsigned)(iter - iter0);
                 acc_solved += (unsigned)solved;
                 if (nsteps > 1) {
                     if (P.iter_log && j == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
@@ -639,6 +655,17 @@ void admm_solve_kernel(const SolveArgs P) {
             if (P.x0_next && acc_iter > 0 && is_state) P.x0_next[(size_t)b * NX + j] = X[1];     // x1 = A x0 + B u0 + f (needs a forward pass)
             const double ps = grp_max16(is_state ? rp : 0.0), pi = grp_max16(is_input ? rp : 0.0);
             const double ds = grp_max16(is_state ? rd : 0.0), di = grp_max16(is_input ? rd : 0.0);
+            if (P.next_index) {
+                const bool open = j == 0 && !solved;
+                const unsigned long long m = __ballot(open);
+                if (m) {
+                    const int first = __ffsll((long long)m) - 1;
+                    int at = 0;
+                    if (lane == first) at = atomicAdd(P.next_count, __popcll(m));
+                    at = __shfl(at, first);
+                    if (open) P.next_index[at + __popcll(m & ((1ull << lane) - 1ull))] = b;
+                }
+            }
             if (j == 0) {
                 P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
                 double4 rr = make_double4(ps, pi, ds, di);

@@ -72,6 +72,12 @@ struct TinyBatch {
     bool advance_x0 = false, debug = false;
     int grid_waves_per_cu = 0, dpp_mode = 2, steps_per_launch = 1;
     bool step_log = false, reset_duals = false;
+    // repack_after = K > 0: a solve is split at iterations K, 2K, 4K, ... -- the instances that have not converged by then are
+    // compacted and carried on by the next launch with four of them per wave again (divergent cold batches: a slow
+    // instance no longer holds a wave by itself).  Results are bit-identical to the unsplit solve.
+    int repack_after = 0;
+    int repack_waves_per_cu = 8, repack_growth = 2;   // grid of the follow-up stages; stage s runs to K * growth^s (measured best: 8, 2)
+    int *d_repack_index = nullptr, *d_repack_count = nullptr;
     int one_shot = 0;                    // 1: cold state assumed, x|u + vnew|znew written; 2: x|u only (bytes_cold of SURVEY.md 8(d))
     double* d_traj = nullptr;
     // heterogeneous problem families: per-instance problem data, caches and lane tables (device)

@@ -67,9 +67,24 @@ def config3(B=262144, reps=3):
         one_shot[f"one_shot={mode}"] = dict(kernel_ms=bm, solves_per_s=B / (bm * 1e-3), admm_iters_per_s=so[0] / (bm * 1e-3),
                                             bytes_per_solve=s.algorithmic_bytes(cold=(2 if mode == 1 else 1)))
     s.set_option("one_shot", 0)
+    repack = {}
+    for cap in (9, 10, 11, 12, 16, 24):      # split solves: stop at `cap`, compact the open instances, finish them densely packed
+        s.set_option("repack_after", cap)
+        bm = None
+        for _ in range(reps):
+            s.reset()
+            s.set_x0(x0)
+            s.set_option("timing", 1)
+            s.solve_async()
+            ms = float(s.timing_ms()[0])
+            bm = ms if bm is None else min(bm, ms)
+        so = s.reduce_stats()
+        assert so[0] == st[0] and so[1] == st[1] and np.array_equal(s.status()["iter"], it), "split solve differs"
+        repack[f"repack_after={cap}"] = dict(kernel_ms=bm, solves_per_s=B / (bm * 1e-3), admm_iters_per_s=so[0] / (bm * 1e-3))
+    s.set_option("repack_after", 0)
     s.close()
     t = best * 1e-3
-    return dict(one_shot=one_shot, config="quadrotor_tracking x262144, per-instance random refs, one cold solve", batch=B, kernel_ms=best,
+    return dict(one_shot=one_shot, repack=repack, config="quadrotor_tracking x262144, per-instance random refs, one cold solve", batch=B, kernel_ms=best,
                 solves_per_s=B / t, admm_iters_per_s=st[0] / t, iters_per_solve=st[0] / B, solved_fraction=st[1] / B,
                 iter_histogram={int(v): int(c) for v, c in zip(*np.unique(it, return_counts=True))},
                 hbm_frac=alg * B / t / 8e12, fp64_frac=st[0] * tm.flops_per_iter(nx, nu, N) / t / 78.6e12)
