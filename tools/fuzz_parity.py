@@ -59,8 +59,12 @@ def trial(seed):
     prob, cfg, cases = suite["problem"], suite["config"], suite["cases"]
     nx, nu, N, B = prob["nx"], prob["nu"], prob["N"], cases["x0"].shape[0]
     ref = sc.run_cases(OracleSolver, suite)
-    out = run_cases_hip(suite)
-    desc = f"seed {seed} shape {(nx, nu, N)} B {B} max_iter {kw['max_iter']} ct {kw['check_termination']} flags " + \
+    orng = np.random.default_rng(seed + 77_000_000)     # launch options: their own stream, so that the problems of a seed stay what they were
+    opts = {}
+    if orng.random() < 0.35:                             # split solve: stop at K, carry the open instances on (must change nothing)
+        opts = {"repack_after": int(orng.integers(1, max(2, kw["max_iter"]))), "repack_growth": int(orng.integers(2, 4))}
+    out = run_cases_hip(suite, options=opts)
+    desc = f"seed {seed} shape {(nx, nu, N)} B {B} max_iter {kw['max_iter']} ct {kw['check_termination']} opts {opts} flags " + \
            "".join(str(cfg[k]) for k in ("en_state_bound", "en_input_bound", "en_state_soc", "en_input_soc", "en_state_linear",
                                           "en_input_linear", "en_tv_state_linear", "en_tv_input_linear"))
     for k in ("iter", "sol_solved", "status"):
