@@ -170,7 +170,7 @@ int tiny_batch_get_status(TinyBatch* b, int* iter, int* solved, int* status, dou
  * max primal_state, max primal_input, max dual_state, max dual_input,
  * iterations accumulated since the last tiny_batch_reset, converged solves accumulated, 0}.
  * host_out and/or device_out (a device pointer to 10 doubles, e.g. the buffer handed to an
- * RCCL all-reduce) may be NULL. */
+ * RCCL collective) may be NULL. */
 int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
 
 /* ---- plumbing ---------------------------------------------------------------------------- */
