@@ -7,8 +7,8 @@ examples/quadrotor_hovering.cpp, warm-started from the previous step, plant adva
 The timed region always starts from the cold state of tiny_setup, so K steps = the first K steps of
 the reference's 100-step episode (K = 100 -> 882 ADMM iterations per instance).
 State is resident in HBM before timing starts.  Multi-GPU: one process per GPU, batch sharded with
-no data-path collective (weak scaling: 65 536 instances per GPU); one RCCL collective on the 80-byte
-residual / iteration statistics vector closes the timed region.
+no data-path collective (weak scaling: 65 536 instances per GPU); the RCCL all-reduces (SUM, MAX) of the 80-byte
+residual / iteration statistics vector close the timed region.
 
   python bench.py --gpus 1 --steps 100 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -142,8 +142,8 @@ def main():
         for _ in range(args.steps // T):
             s.solve_async()
         s.reduce_stats_async(stats.data_ptr())
-        if dist is not None:                         # the one collective of the path: the 80-byte statistics vectors
-            stats = allreduce_stats(stats, dist)     # RCCL all-gather over xGMI, then SUM of counts / MAX of residuals
+        if dist is not None:                         # the one exchange of the path: the 80-byte statistics vectors
+            stats = allreduce_stats(stats, dist)     # RCCL over xGMI: SUM of counts, MAX of residuals
         barrier()
         elapsed = time.perf_counter() - t0
     if dist is not None:
