@@ -21,8 +21,8 @@ def rep(a, b):
     s = s.replace(a, b, 1)
 rep("    const int lane = threadIdx.x & 63;\n    const int j = lane & 15;",
     "    const unsigned long long clk_entry = wall_clock64();\n    const int lane = threadIdx.x & 63;\n    const int j = lane & 15;")
-rep("    const int ntiles = (P.batch + 3) >> 2;\n",
-    "    __builtin_amdgcn_s_waitcnt(0);\n    const unsigned long long clk_pro = wall_clock64();\n    const int ntiles = (P.batch + 3) >> 2;\n")
+rep("    const int ninst = P.index ? *P.count : P.batch;\n",
+    "    __builtin_amdgcn_s_waitcnt(0);\n    const unsigned long long clk_pro = wall_clock64();\n    const int ninst = P.index ? *P.count : P.batch;\n")
 rep("            const double* het = nullptr;\n", "            const unsigned long long c0 = wall_clock64();\n            const double* het = nullptr;\n")
 rep("            int iter = 0, solved = 0, checked = 0;\n",
     "            __builtin_amdgcn_s_waitcnt(0);\n            const unsigned long long c1 = wall_clock64();\n            int iter = 0, solved = 0, checked = 0;\n")
