@@ -287,12 +287,19 @@ __device__ __forceinline__ double grp_max16(double v) {
 // project_soc (admm.cpp:39-60) for one component of a 3-cone; s0,s1,s2 = the cone's vector, mine = s[c], the
 // component this lane owns.  mu and the norm are float, a/mu is a float division.  The reference is built without
 // FMA contraction, and `a` is truncated to float before the branch tests, so the sum of squares must not be fused.
-// The two divisions of the "outside" branch are skipped when no lane of the wave is outside its cone.
+// The two divisions of the "outside" branch are skipped when no lane of the wave is outside its cone, the square root
+// when every cone of the wave is clearly inside.
 __device__ __forceinline__ double soc_component(double s0, double s1, double s2, double mine, int c, float mu) {
 #pragma clang fp contract(off)
     const double u0 = s2 * (double)mu;                                  // :40
     const double q0 = s0 * s0, q1 = s1 * s1;
-    const float a = (float)sqrt(q0 + q1);                               // :42
+    const double q = q0 + q1;
+    // Fast path: when every cone of the wave is inside with a margin that the float rounding of the norm cannot bridge
+    // (sqrt(q) <= u0 (1 - 2^-21) => (float)sqrt(q) <= u0; u0 above 1e-30 and q below 1e70 keep the float normal and finite), the projection is the
+    // identity (:49) and the square root is never needed.  NaNs fail the test and take the exact path.
+    const bool sure_inside = (u0 > 1e-30) && (q <= (u0 * u0) * (1.0 - 0x1p-20)) && (q < 1e70);
+    if (__builtin_amdgcn_ballot_w64(!sure_inside) == 0ull) return mine;
+    const float a = (float)sqrt(q);                                     // :42
     const double ad = (double)a;
     const bool below = ad <= -u0, inside = ad <= u0;                    // :46 | :49
     const bool outside = !below && !inside && (ad >= fabs(u0));         // :52 (else :58 -> 0)
