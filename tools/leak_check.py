@@ -28,6 +28,7 @@ def cycle(i):
         s.set_tv_linear_constraints(np.ones((N, nx)), np.full((1, N), 3.0), np.ones((N - 1, nu)), np.full((1, N - 1), 6.0))
         s.update_settings(max_iter=5, en_state_linear=i % 2, en_tv_input_linear=1 - i % 2)
         s.set_option("debug", 1)
+        s.set_option("repack_after", 2)                         # the split solve's index lists
     s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
     s.solve()
     if i % 3 == 1:
