@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""CPU only: register / scratch / occupancy report of every kernel instantiation compiled into the library
+(hipcc -Rpass-analysis=kernel-resource-usage on tinympc_amd/csrc/_gen/{k,t}_*.hip).  Scratch > 0 = spilled to memory.
+    python tools/register_audit.py [--all] > profiles/rNN_register_audit.md"""
+import concurrent.futures
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tinympc_amd", "csrc", "_gen")
+
+
+def usage(src):
+    with tempfile.TemporaryDirectory() as tmp:
+        p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+                            "-c", src, "-o", os.path.join(tmp, "o.o")], capture_output=True, text=True, cwd=GEN)
+    rows = []
+    for b in p.stderr.split("Function Name:")[1:]:
+        name = b.split()[0]
+        g = lambda k: int(re.search(k + r": (\d+)", b).group(1))
+        rows.append(dict(kind="tile" if "tile_kernel" in name else "one-row", args=[int(v) for _, v in re.findall(r"L([ib])(\d+)E", name)],
+                         vgpr=g("VGPRs"), agpr=g("AGPRs"), scratch=g(r"ScratchSize \[bytes/lane\]"), occ=g(r"Occupancy \[waves/SIMD\]"),
+                         lds=g(r"LDS Size \[bytes/block\]")))
+    return rows
+
+
+def main():
+    srcs = sorted(glob.glob(os.path.join(GEN, "k_*.hip")) + glob.glob(os.path.join(GEN, "t_*.hip")))
+    if not srcs:
+        sys.exit("build the library first (tinympc_amd/csrc/_gen is empty)")
+    with concurrent.futures.ThreadPoolExecutor(8) as ex:
+        rows = [r for rs in ex.map(usage, srcs) for r in rs]
+    show_all = "--all" in sys.argv
+    print(f"{len(rows)} kernel instantiations, {sum(r['scratch'] > 0 for r in rows)} with scratch (memory spills)\n")
+    print("one-row kernel `admm_solve_kernel<NX,NU,N,SOC,DBG,MODE,LIN,HET,KMAX>` -- default variant (box constraints, MODE 2) and its cone variant:\n")
+    print("| (nx,nu,N) | variant | VGPR | AGPR | scratch B/lane | waves/SIMD | LDS B |")
+    print("|---|---|---|---|---|---|---|")
+    for r in sorted((r for r in rows if r["kind"] == "one-row"), key=lambda r: (r["args"][:3], r["args"][3:])):
+        a = r["args"]
+        tag = {(0, 0, 2, 0, 0): "box", (1, 0, 2, 0, 0): "cone"}.get(tuple(a[3:8]))
+        if tag is None and not show_all:
+            continue
+        tag = tag or f"soc{a[3]} dbg{a[4]} mode{a[5]} lin{a[6]} het{a[7]}"
+        print(f"| ({a[0]},{a[1]},{a[2]}) | {tag} | {r['vgpr']} | {r['agpr']} | {r['scratch']} | {r['occ']} | {r['lds']} |")
+    print("\ntile kernel `admm_tile_kernel<NX,NU,N,W,R>`:\n")
+    print("| (nx,nu,N) | W x R | VGPR | AGPR | scratch B/lane | waves/SIMD | LDS B |")
+    print("|---|---|---|---|---|---|---|")
+    for r in sorted((r for r in rows if r["kind"] == "tile"), key=lambda r: r["args"]):
+        a = r["args"]
+        print(f"| ({a[0]},{a[1]},{a[2]}) | {a[3]} x {a[4]} | {r['vgpr']} | {r['agpr']} | {r['scratch']} | {r['occ']} | {r['lds']} |")
+
+
+if __name__ == "__main__":
+    main()
