@@ -36,6 +36,21 @@ def flops_per_iter(nx, nu, N):
             + (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nx + 2 * nu) + 11 * S)
 
 
+def steps_per_launch(steps, warmup, requested=0):
+    """MPC steps fused into one launch: `requested`, or (0 = auto) the largest common divisor of --steps and --warmup that is
+    <= 100 (the reference episode length), so that the timed region is exactly --steps steps in whole launches.  None if a
+    requested value does not divide both."""
+    T = requested
+    if T <= 0:
+        import math
+        g = math.gcd(steps, warmup) if warmup else steps
+        T = max(d for d in range(1, 101) if g % d == 0)
+    T = max(1, T)
+    if steps % T or (warmup % T and warmup):
+        return None
+    return T
+
+
 def main():
     # stdout carries exactly ONE line, the result JSON: libraries that chat on fd 1 (RCCL prints a version banner at
     # communicator creation) are pointed at stderr for the whole run
@@ -101,14 +116,8 @@ def main():
     for kv in args.opt:                              # experiments: --opt grid_waves_per_cu=8
         k, v = kv.split("=")
         s.set_option(k, int(v))
-    T = args.steps_per_launch
-    if T <= 0:
-        import math
-        T = math.gcd(args.steps, args.warmup) if args.warmup else args.steps
-        while T > 100:                          # keep launches at <= 100 MPC steps (the reference episode length)
-            T = next(d for d in range(T // 2, 0, -1) if T % d == 0)
-    T = max(1, T)
-    if args.steps % T or (args.warmup % T and args.warmup):
+    T = steps_per_launch(args.steps, args.warmup, args.steps_per_launch)
+    if T is None:
         sys.exit("--steps and --warmup must be multiples of --steps-per-launch")
     s.set_option("steps_per_launch", T)
     stream = torch.cuda.Stream(device=local_rank)
