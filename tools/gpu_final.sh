@@ -21,5 +21,10 @@ for mode in fused step; do
 done
 cd $R
 timeout 600 python tools/config_bench.py $O/configs_3_4.json > /dev/null 2> $O/configs.err
+# BASELINE config 5 (36-cell sweep), plain and as split solves; skipped with FINAL_QUICK=1 (about 25 s of GPU time each)
+if [ -z "$FINAL_QUICK" ]; then
+  timeout 300 python tools/sweep_bench.py --out $O/sweep_config5.json > $O/sweep_config5.md 2> $O/sweep.err
+  TINYMPC_OPTS=repack_after=32 timeout 300 python tools/sweep_bench.py --out $O/sweep_config5_split_solve.json > $O/sweep_config5_split_solve.md 2>> $O/sweep.err
+fi
 TINYMPC_AMD_LIB=$R/tinympc_amd/libtinympc_amd_clk.so timeout 300 python tools/phase_clocks.py > $O/phase_clocks.txt 2>&1
 find $O -name "*.csv" | head -20
