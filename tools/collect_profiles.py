@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/final (tools/gpu_final.sh) -> profiles/r01_final_* and profiles/traffic.json."""
+"""gpurun_out/final (tools/gpu_final.sh) -> profiles/<tag>_* and profiles/traffic.json.
+    python tools/collect_profiles.py [tag = r01_final]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
@@ -25,7 +26,8 @@ def pmc_per_launch(dirname, counter, kernel="admm_solve_kernel"):
 
 
 for name in ("pytest_gpu.txt", "smoke.txt", "bench_default.json", "bench_per_step.json", "bench_regimes.json", "bench_torchrun1.json",
-             "configs_3_4.json", "phase_clocks.txt"):
+             "configs_3_4.json", "phase_clocks.txt", "sweep_config5.json", "sweep_config5.md", "sweep_config5_split_solve.json",
+             "sweep_config5_split_solve.md"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_{name}"))
 for mode in ("fused", "step"):
