@@ -54,6 +54,20 @@ __global__ void k(double* out, long long* cyc, int iters) {
                 "v_fmac_f64_dpp %0, %3, %2 row_newbcast:14 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %3, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
                 "v_add_f64 %0, %0, %1\n v_mul_f64 %1, %0, %3\n")
                          : "+&v"(a0), "+&v"(a1) : "v"(s), "v"(m));
+        } else if constexpr (TEST == 10 || TEST == 11 || TEST == 12) {
+            // what does the leading "s_nop 1" of a DPP block cost?  16-FMA single-chain blocks (the sweep's shape), the chain's
+            // result being the next block's DPP source: 10 = with the nop (as shipped), 11 = block source not written in between
+            // (no hazard, no nop: the floor), 12 = two independent FP64 adds in the nop's place (the hazard's wait states filled
+            // with useful work)
+#define BLK16(SRC) REP16("v_fmac_f64_dpp %0, " SRC ", %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+            if constexpr (TEST == 10)
+                asm volatile(REP4("s_nop 1\n" BLK16("%1") "v_mov_b64 %1, %0\n") : "+&v"(a0), "+&v"(a1) : "v"(s), "v"(m));
+            else if constexpr (TEST == 11)
+                asm volatile(REP4(BLK16("%2") "v_mov_b64 %1, %0\n") : "+&v"(a0), "+&v"(a1) : "v"(s), "v"(m));
+            else
+                asm volatile(REP4("v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                                  REP16("v_fmac_f64_dpp %0, %1, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n") "v_mov_b64 %1, %0\n")
+                             : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(s), "v"(m));
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -87,5 +101,8 @@ int main() {
     run<7>("v_mov_b64 independent x8", 128);
     run<8>("v_max_f64 |abs| dependent chain", 128);
     run<9>("backward-step shape (18 FP64 + 2 s_nop)", 4 * 20);
+    run<10>("16-FMA DPP block + mov, s_nop 1 in front (cycles per block)", 4);
+    run<11>("16-FMA DPP block + mov, no hazard, no nop (cycles per block)", 4);
+    run<12>("16-FMA DPP block + mov, 2 adds instead of the nop (cycles per block)", 4);
     return 0;
 }
