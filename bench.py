@@ -6,9 +6,20 @@ A "step" = ONE batched tiny_solve over the whole per-GPU batch (one MPC step of 
 examples/quadrotor_hovering.cpp, warm-started from the previous step, plant advanced on device).
 The timed region always starts from the cold state of tiny_setup, so K steps = the first K steps of
 the reference's 100-step episode (K = 100 -> 882 ADMM iterations per instance).
-State is resident in HBM before timing starts.  Multi-GPU: one process per GPU, batch sharded with
-no data-path collective (weak scaling: 65 536 instances per GPU); the RCCL all-reduces (SUM, MAX) of the 80-byte
-residual / iteration statistics vector close the timed region.
+State is resident in HBM before timing starts.  The K-step region is repeated (cold start, barrier,
+K steps, statistics exchange, barrier) until at least --min-seconds of timed work has run; `value`
+comes from the MEDIAN repetition, min / max are reported beside it.  Multi-GPU: one process per GPU,
+batch sharded with no data-path collective (weak scaling: 65 536 instances per GPU); ONE RCCL
+all-gather of the 64-byte statistics message closes every timed repetition.
+
+Rooflines (all in the one JSON line):
+  roofline         the bound that BINDS the timed launches: FP64 VALU issue when the launches carry many
+                   ADMM iterations (cold / fused steps), HBM when they are single warm steps; `traffic` = HBM
+                   bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json)
+  roofline_hbm / roofline_fp64   both fractions of the timed launches, whichever binds
+  regimes          an untimed replay of the reference episode with ONE launch per MPC step after the
+                   timed region: cold steps 0-4 (FP64 fraction) and steady state steps 70-99 (HBM fraction
+                   of real, algorithmic bytes -- every launch loads and stores the records)
 
   python bench.py --gpus 1 --steps 100 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -51,6 +62,22 @@ def steps_per_launch(steps, warmup, requested=0):
     return T
 
 
+def traffic_per_launch(T, B):
+    """PMC-measured HBM bytes per launch of the solve kernel (rocprofv3 FETCH_SIZE / WRITE_SIZE passes,
+    tools/collect_profiles.py).  A launch loads and stores the records once however many MPC steps it fuses."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath) or B != 65536:
+        return None
+    try:
+        t = json.load(open(tpath))
+        for key in (("fused_launch", "fused_100_steps_launch") if T > 1 else ("per_step_launch",)):
+            if key in t:
+                return t[key]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     # stdout carries exactly ONE line, the result JSON: libraries that chat on fd 1 (RCCL prints a version banner at
     # communicator creation) are pointed at stderr for the whole run
@@ -68,9 +95,11 @@ def main():
                     help="closed-loop MPC steps fused into one kernel launch (ADMM state stays in registers); "
                          "0 = auto: the largest divisor of --steps and --warmup that is <= 100; 1 = one launch per step")
     ap.add_argument("--opt", action="append", default=[], help="solver option name=value (experiments)")
-    ap.add_argument("--regimes", action="store_true",
-                    help="after the timed region, replay the episode with one launch per MPC step and report the cold / "
-                         "steady-state regimes separately (adds 100 launches of the same kernel to a profile)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the timed K-step region until this much timed work has run (median reported)")
+    ap.add_argument("--max-repeats", type=int, default=2000)
+    ap.add_argument("--no-regimes", action="store_true", help="skip the untimed one-launch-per-step replay")
+    ap.add_argument("--regimes", action="store_true", help="(kept for old command lines: the replay is always on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -84,11 +113,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    # CPU baseline first (rank 0, N=1 only), before any HIP context exists in this process.
+    # CPU baseline first (rank 0, N=1 only), before any HIP context exists in this process: the real reference on
+    # every host core, the SAME workload as the timed region (the first --steps MPC steps of the episode from cold)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import cpu_baseline
-        cpu = cpu_baseline.run(seconds=args.cpu_seconds)
+        cpu = cpu_baseline.run(seconds=args.cpu_seconds, steps=args.steps)
 
     import numpy as np
     import torch
@@ -120,11 +150,13 @@ def main():
     if T is None:
         sys.exit("--steps and --warmup must be multiples of --steps-per-launch")
     s.set_option("steps_per_launch", T)
+    launches = args.steps // T
     stream = torch.cuda.Stream(device=local_rank)
     s.set_stream(stream.cuda_stream)                 # kernels, events and the RCCL collective share one stream
     xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
     x0 = np.array(h["x0"], dtype=np.float64)
-    stats = torch.zeros(10, dtype=torch.float64, device=f"cuda:{local_rank}")
+    dev = f"cuda:{local_rank}"
+    stats = torch.zeros(10, dtype=torch.float64, device=dev)
 
     def cold_start():
         s.reset()
@@ -137,6 +169,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(values):
+        if dist is None:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def timed_repetition():
+        """cold start (untimed) -> barrier -> EXACTLY --steps MPC steps + the statistics exchange -> barrier."""
+        cold_start()
+        s.set_option("timing", launches)             # HIP events around every timed solve kernel, on `stream`
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            s.solve_async()
+        s.reduce_stats_async(stats.data_ptr())
+        if dist is not None:                         # the one exchange of the path: a 64-byte message per rank, RCCL over xGMI
+            st = allreduce_stats(stats, dist)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is None:
+            st = stats.to("cpu")
+        return elapsed, st.tolist(), s.timing_ms()
+
     with torch.cuda.stream(stream):
         cold_start()
         for _ in range(args.warmup // T):
@@ -145,65 +201,84 @@ def main():
         if dist is not None:                         # first-use costs of the collective stay out of the timed region
             s.reduce_stats_async(stats.data_ptr())
             allreduce_stats(stats, dist)
-        cold_start()
-        s.set_option("timing", args.steps // T)      # HIP events around every timed solve kernel, on `stream`
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps // T):
-            s.solve_async()
-        s.reduce_stats_async(stats.data_ptr())
-        if dist is not None:                         # the one exchange of the path: the 80-byte statistics vectors
-            stats = allreduce_stats(stats, dist)     # RCCL over xGMI: SUM of counts, MAX of residuals
-        barrier()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    st = stats.tolist()
-    acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]
+        e0, st, km = timed_repetition()
+        e0 = max_over_ranks([e0])[0]
+        repeats = int(min(max(3, -(-args.min_seconds // max(e0, 1e-6))), args.max_repeats))
+        rep_s, rep_kernel_ms = [e0], [km]
+        for _ in range(repeats - 1):
+            e, st, km = timed_repetition()
+            rep_s.append(e)
+            rep_kernel_ms.append(km)
+    rep_s = np.array(max_over_ranks(rep_s))          # every repetition: the slowest rank's clock
+    elapsed = float(np.median(rep_s))
+    acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]        # job-wide, one repetition (each starts with a reset)
+    kern_ms = np.concatenate(rep_kernel_ms)          # this rank's solve-kernel durations, all repetitions
+    kern_first = np.array([k[0] for k in rep_kernel_ms])
+    kern_sum_rep = float(np.median([k.sum() for k in rep_kernel_ms]))
 
-    kern_ms = s.timing_ms()
-    # --regimes: after the timed region (rank 0 only, untimed): the same episode with ONE launch per MPC step, so that the two
-    # regimes SURVEY.md 8(d) asks for are visible separately -- cold steps (100 ADMM iterations each, FP64 bound) and
-    # steady state (1-2 iterations, every launch loads and stores the records: the real HBM roofline of this path).
+    # Untimed replay (rank 0): the same episode with ONE launch per MPC step, so that the two regimes SURVEY.md 8(d) asks
+    # for are visible in every line -- cold steps (100 ADMM iterations each, FP64 bound) and steady state (1-2 iterations:
+    # every launch loads and stores the records, the real HBM roofline of this path).  Median over five replays.
     regimes = None
-    if args.regimes and rank == 0 and T > 1 and args.steps >= 100:
+    fl = flops_per_iter(nx, nu, N)
+    bytes_warm = s.algorithmic_bytes(cold=False)
+    if rank == 0 and not args.no_regimes:
+        def replay(lean):
+            runs = []
+            s.set_option("store_primal", 0 if lean else 1)
+            for _ in range(5):
+                cold_start()
+                s.set_option("timing", 100)
+                for _ in range(100):
+                    s.solve_async()
+                s.synchronize()
+                runs.append(s.timing_ms())
+            s.set_option("store_primal", 1)
+            return np.median(np.array(runs), axis=0)
         with torch.cuda.stream(stream):
-            cold_start()
             s.set_option("steps_per_launch", 1)
-            s.set_option("timing", 100)
-            for _ in range(100):
-                s.solve_async()
-            s.synchronize()
-            ms = s.timing_ms()
+            ms = replay(False)
+            ms_lean = replay(True)
             s.set_option("steps_per_launch", T)
-        fl1 = flops_per_iter(nx, nu, N)
-        bw = s.algorithmic_bytes(cold=False) * B
-        warm = float(ms[70:].mean()) * 1e-3
+        S = nx * N + nu * (N - 1)
         cold = float(ms[:5].mean()) * 1e-3
+        warm = float(ms[70:].mean()) * 1e-3
+        lean = float(ms_lean[70:].mean()) * 1e-3
         regimes = {
             "cold": {"steps": "0-4", "admm_iters_per_solve": 100, "ms_per_launch": cold * 1e3,
-                     "fp64_tflops": 100 * B * fl1 / cold / 1e12, "fp64_frac": 100 * B * fl1 / cold / 1e12 / FP64_PEAK_TFLOPS},
-            "steady_state": {"steps": "70-99", "ms_per_launch": warm * 1e3, "hbm_gbs": bw / warm / 1e9,
-                             "hbm_frac": bw / warm / 1e9 / HBM_PEAK_GBS,
-                             "note": "one launch per MPC step: every launch moves bytes_warm per solve through HBM"}}
+                     "fp64_tflops": 100 * B * fl / cold / 1e12, "fp64_frac": 100 * B * fl / cold / 1e12 / FP64_PEAK_TFLOPS},
+            "steady_state": {"steps": "70-99", "ms_per_launch": warm * 1e3, "ms_per_launch_min": float(ms[70:].min()),
+                             "algorithmic_bytes_per_solve": bytes_warm,
+                             "hbm_gbs": bytes_warm * B / warm / 1e9, "hbm_frac": bytes_warm * B / warm / 1e9 / HBM_PEAK_GBS,
+                             "note": "one launch per MPC step; bytes_warm = 8(nx+8S)+44 per solve (SURVEY.md 8(d)) / launch time; a "
+                                     "solve that converges at its first check does not store v|z again (admm.cpp:431-441 returns "
+                                     "before v = vnew), so the bytes really moved are up to 8S = %d B per solve lower" % (8 * S)},
+            "steady_state_lean": {"steps": "70-99", "ms_per_launch": lean * 1e3, "ms_per_launch_min": float(ms_lean[70:].min()),
+                                  "hbm_gbs": bytes_warm * B / lean / 1e9, "hbm_frac": bytes_warm * B / lean / 1e9 / HBM_PEAK_GBS,
+                                  "bytes_moved_per_solve_max": bytes_warm - 8 * S,
+                                  "note": "option store_primal = 0: x|u is not written back either (no consumer between steps: the "
+                                          "plant step runs on the device, solution->x|u = vnew|znew is still stored); the figure is "
+                                          "still bytes_warm / launch time, i.e. solves/s in the formula's units"}}
     solves = float(world) * B * args.steps
     value = solves / elapsed
-    alg_bytes = s.algorithmic_bytes(cold=False) * B * T        # per launch: SURVEY.md 8(d) bytes_warm x solves per launch
     avg_kernel_s = float(kern_ms.mean()) * 1e-3
-    achieved_gbs = alg_bytes / avg_kernel_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch (rocprofv3 passes)
-    if os.path.exists(tpath) and B == 65536:
-        try:
-            key = {1: "per_step_launch", 100: "fused_100_steps_launch"}.get(T)
-            traffic = json.load(open(tpath))[key]["hbm_bytes_per_launch"] if key else None
-        except Exception:
-            traffic = None
-    fl = flops_per_iter(nx, nu, N)
-    iters_local = acc_iters / world
-    fp64_tflops = iters_local * fl / float(kern_ms.sum() * 1e-3) / 1e12
+    # real HBM bytes of one launch: the records are loaded and stored once however many MPC steps it fuses
+    hbm_gbs = bytes_warm * B / avg_kernel_s / 1e9
+    iters_local = acc_iters / world                  # one repetition, this GPU
+    fp64_tflops = iters_local * fl / (kern_sum_rep * 1e-3) / 1e12
+    traffic = traffic_per_launch(T, B)
+    common = {"traffic": traffic, "kernel": "admm_solve_kernel<12,4,10>", "avg_launch_ms": avg_kernel_s * 1e3,
+              "launches_per_repetition": launches, "mpc_steps_per_launch": T}
+    roofline_hbm = dict({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": bytes_warm * B,
+                         "note": "bytes_warm = 8(nx+8S)+44 = %d B per instance and LAUNCH (the ADMM state stays in registers "
+                                 "between the MPC steps a launch fuses) / average launch time" % bytes_warm}, **common)
+    roofline_fp64 = dict({"bound": "fp64-valu", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": fp64_tflops / FP64_PEAK_TFLOPS, "flops_per_admm_iter": fl,
+                          "admm_iters_per_launch_and_instance": iters_local / B / launches,
+                          "note": "ADMM iterations x %d FLOP (SURVEY.md 8 footnote 1) / summed kernel time of one repetition" % fl},
+                         **common)
+    binding = roofline_fp64 if roofline_fp64["frac"] >= roofline_hbm["frac"] else roofline_hbm
     if rank == 0:
         out = {
             "metric": "QP solves/sec (+ ADMM iters/sec), 64k-batch quadrotor hover",
@@ -215,24 +290,20 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}",
                        "grid_waves_per_cu": args.grid_waves_per_cu, "dpp_mode": args.dpp_mode,
                        "mpc_steps_per_launch": T},
+            "timed_region": {"repeats": int(repeats), "seconds_total": float(rep_s.sum()),
+                             "ms": {"median": elapsed * 1e3, "min": float(rep_s.min()) * 1e3, "max": float(rep_s.max()) * 1e3},
+                             "value_min": solves / float(rep_s.max()), "value_max": solves / float(rep_s.min()),
+                             "note": "each repetition = cold start (untimed), barrier, exactly --steps MPC steps + the statistics "
+                                     "exchange, barrier; value and ms_per_step come from the median repetition"},
             "admm_iters_per_s": acc_iters / elapsed,
             "admm_iters_per_solve": acc_iters / solves,
             "solved_fraction": acc_solved / solves,
             "max_residuals": max_resid,
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "admm_solve_kernel<12,4,10>", "avg_launch_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "launches": args.steps // T,
-                         "note": "bytes_warm = 8*(nx+8S)+44 = 10124 B per solve x solves per launch; the launches "
-                                 "that hold the first MPC steps (100 ADMM iterations each) are FP64-issue bound, "
-                                 "see roofline_fp64; with mpc_steps_per_launch > 1 the state stays in registers "
-                                 "between fused steps, so real HBM traffic is below the algorithmic figure"},
-            "roofline_fp64": {"bound": "fp64-valu", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": fp64_tflops / FP64_PEAK_TFLOPS,
-                              "flops_per_admm_iter": fl},
-            "kernel_ms": {"first": float(kern_ms[0]), "last": float(kern_ms[-1]), "sum": float(kern_ms.sum()),
-                          "min": float(kern_ms.min())},
+            "roofline": binding,
+            "roofline_hbm": roofline_hbm,
+            "roofline_fp64": roofline_fp64,
+            "kernel_ms": {"first_launch_median": float(np.median(kern_first)), "sum_per_repetition_median": kern_sum_rep,
+                          "min": float(kern_ms.min()), "max": float(kern_ms.max()), "count": int(kern_ms.size)},
         }
         if regimes is not None:
             out["regimes"] = regimes

@@ -194,7 +194,11 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * bit-identical to the unsplit solve; K is rounded down to a multiple of check_termination.  Worth it for cold solves
  * with a tail of slow instances (config 3: -16 %), not for warm MPC steps (every stage is a launch).  One-row kernel,
  * single-step launches without "advance_x0" / "one_shot"; ignored elsewhere.  "repack_growth" (default 2) and
- * "repack_waves_per_cu" (default 8) tune the stage schedule and the grid of the follow-up launches). */
+ * "repack_waves_per_cu" (default 8) tune the stage schedule and the grid of the follow-up launches),
+ * "store_primal" (default 1; 0: launches do not write work->x|u back -- between closed-loop steps with "advance_x0" it has
+ * no consumer, the plant step and solution->x|u = vnew|znew are still written; tiny_batch_get(TINY_F_X / TINY_F_U) then
+ * returns stale data.  Ignored while a cone / half-space family is enabled, whose slack the next solve initialises from x|u).
+ * A solve that converges at its first termination check never stores v|z: the reference returns before v = vnew. */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
 /* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state
@@ -229,6 +233,56 @@ int tiny_jit_used(char* out, int out_len);                   /* returns the numb
 /* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
  * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */
 long tiny_batch_algorithmic_bytes(TinyBatch* b, int cold);   /* cold: 0 bytes_warm, 1 bytes_cold (one_shot = 2), 2 one_shot = 1 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* (C) Multi-GPU.  The path shards embarrassingly: instances are independent QPs, so a batch is
+ * split over the GPUs with NO data-path collective; the only exchange is one 64-byte statistics message per shard --
+ * {sum iter, sum solved, accumulated iterations, accumulated solves, the four residual maxima} -- moved by ONE RCCL
+ * all-gather over xGMI and reduced (SUM / MAX) on the host.
+ *
+ * TinyGroup: ONE host process (the reference's callers are single-process C++ programs, examples/quadrotor_hovering.cpp)
+ * drives several GPUs.  Each shard is an ordinary TinyBatch on its own device and stream (tiny_group_shard): a group
+ * solve enqueues every shard without waiting.  interleaved = 0: contiguous blocks of instances per shard; 1: instance i
+ * lives on shard i % n_shards (round-robin: balances batches whose iteration counts diverge).  devices == NULL: shard k
+ * on GPU k % device_count; n_shards <= 0: one shard per GPU.  Shards that share a GPU (more shards than GPUs) exchange
+ * through host memory -- RCCL refuses two ranks on one device -- with the identical reduction. */
+typedef struct TinyGroup TinyGroup;
+int tiny_group_setup(TinyGroup** out, const double* Adyn, const double* Bdyn, const double* fdyn, const double* Qdiag,
+                     const double* Rdiag, double rho, int nx, int nu, int N, int batch, const int* devices, int n_shards,
+                     int interleaved, int verbose);
+int tiny_group_destroy(TinyGroup* g);
+int tiny_group_shards(TinyGroup* g);                          /* number of shards */
+TinyBatch* tiny_group_shard(TinyGroup* g, int k);             /* shard k: every tiny_batch_* call works on it */
+int tiny_group_shard_indices(TinyGroup* g, int k, int* idx, int capacity);   /* caller-order instance ids of shard k; returns its size */
+int tiny_group_uses_rccl(TinyGroup* g);                       /* 1: the exchange is an RCCL all-gather, 0: host memory (shared devices) */
+const char* tiny_group_last_error(TinyGroup* g);
+/* problem-family setters and options: forwarded to every shard (same meaning as the tiny_batch_* functions) */
+int tiny_group_set_bound_constraints(TinyGroup* g, const double* x_min, const double* x_max, const double* u_min, const double* u_max);
+int tiny_group_set_cone_constraints(TinyGroup* g, int n_state_cones, const int* Acx, const int* qcx, const double* cx,
+                                    int n_input_cones, const int* Acu, const int* qcu, const double* cu);
+int tiny_group_set_linear_constraints(TinyGroup* g, int n_state, const double* Alin_x, const double* blin_x,
+                                      int n_input, const double* Alin_u, const double* blin_u);
+int tiny_group_set_tv_linear_constraints(TinyGroup* g, int n_state, const double* tv_Alin_x, const double* tv_blin_x,
+                                         int n_input, const double* tv_Alin_u, const double* tv_blin_u);
+int tiny_group_update_settings(TinyGroup* g, double abs_pri_tol, double abs_dua_tol, int max_iter, int check_termination,
+                               int en_state_bound, int en_input_bound, int en_state_soc, int en_input_soc,
+                               int en_state_linear, int en_input_linear, int en_tv_state_linear, int en_tv_input_linear);
+int tiny_group_set_option(TinyGroup* g, const char* name, long value);
+/* per-instance data with the FULL batch axis, host memory, the caller's instance order (flags: TINY_HOST or TINY_BROADCAST) */
+int tiny_group_set(TinyGroup* g, TinyField field, const double* src, int flags);
+int tiny_group_get(TinyGroup* g, TinyField field, double* dst);
+int tiny_group_reset(TinyGroup* g);
+/* == tiny_solve on every shard; tiny_group_solve returns 0 when every instance on every GPU converged, else 1 */
+int tiny_group_solve(TinyGroup* g);
+int tiny_group_solve_async(TinyGroup* g);
+int tiny_group_synchronize(TinyGroup* g);
+int tiny_group_get_status(TinyGroup* g, int* iter, int* solved, int* status, double* residuals);   /* caller order */
+/* the one exchange: out10 = job-wide statistics in the tiny_batch_reduce_stats layout (waits for every shard) */
+int tiny_group_allreduce_stats(TinyGroup* g, double* out10);
+/* One process per GPU (MPI / torchrun-style hosts): the same 64-byte exchange on a communicator the CALLER created with
+ * ncclCommInitRank; rccl_comm = its ncclComm_t.  Enqueued on the batch's stream behind the solve, returns when the
+ * stream has drained, the same job-wide vector on every rank.  total_batch = the unsharded batch size. */
+int tiny_batch_allreduce_stats(TinyBatch* b, void* rccl_comm, int n_ranks, int rank, long total_batch, double* out10);
 
 /* ------------------------------------------------------------------------------------------ */
 /* (B) Reference entry points over plain-data mirrors of the reference structs.

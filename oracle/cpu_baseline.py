@@ -1,8 +1,11 @@
 """TEST/BENCH INFRASTRUCTURE -- times the CPU path on the hover workload (bench.py's cpu_baseline leg).
 
 One PROCESS per core (threads of one process contend on the reference's std::cout and malloc,
-SURVEY.md section 6), each running whole 100-step quadrotor-hover closed-loop episodes
-(examples/quadrotor_hovering.cpp) for a bounded wall time.  kind = "reference" runs the real TinyMPC
+SURVEY.md section 6), each running `steps`-step quadrotor-hover closed-loop episodes from the cold
+state of tiny_setup (examples/quadrotor_hovering.cpp) -- the SAME first-K-steps workload bench.py
+times on the GPU, so ADMM iterations per solve are equal on both sides -- for a bounded time.  Like the
+GPU side's cold start, building the fresh solver of an episode is outside the clock: only the
+closed-loop solves are timed.  kind = "reference" runs the real TinyMPC
 (oracle/_ref/libtinympc_ref.so, stdout muted) when that library exists, else "port" runs the C
 restatement (oracle/liboracle.so).
 """
@@ -27,17 +30,19 @@ def _worker(args):
     cfg = sc._hover_cfg(prob, extra)
     h = extra["hover"]
     solves = iters = 0
-    t0 = time.perf_counter()
+    busy = 0.0
     while True:
         s = sc.make_solver(cls, prob, cfg)          # fresh cold workspace per episode, like the example's main()
         s["Xref"] = np.tile(np.array(h["xref"], dtype=np.float64).reshape(-1, 1), (1, prob["N"]))
+        t0 = time.perf_counter()
         total, _, _, _ = s.closed_loop(h["x0"], steps)
+        busy += time.perf_counter() - t0
         s.close()
         solves += steps
         iters += total
-        if time.perf_counter() - t0 >= seconds:
+        if busy >= seconds:
             break
-    return solves, iters, time.perf_counter() - t0
+    return solves, iters, busy
 
 
 def run(seconds=8.0, steps=100, cores=None):
@@ -53,11 +58,12 @@ def run(seconds=8.0, steps=100, cores=None):
     solves = sum(r[0] for r in res)
     iters = sum(r[1] for r in res)
     single = max(r[0] / r[2] for r in res)
-    return dict(value=solves / wall, unit="QP solves/s", cores=cores, kind=kind,
-                sample=f"{solves // steps} closed-loop hover episodes x {steps} MPC steps "
-                       f"(quadrotor nx=12 nu=4 N=10, {iters / max(solves, 1):.2f} ADMM iters/solve) over {wall:.1f} s, "
-                       f"one process per core",
-                admm_iters_per_s=iters / wall, best_single_core_solves_per_s=single)
+    rate = sum(r[0] / r[2] for r in res)             # every core runs concurrently: the rates add
+    return dict(value=rate, unit="QP solves/s", cores=cores, kind=kind,
+                sample=f"{solves // steps} closed-loop hover episodes x the first {steps} MPC steps from a cold start "
+                       f"(quadrotor nx=12 nu=4 N=10), {wall:.1f} s of solve time per core, one process per core",
+                admm_iters_per_solve=iters / max(solves, 1),
+                admm_iters_per_s=sum(r[1] / r[2] for r in res), best_single_core_solves_per_s=single)
 
 
 if __name__ == "__main__":

@@ -20,10 +20,21 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "g
 
 
 def main():
+    """python oracle/gen_golden.py [--only name,name,...]   (--only: just those single-solve suites of section 2)"""
     if build_ref() is None:
         sys.exit("oracle/_ref/libtinympc_ref.so missing and /root/reference absent")
     os.makedirs(OUT, exist_ok=True)
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    if only is None:
+        cache_kats()
+    single_solve_suites(only)
+    if only is None:
+        episode_and_phase_kats()
 
+
+def cache_kats():
     # 1. cache known-answer values (tiny_api.cpp:307-381) for the four problem families
     kat = {}
     for name in ("codegen_random", "cartpole", "quadrotor_20hz", "rocket_landing_20hz"):
@@ -34,6 +45,8 @@ def main():
         s.close()
     np.savez_compressed(os.path.join(OUT, "cache_kat.npz"), **kat)
 
+
+def single_solve_suites(only=None):
     # 2. single-solve suites
     suites = {
         "hover_warm": sc.hover_suite(RefSolver),
@@ -49,11 +62,16 @@ def main():
         "sweep_8_4_30": sc.sweep_suite(8, 4, 30, B=3),
         "sweep_12_2_10": sc.sweep_suite(12, 2, 10, B=3),
         "sweep_20_8_10": sc.sweep_suite(20, 8, 10, B=2),
+        # one golden per tile-kernel shape class (tile_dims.txt): long one-row-wide (W=1,R=2), wide N=30 and wide N=50 (W=2,R=2)
+        "sweep_4_2_50": sc.sweep_suite(4, 2, 50, B=3),
+        "sweep_12_4_50": sc.sweep_suite(12, 4, 50, B=3),
+        "sweep_12_8_30": sc.sweep_suite(12, 8, 30, B=2),
+        "sweep_20_8_50": sc.sweep_suite(20, 8, 50, B=2),
         "linear_random_all": sc.random_linear_suite("quadrotor_20hz", B=4, seed=21),
         "linear_random_rocket_soc": sc.random_linear_suite("rocket_landing_20hz", B=4, seed=22, soc=True),
         "linear_random_tv_only": sc.random_linear_suite("cartpole", B=4, seed=23, static=False, box=False),
     }
-    for tv in (False, True):
+    for tv in ((False, True) if only is None else ()):
         subs, its, solved = sc.linear_example_suite(RefSolver, tv)
         for n, sub in enumerate(subs):
             suites[f"linear_example_{'tv' if tv else 'static'}_{n}"] = sub
@@ -61,6 +79,8 @@ def main():
               "converged-iteration sum", int(its[solved == 1].sum()))
     slim = ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc")
     for name, suite in suites.items():
+        if only is not None and name not in only:
+            continue
         soc = suite["config"]["en_state_soc"] or suite["config"]["en_input_soc"]
         fields = [f for f in slim if soc or f not in ("vcnew", "zcnew", "gc", "yc")]
         if suite["config"].get("en_state_linear") or suite["config"].get("en_input_linear"):
@@ -75,6 +95,8 @@ def main():
         print(f"{name:26s} B={len(out['iter'])} iters={out['iter'].astype(int).tolist()}"
               + (f" episode_total={int(ep['iters'].sum())}" if ep else ""))
 
+
+def episode_and_phase_kats():
     # 3. tracking episode summary (examples/quadrotor_tracking.cpp): per-step iterations
     prob, extra = sc.load_problem("quadrotor_20hz")
     cfg = sc._hover_cfg(prob, extra)

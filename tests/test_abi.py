@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     L = tm.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/tinympc_amd.h but not exported by libtinympc_amd.so"
-    assert set(tm.BATCH_SYMBOLS) | set(tm.REFERENCE_SYMBOLS) == set(names)
+    assert set(tm.BATCH_SYMBOLS) | set(tm.GROUP_SYMBOLS) | set(tm.REFERENCE_SYMBOLS) == set(names)
 
 
 def test_struct_sizes_match_reference_layout():

@@ -41,7 +41,13 @@ BATCH_SYMBOLS = (
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
-    "tiny_jit_compile", "tiny_jit_used")
+    "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats")
+GROUP_SYMBOLS = (
+    "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
+    "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
+    "tiny_group_set_linear_constraints", "tiny_group_set_tv_linear_constraints", "tiny_group_update_settings",
+    "tiny_group_set_option", "tiny_group_set", "tiny_group_get", "tiny_group_reset", "tiny_group_solve",
+    "tiny_group_solve_async", "tiny_group_synchronize", "tiny_group_get_status", "tiny_group_allreduce_stats")
 REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
@@ -111,6 +117,27 @@ def lib():
         L.tiny_jit_compile.argtypes = [C.c_char_p, _ip, C.c_char_p, C.c_int]
         L.tiny_jit_compile.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
+        L.tiny_batch_allreduce_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, _dp]
+        L.tiny_group_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _ip, C.c_int, C.c_int, C.c_int]
+        for name in ("tiny_group_destroy", "tiny_group_shards", "tiny_group_uses_rccl", "tiny_group_reset", "tiny_group_solve",
+                     "tiny_group_solve_async", "tiny_group_synchronize"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.tiny_group_shard.argtypes = [C.c_void_p, C.c_int]
+        L.tiny_group_shard.restype = C.c_void_p
+        L.tiny_group_shard_indices.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int]
+        L.tiny_group_last_error.argtypes = [C.c_void_p]
+        L.tiny_group_last_error.restype = C.c_char_p
+        L.tiny_group_set_bound_constraints.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.tiny_group_set_cone_constraints.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp]
+        L.tiny_group_set_linear_constraints.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        L.tiny_group_set_tv_linear_constraints.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        L.tiny_group_update_settings.argtypes = [C.c_void_p, C.c_double, C.c_double] + [C.c_int] * 10
+        L.tiny_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.tiny_group_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.tiny_group_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.tiny_group_get_status.argtypes = [C.c_void_p, _ip, _ip, _ip, _dp]
+        L.tiny_group_allreduce_stats.argtypes = [C.c_void_p, _dp]
         _lib = L
     return _lib
 
@@ -410,6 +437,145 @@ class TinyBatchSolver:
     def algorithmic_bytes(self, cold=False) -> int:
         """cold: False / 0 bytes_warm, True / 1 bytes_cold (one_shot = 2), 2 the traffic of one_shot = 1."""
         return int(lib().tiny_batch_algorithmic_bytes(self._h, int(cold)))
+
+
+class TinyGroupSolver:
+    """ctypes mirror of TinyGroup (include/tinympc_amd.h section C): ONE host process, the batch sharded over several
+    GPUs (contiguous blocks or round-robin), one RCCL all-gather of 64-byte statistics messages as the only exchange.
+    Per-instance arrays carry the FULL batch axis in the caller's order."""
+
+    def __init__(self, A, B, f, Q, R, rho, nx, nu, N, batch, devices=None, n_shards=0, interleaved=False, verbose=0):
+        self._h = C.c_void_p()
+        self.nx, self.nu, self.N, self.batch = int(nx), int(nu), int(N), int(batch)
+        A = _colmajor(A, (nx, nx))
+        Bm = _colmajor(B, (nx, nu))
+        fv = _f64(np.zeros(nx) if f is None else f).ravel()
+        Q, R = _f64(Q), _f64(R)
+        Qd = (np.diag(Q) if Q.ndim == 2 else Q).copy()
+        Rd = (np.diag(R) if R.ndim == 2 else R).copy()
+        dev = None
+        if devices is not None:
+            dev = np.ascontiguousarray(devices, dtype=np.int32)
+            n_shards = len(dev)
+        rc = lib().tiny_group_setup(C.byref(self._h), A.ctypes.data_as(_dp), Bm.ctypes.data_as(_dp), fv.ctypes.data_as(_dp),
+                                    Qd.ctypes.data_as(_dp), Rd.ctypes.data_as(_dp), float(rho), nx, nu, N, batch,
+                                    None if dev is None else dev.ctypes.data_as(_ip), int(n_shards), int(bool(interleaved)), verbose)
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise TinyMPCError(f"tiny_group_setup failed ({rc})")
+
+    @classmethod
+    def from_problem(cls, prob, batch, **kw):
+        return cls(prob["A"], prob["B"], prob.get("f"), prob["Q"], prob["R"], prob["rho"], prob["nx"], prob["nu"], prob["N"], batch, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tiny_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise TinyMPCError(f"{what} failed ({rc}): {lib().tiny_group_last_error(self._h).decode()}")
+
+    @property
+    def shards(self):
+        return int(lib().tiny_group_shards(self._h))
+
+    def uses_rccl(self):
+        return bool(lib().tiny_group_uses_rccl(self._h))
+
+    def shard_indices(self, k):
+        n = lib().tiny_group_shard_indices(self._h, k, None, 0)
+        idx = np.zeros(n, dtype=np.int32)
+        lib().tiny_group_shard_indices(self._h, k, idx.ctypes.data_as(_ip), n)
+        return idx
+
+    def set_bound_constraints(self, x_min, x_max, u_min, u_max):
+        nx, nu, N = self.nx, self.nu, self.N
+        xm, xM = _colmajor(x_min, (nx, N)), _colmajor(x_max, (nx, N))
+        um, uM = _colmajor(u_min, (nu, N - 1)), _colmajor(u_max, (nu, N - 1))
+        self._check(lib().tiny_group_set_bound_constraints(self._h, xm.ctypes.data_as(_dp), xM.ctypes.data_as(_dp),
+                                                           um.ctypes.data_as(_dp), uM.ctypes.data_as(_dp)), "set_bound_constraints")
+
+    def set_cone_constraints(self, Acx, qcx, cx, Acu, qcu, cu):
+        ai = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        Acx, qcx, Acu, qcu = ai(Acx), ai(qcx), ai(Acu), ai(qcu)
+        cx, cu = _f64(cx).ravel(), _f64(cu).ravel()
+        self._check(lib().tiny_group_set_cone_constraints(self._h, len(Acx), Acx.ctypes.data_as(_ip), qcx.ctypes.data_as(_ip),
+                                                          cx.ctypes.data_as(_dp), len(Acu), Acu.ctypes.data_as(_ip),
+                                                          qcu.ctypes.data_as(_ip), cu.ctypes.data_as(_dp)), "set_cone_constraints")
+
+    def update_settings(self, abs_pri_tol=1e-3, abs_dua_tol=1e-3, max_iter=1000, check_termination=1, en_state_bound=1,
+                        en_input_bound=1, en_state_soc=0, en_input_soc=0, en_state_linear=0, en_input_linear=0,
+                        en_tv_state_linear=0, en_tv_input_linear=0):
+        self._check(lib().tiny_group_update_settings(self._h, abs_pri_tol, abs_dua_tol, max_iter, check_termination, en_state_bound,
+                                                     en_input_bound, en_state_soc, en_input_soc, en_state_linear, en_input_linear,
+                                                     en_tv_state_linear, en_tv_input_linear), "update_settings")
+
+    def set_option(self, name, value):
+        self._check(lib().tiny_group_set_option(self._h, name.encode(), int(value)), f"set_option({name})")
+
+    def _shape(self, name):
+        if name == "x0":
+            return self.nx, 1
+        return (self.nx, self.N) if name in STATE_FIELDS else (self.nu, self.N - 1)
+
+    def set(self, name, value, broadcast=False):
+        r, c = self._shape(name)
+        a = np.asarray(value, dtype=np.float64)
+        flat = (np.ascontiguousarray(a.reshape(r, c).T) if broadcast else
+                np.ascontiguousarray(a.reshape(self.batch, r, c).transpose(0, 2, 1))).ravel()
+        self._check(lib().tiny_group_set(self._h, FIELD_ID[name], flat.ctypes.data_as(C.c_void_p), HOST | (BROADCAST if broadcast else 0)), f"set({name})")
+
+    def get(self, name):
+        r, c = self._shape(name)
+        out = np.zeros((self.batch, c, r))
+        self._check(lib().tiny_group_get(self._h, FIELD_ID[name], out.ctypes.data_as(C.c_void_p)), f"get({name})")
+        out = out.transpose(0, 2, 1)
+        return out[:, :, 0] if name == "x0" else out
+
+    def set_x0(self, x0, broadcast=False):
+        self.set("x0", x0, broadcast)
+
+    def set_x_ref(self, x_ref, broadcast=False):
+        self.set("Xref", x_ref, broadcast)
+
+    def set_u_ref(self, u_ref, broadcast=False):
+        self.set("Uref", u_ref, broadcast)
+
+    def reset(self):
+        self._check(lib().tiny_group_reset(self._h), "reset")
+
+    def solve(self) -> int:
+        rc = lib().tiny_group_solve(self._h)
+        if rc not in (0, 1):
+            self._check(rc, "solve")
+        return rc
+
+    def solve_async(self):
+        self._check(lib().tiny_group_solve_async(self._h), "solve_async")
+
+    def synchronize(self):
+        self._check(lib().tiny_group_synchronize(self._h), "synchronize")
+
+    def allreduce_stats(self):
+        out = np.zeros(10)
+        self._check(lib().tiny_group_allreduce_stats(self._h, out.ctypes.data_as(_dp)), "allreduce_stats")
+        return out
+
+    def status(self):
+        B = self.batch
+        it, so, st = (np.zeros(B, dtype=np.int32) for _ in range(3))
+        res = np.zeros((B, 4))
+        self._check(lib().tiny_group_get_status(self._h, it.ctypes.data_as(_ip), so.ctypes.data_as(_ip), st.ctypes.data_as(_ip),
+                                                res.ctypes.data_as(_dp)), "get_status")
+        return dict(iter=it, solved=so, status=st, residuals=res)
 
 
 def load_problem(name):

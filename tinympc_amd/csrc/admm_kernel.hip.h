@@ -456,6 +456,7 @@ void admm_solve_kernel(const SolveArgs P) {
 
             int iter = 0, solved = 0, checked = 0;
             unsigned acc_iter = 0, acc_solved = 0;
+            bool vp_touched = false;                           // v|z differ from what was loaded (a solve that converges at its first check leaves them alone)
             double rp = 0.0, rd = 0.0;
             const int nsteps = P.steps > 1 ? P.steps : 1;
             for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch
@@ -622,6 +623,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)
 #pragma unroll
                     for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446
+                    vp_touched = true;
                 }
                 acc_iter += (unsigned)(iter - iter0);
                 acc_solved += (unsigned)solved;
@@ -644,7 +646,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     if ((P.store_mask & 1) && (acc_iter > 0 || (s == 0 && is_state))) P.prim[off] = X[s];
                     if (P.store_mask & 2) P.slack[off] = VN[s];
                     if (P.store_mask & 4) P.dual[off] = G[s];
-                    if (P.store_mask & 8) P.slack_prev[off] = VP[s];
+                    if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];   // admm.cpp:431-441 returns before v = vnew
                     if constexpr (SOC) {
                         // a family whose cone switch is off keeps its records (admm.cpp:102-109, 228-235)
                         if (soc_lane && (P.store_mask & 16)) { P.cslack[off] = VC[s]; P.cdual[off] = GC[s]; }

@@ -66,14 +66,27 @@ __global__ __launch_bounds__(256) void reduce_stats_kernel(const int4* __restric
         m0 = fmax(m0, __shfl_xor(m0, off)); m1 = fmax(m1, __shfl_xor(m1, off));
         m2 = fmax(m2, __shfl_xor(m2, off)); m3 = fmax(m3, __shfl_xor(m3, off));
     }
+    // the block's four waves meet in LDS, so that the device-scope atomics (all on the same few addresses) stay at eight
+    // per BLOCK: with one set per wave this kernel took 87 us on 65 536 instances, most of it serialised atomics
+    __shared__ double part[4][8];
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(out + 0, si); atomicAdd(out + 1, ss); atomicAdd(out + 7, ai); atomicAdd(out + 8, as);
+        part[w][0] = si; part[w][1] = ss; part[w][2] = ai; part[w][3] = as;
+        part[w][4] = m0; part[w][5] = m1; part[w][6] = m2; part[w][7] = m3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            for (int e = 0; e < 4; ++e) part[0][e] += part[k][e];
+            for (int e = 4; e < 8; ++e) part[0][e] = fmax(part[0][e], part[k][e]);
+        }
+        atomicAdd(out + 0, part[0][0]); atomicAdd(out + 1, part[0][1]); atomicAdd(out + 7, part[0][2]); atomicAdd(out + 8, part[0][3]);
         unsigned long long* mo = reinterpret_cast<unsigned long long*>(out);
-        atomicMax(mo + 3, (unsigned long long)__double_as_longlong(m0));
-        atomicMax(mo + 4, (unsigned long long)__double_as_longlong(m1));
-        atomicMax(mo + 5, (unsigned long long)__double_as_longlong(m2));
-        atomicMax(mo + 6, (unsigned long long)__double_as_longlong(m3));
-        if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = (double)batch;
+        atomicMax(mo + 3, (unsigned long long)__double_as_longlong(part[0][4]));
+        atomicMax(mo + 4, (unsigned long long)__double_as_longlong(part[0][5]));
+        atomicMax(mo + 5, (unsigned long long)__double_as_longlong(part[0][6]));
+        atomicMax(mo + 6, (unsigned long long)__double_as_longlong(part[0][7]));
+        if (blockIdx.x == 0) out[2] = (double)batch;
     }
 }
 
@@ -633,6 +646,9 @@ int launch_solve(TinyBatch* b) {
     a.traj_step0 = (int)b->traj_step; a.reset_duals = b->reset_duals ? 1 : 0;
     a.cold = b->one_shot ? 1 : 0;
     a.store_mask = b->one_shot == 2 ? 1 : (b->one_shot == 1 ? 3 : 31);
+    // "store_primal" = 0: work->x|u is not written back.  A cone / half-space slack is initialised from it by the next
+    // solve (admm.cpp:352-374) and the debug outputs belong to it, so those launches keep the store.
+    if (!b->store_primal && !b->one_shot && !soc && !lin_variant(b) && !b->debug) a.store_mask &= ~1;
     if (steps > 1 && b->step_log) {
         if (int rc = ensure_step_logs(b, steps)) return rc;
         a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
@@ -806,6 +822,7 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     if (!out || !Adyn || !Bdyn || !Qdiag || !Rdiag) return TINY_ERR_NULL;
     *out = nullptr;
     if (nx <= 0 || nu <= 0 || N < 2 || batch <= 0) return TINY_ERR_DIM;
+    if (device < 0) return TINY_ERR_ARG;
     const KernelEntry* ke = find_kernel(nx, nu, N);   // nullptr -> coverage kernel (general_kernel.hip.h)
     if (!ke && nx + nu > 32) {
         if (verbose) fprintf(stderr, "tinympc_amd: (nx,nu,N)=(%d,%d,%d): nx+nu > 32 is not supported\n", nx, nu, N);
@@ -950,9 +967,11 @@ int tiny_batch_destroy(TinyBatch* b) {
                     b->d_stage, b->d_status, b->d_resid, b->d_stats, b->d_tab, b->d_dbg_qr, b->d_dbg_pd, b->d_accum,
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
-                    b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count};
+                    b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count,
+                    b->d_wire};
     for (void* p : bufs)
         if (p) hipFree(p);
+    if (b->h_wire) hipHostFree(b->h_wire);
     for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
     for (hipEvent_t e : b->ev_stop) hipEventDestroy(e);
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
@@ -978,6 +997,7 @@ int tiny_batch_set_cone_constraints(TinyBatch* b, int nsc, const int* Acx, const
                                     int nic, const int* Acu, const int* qcu, const double* cu) {
     if (!b) { printf("Error in tiny_set_cone_constraints: solver is nullptr\n"); return 1; }     // tiny_api.cpp:179-182
     if (nsc < 0 || nic < 0) return fail(b, TINY_ERR_DIM, "negative cone count");
+    if ((nsc > 0 && (!Acx || !qcx || !cx)) || (nic > 0 && (!Acu || !qcu || !cu))) return fail(b, TINY_ERR_NULL, "null cone descriptor with a positive count");
     std::vector<int> used((size_t)(b->nx + b->nu), 0);
     for (int pass = 0; pass < 2; ++pass) {
         const int n = pass ? nic : nsc;
@@ -1022,6 +1042,7 @@ int tiny_batch_set_linear_constraints(TinyBatch* b, int n_state, const double* A
                                       const double* Alin_u, const double* blin_u) {
     if (!b) { printf("Error in tiny_set_linear_constraints: solver is nullptr\n"); return 1; }   // tiny_api.cpp:213-216
     if (n_state < 0 || n_input < 0) return fail(b, TINY_ERR_DIM, "negative constraint count");
+    if ((n_state > 0 && (!Alin_x || !blin_x)) || (n_input > 0 && (!Alin_u || !blin_u))) return fail(b, TINY_ERR_NULL, "null constraint table with a positive count");
     b->nsl = n_state; b->nil = n_input;
     rows_of(Alin_x, n_state, b->nx, &b->Alin_x); b->blin_x.assign(blin_x, blin_x + n_state);
     rows_of(Alin_u, n_input, b->nu, &b->Alin_u); b->blin_u.assign(blin_u, blin_u + n_input);
@@ -1033,6 +1054,7 @@ int tiny_batch_set_tv_linear_constraints(TinyBatch* b, int n_state, const double
                                          int n_input, const double* tv_Alin_u, const double* tv_blin_u) {
     if (!b) { printf("Error in tiny_set_linear_constraints: solver is nullptr\n"); return 1; }   // tiny_api.cpp:256-259
     if (n_state < 0 || n_input < 0) return fail(b, TINY_ERR_DIM, "negative constraint count");
+    if ((n_state > 0 && (!tv_Alin_x || !tv_blin_x)) || (n_input > 0 && (!tv_Alin_u || !tv_blin_u))) return fail(b, TINY_ERR_NULL, "null constraint table with a positive count");
     const int N = b->N;
     b->ntsl = n_state; b->ntil = n_input;
     // tv_Alin_x is (n_state*N) x nx column-major with row n_state*i + k = constraint k at knot i (admm.cpp:189):
@@ -1072,6 +1094,7 @@ int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags) 
             const double* s = src;
             if (!dev) { HIP_TRY(b, hipMemcpyAsync(b->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream)); s = b->d_stage; }
             hipLaunchKernelGGL(broadcast_rows_kernel, dim3(1024), dim3(256), 0, b->stream, b->d_x0, s, b->batch, nx);
+            HIP_TRY(b, hipGetLastError());
         }
         if (!dev) HIP_TRY(b, hipStreamSynchronize(b->stream));
         return TINY_OK;
@@ -1157,8 +1180,8 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out) {
     HIP_TRY(b, hipSetDevice(b->device));
     double* dst = device_out ? (double*)device_out : b->d_stats;
     HIP_TRY(b, hipMemsetAsync(dst, 0, 10 * sizeof(double), b->stream));
-    int blocks = (b->batch + 255) / 256;
-    if (blocks > 256) blocks = 256;
+    int blocks = (b->batch + 1023) / 1024;                // four instances per thread at most 64 blocks: 512 atomics
+    if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(blocks), dim3(256), 0, b->stream, b->d_status, b->d_resid, b->d_accum,
                        b->batch, dst);
     HIP_TRY(b, hipGetLastError());
@@ -1210,6 +1233,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
+    else if (!strcmp(name, "store_primal")) b->store_primal = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
     else if (!strcmp(name, "repack_after")) { if (value < 0) return fail(b, TINY_ERR_ARG, "repack_after: >= 0"); b->repack_after = (int)value; }
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);
@@ -1231,6 +1255,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
 
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream) {
     if (!b) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
     b->stream = (hipStream_t)hip_stream;

@@ -78,6 +78,7 @@ struct TinyBatch {
     int repack_after = 0;
     int repack_waves_per_cu = 8, repack_growth = 2;   // grid of the follow-up stages; stage s runs to K * growth^s (measured best: 8, 2)
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
+    bool store_primal = true;            // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)
     int one_shot = 0;                    // 1: cold state assumed, x|u + vnew|znew written; 2: x|u only (bytes_cold of SURVEY.md 8(d))
     double* d_traj = nullptr;
     // heterogeneous problem families: per-instance problem data, caches and lane tables (device)
@@ -89,6 +90,9 @@ struct TinyBatch {
     int* d_traj_offsets = nullptr;
     int traj_points = 0;
     long traj_step = 0;
+    // tiny_batch_allreduce_stats (group_api.hip): the gather table of the 64-byte statistics messages, device + pinned host
+    double *d_wire = nullptr, *h_wire = nullptr;
+    int wire_ranks = 0;
     // timing
     std::vector<hipEvent_t> ev_start, ev_stop;
     int timing_n = 0, timing_left = 0;

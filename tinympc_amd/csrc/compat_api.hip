@@ -98,6 +98,7 @@ Mat to_mat(const TinyMatrixPOD* m) { return Mat((int)m->rows, (int)m->cols, m->d
 struct Ctx {
     TinyBatch* b = nullptr;
     int n = 0;
+    int nx = 0, nu = 0, N = 0;     // the shape the batch was created for: a freed solver's address can come back with another shape
     // the problem family last uploaded (hash of cache, dynamics, costs, settings, bounds, cones, half-spaces): a solve
     // whose family is unchanged skips the table rebuild and upload
     uint64_t family = 0;
@@ -172,7 +173,9 @@ int sync_family(TinyBatch* b, const TinySolver* s) {
         b->have_bounds = true;
     }
     b->tab_dirty = true;
-    const int nsc = w->numStateCones, nic = w->numInputCones;
+    // a family whose cone switch is off never reaches the cone code of the reference (admm.cpp:102,107): its descriptors are
+    // not validated or forwarded, so that e.g. q != 3 cones with en_*_soc = 0 solve as they do there
+    const int nsc = st->en_state_soc ? w->numStateCones : 0, nic = st->en_input_soc ? w->numInputCones : 0;
     return tiny_batch_set_cone_constraints(b, nsc, w->Acx.data, w->qcx.data, w->cx.data, nic, w->Acu.data, w->qcu.data, w->cu.data);
 }
 
@@ -211,7 +214,9 @@ bool is_state_field(TinyField f) {
 int device_context(TinySolver* s0, int n, TinyBatch** out) {
     const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
     Ctx& ctx = g_ctx[s0];
-    if (ctx.b && ctx.n != n) release(ctx);
+    // The reference has no destroy function, so a caller may free a solver and tiny_setup() another one of a different
+    // shape at the same address: the context is only reused when group size AND (nx, nu, N) still match.
+    if (ctx.b && (ctx.n != n || ctx.nx != nx || ctx.nu != nu || ctx.N != N)) release(ctx);
     if (!ctx.b) {
         int rc = raw_batch(&ctx.b, nx, nu, N, n);
         if (rc) {
@@ -220,7 +225,7 @@ int device_context(TinySolver* s0, int n, TinyBatch** out) {
             g_ctx.erase(s0);
             return rc;
         }
-        ctx.n = n;
+        ctx.n = n; ctx.nx = nx; ctx.nu = nu; ctx.N = N;
         tiny_batch_set_option(ctx.b, "debug", 1);
     }
     *out = ctx.b;

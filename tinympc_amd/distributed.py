@@ -2,15 +2,20 @@
 
 Instances are independent QPs, so each rank owns a contiguous (or, for
 divergent iteration counts, round-robin) slice of the batch for the whole episode; the only
-exchange is the reduction of the 10-double statistics vector produced by tiny_batch_reduce_stats:
-SUM over {sum_iter, sum_solved, batch, accumulated iters, accumulated solved}, MAX over the four
-residual maxima -- two 80-byte all-reduces.  With backend "nccl" this is RCCL over xGMI (latency bound);
-the same code runs on "gloo" for the CPU tests.
+exchange is ONE collective over a 64-byte message per rank: the eight statistics a shard cannot know
+about the others -- {sum iter, sum solved, accumulated iterations, accumulated solves} and the four
+residual maxima -- are all-gathered and every rank reduces the world x 8 table itself (SUM over the
+counts, MAX over the residuals).  With backend "nccl" this is RCCL over xGMI (latency bound); the
+same code runs on "gloo" for the CPU tests.  The native form of the same exchange is
+tiny_group_allreduce_stats / tiny_batch_allreduce_stats (include/tinympc_amd.h).
 """
 from __future__ import annotations
 
+# positions in the 10-double vector of tiny_batch_reduce_stats
 COUNT_IDX = (0, 1, 2, 7, 8)
 MAX_IDX = (3, 4, 5, 6)
+# the 64-byte wire message: four counts, then the four residual maxima (the shard sizes are known by construction)
+WIRE_IDX = (0, 1, 7, 8, 3, 4, 5, 6)
 
 
 def shard_bounds(total: int, rank: int, world: int):
@@ -28,20 +33,45 @@ def shard_indices(total: int, rank: int, world: int, interleaved: bool = False):
     return list(range(lo, hi))
 
 
-def allreduce_stats(stats, dist=None, group=None):
+def shard_size(total: int, rank: int, world: int, interleaved: bool = False) -> int:
+    if interleaved:
+        return len(range(rank, total, world))
+    lo, hi = shard_bounds(total, rank, world)
+    return hi - lo
+
+
+_wire_index = {}
+
+
+def reduce_table(table, total_batch):
+    """Host-side reduction of the gathered world x 8 table of wire messages -> the 10-entry statistics vector."""
+    import torch
+    t = torch.as_tensor(table, dtype=torch.float64).reshape(-1, len(WIRE_IDX))
+    out = torch.zeros(10, dtype=torch.float64)
+    sums = t[:, :4].sum(dim=0)
+    out[0], out[1], out[7], out[8] = sums[0], sums[1], sums[2], sums[3]
+    out[3:7] = t[:, 4:].max(dim=0).values
+    out[2] = float(total_batch)
+    return out
+
+
+def allreduce_stats(stats, dist=None, group=None, total_batch=None):
     """stats: 1-D float64 torch tensor of 10 entries (device or CPU) as written by
-    TinyBatchSolver.reduce_stats(_async).  Returns the job-wide vector (all ranks get it)."""
+    TinyBatchSolver.reduce_stats(_async).  Returns the job-wide vector as a CPU tensor (every rank gets
+    the same one).  total_batch: the unsharded batch size; default = this rank's batch x world size."""
     import torch
     if dist is None:
         import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return stats.clone()
-    # Measured on one MI355X (torchrun, one rank, the bench workload): packing both reductions into ONE collective -- an
-    # all-gather reduced locally, or a MAX all-reduce over one-hot count slots -- needs a handful of extra small device ops
-    # and came out 5-6 % slower end to end than these two plain all-reduces, so they stay.
-    total = stats.clone()
-    peak = stats.clone()
-    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)     # counts
-    dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)      # residual maxima
-    total[MAX_IDX[0]:MAX_IDX[-1] + 1] = peak[MAX_IDX[0]:MAX_IDX[-1] + 1]
-    return total
+        return stats.detach().to("cpu").clone()
+    world = dist.get_world_size(group)
+    idx = _wire_index.get(stats.device)
+    if idx is None:                                                 # built once per device: no host->device copy per call
+        idx = _wire_index[stats.device] = torch.tensor(WIRE_IDX, dtype=torch.long, device=stats.device)
+    wire = stats.index_select(0, idx)                               # 8 doubles = 64 bytes
+    table = torch.empty(world * len(WIRE_IDX), dtype=stats.dtype, device=stats.device)
+    dist.all_gather_into_tensor(table, wire, group=group)           # the one collective of the path
+    t = table.to("cpu")                                             # device -> host (synchronises), reduced here
+    if total_batch is None:
+        total_batch = float(stats[2]) * world
+    return reduce_table(t, total_batch)

@@ -1,0 +1,52 @@
+#!/bin/bash
+# One script for every intermediate GPU call of a round (the round-end evidence run is tools/gpu_final.sh):
+#     gpurun --timeout 900 -- 'bash tools/gpu_stage.sh <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/<stage>/ and prints a short tail.  Stages:
+#   tests        pytest -m gpu (whole suite) + smoke
+#   tests_fast   the parity / sharding / native-group tests only
+#   bench        bench.py with the driver's flags (--steps 20 --warmup 5) and the defaults
+#   prof         rocprofv3 kernel stats + PMC traffic passes of both bench commands
+#   configs      tools/config_bench.py (configs 3, 4, linear examples)
+#   sweep        tools/sweep_bench.py (config 5)
+#   adaptive     the adaptive-rho parity tests + a timing of the adaptive kernel variant
+#   exp          whatever tools/gpu_experiment.sh holds (kernel experiments of the moment)
+set +e
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R
+for stage in "$@"; do
+  O=gpurun_out/$stage; mkdir -p $O
+  echo "=== stage $stage"
+  case $stage in
+    tests)
+      timeout 1200 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -4 $O/pytest_gpu.txt
+      python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt ;;
+    tests_fast)
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharding.py tests/test_gpu_group.py tests/test_gpu_repack.py -m gpu -q > $O/pytest_gpu.txt 2>&1
+      echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -6 $O/pytest_gpu.txt ;;
+    bench)
+      timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; tail -c 1500 $O/bench_driver_flags.json; echo
+      timeout 600 python bench.py --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
+      timeout 300 python bench.py --steps-per-launch 1 --no-cpu-baseline --no-regimes > $O/bench_per_step.json 2> $O/bench_per_step.err
+      TINYMPC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+      tail -c 300 $O/bench_torchrun1.json; echo ;;
+    prof)
+      cd /tmp
+      for mode in driver default step; do
+        case $mode in driver) extra="--steps 20 --warmup 5" ;; default) extra="" ;; step) extra="--steps-per-launch 1 --warmup 0" ;; esac
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${mode}_trace -o hover -- python $R/bench.py --no-cpu-baseline --min-seconds 0.2 $extra > $R/$O/rocprof_${mode}_bench.json 2> $R/$O/rocprof_${mode}_trace.err
+        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_${mode}_fetch -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_fetch.err
+        timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_${mode}_write -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_write.err
+      done
+      cd $R; find $O -name "*kernel_stats.csv" | head ;;
+    configs)
+      timeout 900 python tools/config_bench.py $O/configs_3_4.json > $O/configs.out 2> $O/configs.err; tail -c 800 $O/configs.out ;;
+    sweep)
+      timeout 600 python tools/sweep_bench.py --out $O/sweep_config5.json > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md ;;
+    adaptive)
+      timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt ;;
+    exp)
+      bash tools/gpu_experiment.sh $O ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
