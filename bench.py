@@ -123,7 +123,7 @@ def main():
     import numpy as np
     import torch
     import tinympc_amd as tm
-    from tinympc_amd.distributed import allreduce_stats
+    from tinympc_amd.distributed import StatsExchange
 
     if not torch.cuda.is_available() or tm.device_count() == 0:
         sys.exit("bench.py needs an MI355X: tinympc_amd has no CPU fallback")
@@ -163,10 +163,15 @@ def main():
         s.set_x_ref(xref, broadcast=True)
         s.set_x0(x0, broadcast=True)
 
+    one = torch.zeros(1, device=dev)
+    exchange = StatsExchange(s, dist, dev, total_batch=world * B) if dist is not None else None
+
     def barrier():
+        # no rank leaves before every rank has arrived: a one-element all-reduce between two device synchronisations
+        # (dist.barrier() itself costs 0.5 ms on this stack, 25x the all-reduce: tools/dist_exchange_cost.py)
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.all_reduce(one)
         torch.cuda.synchronize()
 
     def max_over_ranks(values):
@@ -184,9 +189,10 @@ def main():
         t0 = time.perf_counter()
         for _ in range(launches):
             s.solve_async()
-        s.reduce_stats_async(stats.data_ptr())
         if dist is not None:                         # the one exchange of the path: a 64-byte message per rank, RCCL over xGMI
-            st = allreduce_stats(stats, dist)
+            st = exchange()
+        else:
+            s.reduce_stats_async(stats.data_ptr())
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is None:
@@ -199,8 +205,8 @@ def main():
             s.solve_async()
         s.synchronize()
         if dist is not None:                         # first-use costs of the collective stay out of the timed region
-            s.reduce_stats_async(stats.data_ptr())
-            allreduce_stats(stats, dist)
+            exchange()
+            barrier()
         e0, st, km = timed_repetition()
         e0 = max_over_ranks([e0])[0]
         repeats = int(min(max(3, -(-args.min_seconds // max(e0, 1e-6))), args.max_repeats))

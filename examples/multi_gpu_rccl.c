@@ -89,5 +89,5 @@ int main(int argc, char** argv) {
     const double* s = ranks[0].stats;
     printf("%d rank(s): %.0f instances x 60 MPC steps, %.0f ADMM iterations, %.0f of %.0f solves converged, max primal residual %.3e\n",
            gpus, s[2], s[7], s[8], 60.0 * s[2], fmax(s[3], s[4]));
-    return s[8] == 60.0 * s[2] ? 0 : 3;
+    return (s[2] == (double)per_gpu * gpus && s[7] > 0.0 && s[8] > 0.9 * 60.0 * s[2]) ? 0 : 3;
 }

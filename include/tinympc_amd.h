@@ -283,6 +283,10 @@ int tiny_group_allreduce_stats(TinyGroup* g, double* out10);
  * ncclCommInitRank; rccl_comm = its ncclComm_t.  Enqueued on the batch's stream behind the solve, returns when the
  * stream has drained, the same job-wide vector on every rank.  total_batch = the unsharded batch size. */
 int tiny_batch_allreduce_stats(TinyBatch* b, void* rccl_comm, int n_ranks, int rank, long total_batch, double* out10);
+/* Only the message: the 8 doubles {sum iter, sum solved, accumulated iterations, accumulated solves, max primal_state,
+ * primal_input, dual_state, dual_input} of this batch, written to device memory on the batch's stream behind the solve,
+ * for hosts that run the collective themselves (bench.py hands it to torch.distributed = RCCL). */
+int tiny_batch_stats_message(TinyBatch* b, void* device_out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* (B) Reference entry points over plain-data mirrors of the reference structs.

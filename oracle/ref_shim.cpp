@@ -100,6 +100,8 @@ double* ref_ptr(void* hv, const char* name, int* rows, int* cols) {
     M_("sol_x", s->solution->x) M_("sol_u", s->solution->u)
     M_("vlnew", w->vlnew) M_("zlnew", w->zlnew) M_("gl", w->gl) M_("yl", w->yl)
     M_("vlnew_tv", w->vlnew_tv) M_("zlnew_tv", w->zlnew_tv) M_("gl_tv", w->gl_tv) M_("yl_tv", w->yl_tv)
+    M_("C1", c->C1) M_("C2", c->C2)
+    M_("dKinf_drho", c->dKinf_drho) M_("dPinf_drho", c->dPinf_drho) M_("dC1_drho", c->dC1_drho) M_("dC2_drho", c->dC2_drho)
 #undef M_
 #undef V_
     if (m) { if (rows) *rows = (int)m->rows(); if (cols) *cols = (int)m->cols(); return m->data(); }
@@ -131,6 +133,10 @@ double ref_get(void* hv, const char* name) {
     if (n == "sol_iter") return s->solution->iter;
     if (n == "sol_solved") return s->solution->solved;
     if (n == "rho") return s->cache->rho;
+    if (n == "adaptive_rho") return s->settings->adaptive_rho;
+    if (n == "adaptive_rho_min") return s->settings->adaptive_rho_min;
+    if (n == "adaptive_rho_max") return s->settings->adaptive_rho_max;
+    if (n == "adaptive_rho_enable_clipping") return s->settings->adaptive_rho_enable_clipping;
     if (n == "nx") return s->work->nx;
     if (n == "nu") return s->work->nu;
     if (n == "N") return s->work->N;
@@ -152,11 +158,43 @@ int ref_set(void* hv, const char* name, double v) {
     else if (n == "en_input_linear") s->settings->en_input_linear = (int)v;
     else if (n == "en_tv_state_linear") s->settings->en_tv_state_linear = (int)v;
     else if (n == "en_tv_input_linear") s->settings->en_tv_input_linear = (int)v;
+    else if (n == "adaptive_rho") s->settings->adaptive_rho = (int)v;
+    else if (n == "adaptive_rho_min") s->settings->adaptive_rho_min = v;
+    else if (n == "adaptive_rho_max") s->settings->adaptive_rho_max = v;
+    else if (n == "adaptive_rho_enable_clipping") s->settings->adaptive_rho_enable_clipping = (int)v;
+    else if (n == "rho") s->cache->rho = v;
     else return 1;
     return 0;
 }
 
-int ref_solve(void* hv) { return tiny_solve(static_cast<RefHandle*>(hv)->solver); }
+// Adaptive rho (admm.cpp:339-345, 397-423).  solve() declares `RhoAdapter adapter;` without initialising it, and
+// format_matrices (rho_benchmark.cpp:57-59) sizes the adapter's matrices only when the indeterminate
+// `adapter.matrices_initialized` happens to read false: with a nonzero byte there the 0x0 matrices are written out of
+// bounds.  ref_stack_fill paints the stack region solve()'s frame is going to occupy, so that the flag's value is chosen
+// by the caller instead of by whatever ran before: fill 0 = the deterministic behaviour the goldens pin ("matrices sized
+// at the first adaptation of every solve"), any other byte = the probe of tools/adaptive_rho_probe.py.
+__attribute__((noinline)) void ref_stack_fill(int byte, int bytes) {
+    volatile char pad[1 << 16];
+    const int n = bytes < (int)sizeof(pad) ? bytes : (int)sizeof(pad);
+    for (int i = 0; i < n; ++i) pad[sizeof(pad) - 1 - i] = (char)byte;   // the top of this frame = where the next call's frame starts
+    for (int i = 0; i < (int)sizeof(pad) - n; ++i) pad[i] = (char)byte;
+}
+
+// tiny_initialize_sensitivity_matrices (tiny_api.cpp:479-540): quadrotor-sized tables only (4x12 / 12x12 / 4x4)
+int ref_init_sensitivity(void* hv) {
+    TinySolver* s = static_cast<RefHandle*>(hv)->solver;
+    if (s->work->nx != 12 || s->work->nu != 4) return 1;
+    tiny_initialize_sensitivity_matrices(s);
+    return 0;
+}
+
+int ref_solve(void* hv) {
+    TinySolver* s = static_cast<RefHandle*>(hv)->solver;
+    if (s->settings->adaptive_rho) ref_stack_fill(0, 1 << 16);
+    return tiny_solve(s);
+}
+// the same without scrubbing the stack first (the probe fills it with something else)
+int ref_solve_raw(void* hv) { return tiny_solve(static_cast<RefHandle*>(hv)->solver); }
 
 int ref_phase(void* hv, const char* name) {
     TinySolver* s = static_cast<RefHandle*>(hv)->solver;
@@ -184,6 +222,7 @@ long ref_closed_loop(void* hv, double* x0, int steps, int* iters_out, double* u0
     long total = 0;
     for (int k = 0; k < steps; ++k) {
         tiny_set_x0(s, x);
+        if (s->settings->adaptive_rho) ref_stack_fill(0, 1 << 16);
         tiny_solve(s);
         total += s->solution->iter;
         if (iters_out) iters_out[k] = s->solution->iter;

@@ -41,7 +41,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
-    "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats")
+    "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -117,6 +117,7 @@ def lib():
         L.tiny_jit_compile.argtypes = [C.c_char_p, _ip, C.c_char_p, C.c_int]
         L.tiny_jit_compile.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
+        L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_allreduce_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, _dp]
         L.tiny_group_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _ip, C.c_int, C.c_int, C.c_int]
@@ -400,6 +401,10 @@ class TinyBatchSolver:
     def reduce_stats_async(self, device_out):
         self._check(lib().tiny_batch_reduce_stats(self._h, None, C.c_void_p(device_out)), "reduce_stats")
 
+    def stats_message_async(self, device_out):
+        """the batch's 64-byte statistics message (8 doubles) -> device memory, on the batch's stream behind the solve"""
+        self._check(lib().tiny_batch_stats_message(self._h, C.c_void_p(device_out)), "stats_message")
+
     def set_option(self, name, value):
         self._check(lib().tiny_batch_set_option(self._h, name.encode(), int(value)), f"set_option({name})")
 
@@ -462,7 +467,7 @@ class TinyGroupSolver:
                                     None if dev is None else dev.ctypes.data_as(_ip), int(n_shards), int(bool(interleaved)), verbose)
         if rc != OK:
             self._h = C.c_void_p()
-            raise TinyMPCError(f"tiny_group_setup failed ({rc})")
+            raise TinyMPCError(f"tiny_group_setup failed ({rc}): {lib().tiny_group_last_error(None).decode()}")
 
     @classmethod
     def from_problem(cls, prob, batch, **kw):

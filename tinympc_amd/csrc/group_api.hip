@@ -104,6 +104,8 @@ struct TinyGroup {
 
 namespace {
 
+thread_local char g_setup_err[320] = "";      // why the last tiny_group_setup on this thread failed (there is no handle to ask)
+
 int gfail(TinyGroup* g, int code, const char* fmt, ...) {
     if (g) {
         va_list ap;
@@ -153,31 +155,38 @@ int tiny_group_setup(TinyGroup** out, const double* Adyn, const double* Bdyn, co
         const int base = batch / n_shards, rem = batch % n_shards;    // both splits give the first `rem` shards one more
         g->count.push_back(base + (k < rem ? 1 : 0));
     }
-    auto bail = [&](int rc) { tiny_group_destroy(g); return rc; };
+    g_setup_err[0] = 0;
+    auto bail = [&](int rc, const char* what, const char* detail) {
+        snprintf(g_setup_err, sizeof(g_setup_err), "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+        if (verbose) fprintf(stderr, "tinympc_amd: tiny_group_setup: %s\n", g_setup_err);
+        tiny_group_destroy(g);
+        return rc;
+    };
     for (int k = 0; k < n_shards; ++k) {
         TinyBatch* b = nullptr;
         const int rc = tiny_batch_setup(&b, Adyn, Bdyn, fdyn, Qdiag, Rdiag, rho, nx, nu, N, g->count[k], g->device[k], verbose);
-        if (rc) return bail(rc);
+        if (rc) return bail(rc, "tiny_batch_setup of a shard failed", nullptr);
         g->shard.push_back(b);
         double *ds = nullptr, *dw = nullptr;
         if (hipSetDevice(g->device[k]) != hipSuccess || hipMalloc(&ds, 10 * sizeof(double)) != hipSuccess ||
-            hipMalloc(&dw, (size_t)n_shards * WIRE * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
+            hipMalloc(&dw, (size_t)n_shards * WIRE * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP, "hipMalloc of the statistics buffers", nullptr);
         g->d_stats.push_back(ds); g->d_wire.push_back(dw);
     }
     if (hipHostMalloc(reinterpret_cast<void**>(&g->h_table), (size_t)n_shards * WIRE * sizeof(double), hipHostMallocDefault) != hipSuccess)
-        return bail(TINY_ERR_HIP);
+        return bail(TINY_ERR_HIP, "hipHostMalloc of the gather table", nullptr);
     // RCCL refuses two ranks on one device: shards that share a GPU (more shards than GPUs -- the single-GPU tests of the
     // sharding logic) exchange their 64-byte messages through host memory instead, with the identical reduction
     g->use_rccl = (int)distinct.size() == n_shards && !getenv("TINYMPC_GROUP_HOST_EXCHANGE");
     if (g->use_rccl) {
         Rccl* r = rccl();
-        if (!r) { if (verbose) fprintf(stderr, "tinympc_amd: RCCL unavailable\n"); return bail(TINY_ERR_NO_DEVICE); }
-        g->comm.resize(n_shards);
+        if (!r) return bail(TINY_ERR_NO_DEVICE, "RCCL unavailable", nullptr);
+        g->comm.assign(n_shards, nullptr);
+        for (int k = 0; k < n_shards; ++k) { hipSetDevice(g->device[k]); hipDeviceSynchronize(); }
+        (void)hipGetLastError();      // RCCL's own HIP checks would trip over an error some earlier, unrelated call left behind
         const ncclResult_t rc = r->CommInitAll(g->comm.data(), n_shards, g->device.data());
         if (rc != ncclSuccess) {
-            if (verbose) fprintf(stderr, "tinympc_amd: ncclCommInitAll: %s\n", r->GetErrorString(rc));
             g->comm.clear();
-            return bail(TINY_ERR_HIP);
+            return bail(TINY_ERR_HIP, "ncclCommInitAll", r->GetErrorString(rc));
         }
     }
     *out = g;
@@ -203,7 +212,7 @@ int tiny_group_destroy(TinyGroup* g) {
 int tiny_group_shards(TinyGroup* g) { return g ? g->n : TINY_ERR_NULL; }
 TinyBatch* tiny_group_shard(TinyGroup* g, int k) { return (g && k >= 0 && k < g->n) ? g->shard[k] : nullptr; }
 int tiny_group_uses_rccl(TinyGroup* g) { return g ? (g->use_rccl ? 1 : 0) : TINY_ERR_NULL; }
-const char* tiny_group_last_error(TinyGroup* g) { return g ? g->err : "null group"; }
+const char* tiny_group_last_error(TinyGroup* g) { return g ? g->err : g_setup_err; }   /* NULL: the last failed tiny_group_setup */
 
 int tiny_group_shard_indices(TinyGroup* g, int k, int* idx, int capacity) {
     if (!g || k < 0 || k >= g->n) return TINY_ERR_NULL;
@@ -353,6 +362,17 @@ int tiny_group_get_status(TinyGroup* g, int* iter, int* solved, int* status, dou
             if (residuals) memcpy(residuals + gi * 4, rs.data() + i * 4, 4 * sizeof(double));
         }
     }
+    return TINY_OK;
+}
+
+// The 64-byte wire message of this batch -- {sum iter, sum solved, accumulated iterations, accumulated solves, four
+// residual maxima} -- written to device_out (8 doubles of device memory) on the batch's stream, behind the solve: for
+// hosts that run the exchange themselves (bench.py hands it to torch.distributed, i.e. RCCL).
+int tiny_batch_stats_message(TinyBatch* b, void* device_out) {
+    if (!b || !device_out) return TINY_ERR_NULL;
+    if (int rc = tiny_batch_reduce_stats(b, nullptr, nullptr)) return rc;          // into the batch's own d_stats
+    hipLaunchKernelGGL(pack_wire_kernel, dim3(1), dim3(64), 0, b->stream, b->d_stats, static_cast<double*>(device_out));
+    if (hipGetLastError() != hipSuccess) return tinympc_amd::fail(b, TINY_ERR_HIP, "pack_wire_kernel launch failed");
     return TINY_OK;
 }
 

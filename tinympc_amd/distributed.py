@@ -55,23 +55,48 @@ def reduce_table(table, total_batch):
     return out
 
 
+def _world_rank(dist, group):
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
 def allreduce_stats(stats, dist=None, group=None, total_batch=None):
     """stats: 1-D float64 torch tensor of 10 entries (device or CPU) as written by
     TinyBatchSolver.reduce_stats(_async).  Returns the job-wide vector as a CPU tensor (every rank gets
-    the same one).  total_batch: the unsharded batch size; default = this rank's batch x world size."""
+    the same one).  total_batch: the unsharded batch size; default = this rank's batch x world size.
+
+    The gather of the 64-byte messages is issued as ONE all-reduce(SUM) over a world x 8 table in which a
+    rank fills only its own row (adding the other ranks' zeros is exact): on this stack a small all-reduce
+    costs 20 us, all_gather_into_tensor of the same bytes 0.9 ms (measured, tools/dist_exchange_cost.py)."""
     import torch
     if dist is None:
         import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return stats.detach().to("cpu").clone()
-    world = dist.get_world_size(group)
+    world, rank = _world_rank(dist, group)
     idx = _wire_index.get(stats.device)
     if idx is None:                                                 # built once per device: no host->device copy per call
         idx = _wire_index[stats.device] = torch.tensor(WIRE_IDX, dtype=torch.long, device=stats.device)
-    wire = stats.index_select(0, idx)                               # 8 doubles = 64 bytes
-    table = torch.empty(world * len(WIRE_IDX), dtype=stats.dtype, device=stats.device)
-    dist.all_gather_into_tensor(table, wire, group=group)           # the one collective of the path
-    t = table.to("cpu")                                             # device -> host (synchronises), reduced here
+    table = torch.zeros(world, len(WIRE_IDX), dtype=stats.dtype, device=stats.device)
+    table[rank] = stats.index_select(0, idx)                        # 8 doubles = 64 bytes
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)       # the one collective of the path
     if total_batch is None:
         total_batch = float(stats[2]) * world
-    return reduce_table(t, total_batch)
+    return reduce_table(table.to("cpu"), total_batch)               # device -> host (synchronises), reduced here
+
+
+class StatsExchange:
+    """The exchange for a device-resident TinyBatchSolver: the library writes the batch's 64-byte message straight
+    into this rank's row of a preallocated world x 8 table (tiny_batch_stats_message, on the solver's stream behind the
+    solve), ONE all-reduce(SUM) of the table plays the all-gather, one device->host copy brings it back."""
+
+    def __init__(self, solver, dist, device, total_batch, group=None):
+        import torch
+        self.s, self.dist, self.group, self.total = solver, dist, group, float(total_batch)
+        self.world, self.rank = _world_rank(dist, group)
+        self.table = torch.zeros(self.world, len(WIRE_IDX), dtype=torch.float64, device=device)
+
+    def __call__(self):
+        self.table.zero_()
+        self.s.stats_message_async(self.table[self.rank].data_ptr())
+        self.dist.all_reduce(self.table, op=self.dist.ReduceOp.SUM, group=self.group)
+        return reduce_table(self.table.to("cpu"), self.total)

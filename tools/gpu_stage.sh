@@ -34,7 +34,7 @@ for stage in "$@"; do
       cd /tmp
       for mode in driver default step; do
         case $mode in driver) extra="--steps 20 --warmup 5" ;; default) extra="" ;; step) extra="--steps-per-launch 1 --warmup 0" ;; esac
-        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${mode}_trace -o hover -- python $R/bench.py --no-cpu-baseline --min-seconds 0.2 $extra > $R/$O/rocprof_${mode}_bench.json 2> $R/$O/rocprof_${mode}_trace.err
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${mode}_trace -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.3 $extra > $R/$O/rocprof_${mode}_bench.json 2> $R/$O/rocprof_${mode}_trace.err
         timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_${mode}_fetch -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_fetch.err
         timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_${mode}_write -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_write.err
       done
