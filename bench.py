@@ -10,7 +10,8 @@ State is resident in HBM before timing starts.  The K-step region is repeated (c
 K steps, statistics exchange, barrier) until at least --min-seconds of timed work has run; `value`
 comes from the MEDIAN repetition, min / max are reported beside it.  Multi-GPU: one process per GPU,
 batch sharded with no data-path collective (weak scaling: 65 536 instances per GPU); ONE RCCL
-all-gather of the 64-byte statistics message closes every timed repetition.
+all-gather of the 64-byte statistics message (tiny_batch_allreduce_stats, the library's native exchange, on a
+communicator bootstrapped over torch.distributed) closes every timed repetition.
 
 Rooflines (all in the one JSON line):
   roofline         the bound that BINDS the timed launches: FP64 VALU issue when the launches carry many
@@ -164,7 +165,7 @@ def main():
         s.set_x0(x0, broadcast=True)
 
     one = torch.zeros(1, device=dev)
-    exchange = StatsExchange(s, dist, dev, total_batch=world * B) if dist is not None else None
+    exchange = StatsExchange(s, dist, local_rank, total_batch=world * B) if dist is not None else None
 
     def barrier():
         # no rank leaves before every rank has arrived: a one-element all-reduce between two device synchronisations
@@ -317,6 +318,8 @@ def main():
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if exchange is not None:
+        exchange.close()
     s.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -283,6 +283,11 @@ int tiny_group_allreduce_stats(TinyGroup* g, double* out10);
  * ncclCommInitRank; rccl_comm = its ncclComm_t.  Enqueued on the batch's stream behind the solve, returns when the
  * stream has drained, the same job-wide vector on every rank.  total_batch = the unsharded batch size. */
 int tiny_batch_allreduce_stats(TinyBatch* b, void* rccl_comm, int n_ranks, int rank, long total_batch, double* out10);
+/* Communicator plumbing for hosts that have no RCCL binding of their own: rank 0 draws the 128-byte ncclUniqueId, the host
+ * hands it to every rank (MPI_Bcast, a file, torch.distributed ...), each rank joins on its device.  *comm is an ncclComm_t. */
+int tiny_rccl_unique_id(void* id128);
+int tiny_rccl_comm_init_rank(void** comm, int n_ranks, const void* id128, int rank, int device);
+int tiny_rccl_comm_destroy(void* comm);
 /* Only the message: the 8 doubles {sum iter, sum solved, accumulated iterations, accumulated solves, max primal_state,
  * primal_input, dual_state, dual_input} of this batch, written to device memory on the batch's stream behind the solve,
  * for hosts that run the collective themselves (bench.py hands it to torch.distributed = RCCL). */

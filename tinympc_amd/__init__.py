@@ -41,7 +41,8 @@ BATCH_SYMBOLS = (
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
-    "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message")
+    "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
+    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -118,6 +119,9 @@ def lib():
         L.tiny_jit_compile.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
+        L.tiny_rccl_unique_id.argtypes = [C.c_void_p]
+        L.tiny_rccl_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.tiny_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.tiny_batch_allreduce_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, _dp]
         L.tiny_group_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _ip, C.c_int, C.c_int, C.c_int]
@@ -401,6 +405,14 @@ class TinyBatchSolver:
     def reduce_stats_async(self, device_out):
         self._check(lib().tiny_batch_reduce_stats(self._h, None, C.c_void_p(device_out)), "reduce_stats")
 
+    def allreduce_stats(self, comm, n_ranks, rank, total_batch):
+        """the path's one exchange on an RCCL communicator the caller owns (tiny_batch_allreduce_stats); returns the
+        job-wide 10-entry statistics vector (the same on every rank)"""
+        out = np.zeros(10)
+        self._check(lib().tiny_batch_allreduce_stats(self._h, C.c_void_p(comm), int(n_ranks), int(rank), int(total_batch),
+                                                     out.ctypes.data_as(_dp)), "allreduce_stats")
+        return out
+
     def stats_message_async(self, device_out):
         """the batch's 64-byte statistics message (8 doubles) -> device memory, on the batch's stream behind the solve"""
         self._check(lib().tiny_batch_stats_message(self._h, C.c_void_p(device_out)), "stats_message")
@@ -581,6 +593,28 @@ class TinyGroupSolver:
         self._check(lib().tiny_group_get_status(self._h, it.ctypes.data_as(_ip), so.ctypes.data_as(_ip), st.ctypes.data_as(_ip),
                                                 res.ctypes.data_as(_dp)), "get_status")
         return dict(iter=it, solved=so, status=st, residuals=res)
+
+
+def rccl_unique_id() -> bytes:
+    """rank 0: a fresh 128-byte ncclUniqueId (tiny_rccl_unique_id)"""
+    buf = C.create_string_buffer(128)
+    rc = lib().tiny_rccl_unique_id(buf)
+    if rc != OK:
+        raise TinyMPCError(f"tiny_rccl_unique_id failed ({rc})")
+    return buf.raw
+
+
+def rccl_comm_init_rank(n_ranks, unique_id: bytes, rank, device) -> int:
+    """join the communicator of `unique_id` as `rank` on GPU `device`; returns the ncclComm_t as an integer"""
+    comm = C.c_void_p()
+    rc = lib().tiny_rccl_comm_init_rank(C.byref(comm), int(n_ranks), C.c_char_p(unique_id), int(rank), int(device))
+    if rc != OK:
+        raise TinyMPCError(f"tiny_rccl_comm_init_rank failed ({rc})")
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    lib().tiny_rccl_comm_destroy(C.c_void_p(comm))
 
 
 def load_problem(name):

@@ -33,6 +33,8 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
     std::string why;
 };
 
@@ -41,10 +43,28 @@ Rccl* rccl() {
     static bool tried = false;
     if (tried) return r.so ? &r : nullptr;
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (r.so) break;
+    // RCCL must sit on the SAME HIP / HSA runtime this library is bound to.  A process can hold two ROCm stacks -- the
+    // system's under /opt/rocm and the one PyTorch-ROCm bundles in torch/lib, whichever got loaded first serves the HIP
+    // calls of this library -- and an RCCL from the other stack finds its own, uninitialised HSA runtime ("no ROCm-capable
+    // device").  So: the librccl that lives next to the libamdhip64 our HIP symbols resolve to; a bare soname lookup only
+    // as the last resort.
+    Dl_info hip_lib;
+    std::string dir;
+    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &hip_lib) && hip_lib.dli_fname) {
+        dir = hip_lib.dli_fname;
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
     }
+    if (!dir.empty())
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.so = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (r.so) break;
+        }
+    if (!r.so)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.so) break;
+        }
     if (!r.so) { r.why = dlerror() ? dlerror() : "librccl.so not found"; return nullptr; }
     auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p) r.why = std::string("missing symbol ") + n; return p; };
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
@@ -53,6 +73,8 @@ Rccl* rccl() {
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
         dlclose(r.so);
         r.so = nullptr;
@@ -363,6 +385,34 @@ int tiny_group_get_status(TinyGroup* g, int* iter, int* solved, int* status, dou
         }
     }
     return TINY_OK;
+}
+
+// Communicator plumbing for hosts without an RCCL binding of their own (the ctypes mirror, bench.py): rank 0 draws a
+// 128-byte ncclUniqueId, the host distributes it however it talks to its ranks, every rank joins with it.
+int tiny_rccl_unique_id(void* id128) {
+    if (!id128) return TINY_ERR_NULL;
+    Rccl* r = rccl();
+    if (!r || !r->GetUniqueId) return TINY_ERR_NO_DEVICE;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    return r->GetUniqueId(static_cast<ncclUniqueId*>(id128)) == ncclSuccess ? TINY_OK : TINY_ERR_HIP;
+}
+int tiny_rccl_comm_init_rank(void** comm, int n_ranks, const void* id128, int rank, int device) {
+    if (!comm || !id128) return TINY_ERR_NULL;
+    Rccl* r = rccl();
+    if (!r || !r->CommInitRank) return TINY_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TINY_ERR_NO_DEVICE;
+    (void)hipGetLastError();
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    if (r->CommInitRank(&c, n_ranks, id, rank) != ncclSuccess) return TINY_ERR_HIP;
+    *comm = c;
+    return TINY_OK;
+}
+int tiny_rccl_comm_destroy(void* comm) {
+    Rccl* r = rccl();
+    if (!r || !comm) return TINY_ERR_NULL;
+    return r->CommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? TINY_OK : TINY_ERR_HIP;
 }
 
 // The 64-byte wire message of this batch -- {sum iter, sum solved, accumulated iterations, accumulated solves, four

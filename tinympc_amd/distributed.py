@@ -85,18 +85,25 @@ def allreduce_stats(stats, dist=None, group=None, total_batch=None):
 
 
 class StatsExchange:
-    """The exchange for a device-resident TinyBatchSolver: the library writes the batch's 64-byte message straight
-    into this rank's row of a preallocated world x 8 table (tiny_batch_stats_message, on the solver's stream behind the
-    solve), ONE all-reduce(SUM) of the table plays the all-gather, one device->host copy brings it back."""
+    """The exchange for a device-resident TinyBatchSolver on the library's NATIVE path: an RCCL communicator of our own
+    (the ncclUniqueId of rank 0 travels over torch.distributed once, at construction) and tiny_batch_allreduce_stats --
+    device reduction, 64-byte message, ONE ncclAllGather on the solver's stream, pinned device->host copy, host
+    reduction.  No torch op sits between the last solve launch and the result."""
 
-    def __init__(self, solver, dist, device, total_batch, group=None):
-        import torch
-        self.s, self.dist, self.group, self.total = solver, dist, group, float(total_batch)
+    def __init__(self, solver, dist, device_index, total_batch, group=None):
+        import tinympc_amd as tm
+        self.s, self.total = solver, int(total_batch)
         self.world, self.rank = _world_rank(dist, group)
-        self.table = torch.zeros(self.world, len(WIRE_IDX), dtype=torch.float64, device=device)
+        box = [tm.rccl_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.comm = tm.rccl_comm_init_rank(self.world, box[0], self.rank, device_index)
 
     def __call__(self):
-        self.table.zero_()
-        self.s.stats_message_async(self.table[self.rank].data_ptr())
-        self.dist.all_reduce(self.table, op=self.dist.ReduceOp.SUM, group=self.group)
-        return reduce_table(self.table.to("cpu"), self.total)
+        import torch
+        return torch.from_numpy(self.s.allreduce_stats(self.comm, self.world, self.rank, self.total))
+
+    def close(self):
+        if self.comm:
+            import tinympc_amd as tm
+            tm.rccl_comm_destroy(self.comm)
+            self.comm = None
