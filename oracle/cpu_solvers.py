@@ -90,6 +90,19 @@ class _CpuSolver:
             cls._libs[cls.so] = lib
         return cls._libs[cls.so]
 
+    # ---- adaptive rho (types.hpp:75-79, tiny_api.cpp:479-540)
+    def set_adaptive_rho(self, enable=1, rho_min=1.0, rho_max=100.0, clip=1):
+        for k, v in (("adaptive_rho", enable), ("adaptive_rho_min", rho_min), ("adaptive_rho_max", rho_max),
+                     ("adaptive_rho_enable_clipping", clip)):
+            self.set(k, v)
+
+    def set_sensitivity(self, tables):
+        """tables: dict name -> (rows, cols) array for dKinf_drho, dPinf_drho, dC1_drho, dC2_drho"""
+        for k in ("dKinf_drho", "dPinf_drho", "dC1_drho", "dC2_drho"):
+            self[k] = tables[k]
+
+    CACHE_STATE = ("Kinf", "Pinf", "C1", "C2")
+
     def _f(self, name):
         return getattr(self.lib(), self.prefix + name)
 
@@ -214,9 +227,27 @@ class RefSolver(_CpuSolver):
     prefix = "ref_"
     so = REF_SO
 
+    def init_sensitivity(self):
+        """the reference's own tiny_initialize_sensitivity_matrices (quadrotor sizes only)"""
+        if self._f("init_sensitivity")(self.h):
+            raise RuntimeError("tiny_initialize_sensitivity_matrices needs nx = 12, nu = 4")
+
+    def set_sensitivity(self, tables):
+        if self.nx == 12 and self.nu == 4 and tables is None:
+            return self.init_sensitivity()
+        # other shapes: size the (empty) Eigen matrices through the shim, then fill them
+        f = self._f("alloc_sensitivity")
+        f.argtypes = [C.c_void_p]
+        f(self.h)
+        super().set_sensitivity(tables)
+
     @classmethod
     def lib(cls):
         lib = super().lib()
         lib.ref_mute_stdout.argtypes = [C.c_int]
         lib.ref_mute_stdout(1)
+        lib.ref_init_sensitivity.argtypes = [C.c_void_p]
+        lib.ref_stack_fill.argtypes = [C.c_int, C.c_int]
+        lib.ref_stack_fill.restype = None
+        lib.ref_solve_fill.argtypes = [C.c_void_p, C.c_int]
         return lib

@@ -67,6 +67,11 @@ def single_solve_suites(only=None):
         "sweep_12_4_50": sc.sweep_suite(12, 4, 50, B=3),
         "sweep_12_8_30": sc.sweep_suite(12, 8, 30, B=2),
         "sweep_20_8_50": sc.sweep_suite(20, 8, 50, B=2),
+        # adaptive rho (admm.cpp:397-423, rho_benchmark.cpp) with the reference's own sensitivity tables; the real reference
+        # runs with the stack under solve() scrubbed (oracle/ref_shim.cpp: its RhoAdapter flag is uninitialised)
+        "adaptive_hover": sc.hover_adaptive_suite(RefSolver),
+        "adaptive_tracking": sc.tracking_adaptive_suite(),
+        "adaptive_tracking_noclip": sc.tracking_adaptive_suite(B=8, seed=5, clip=0, max_iter=40),
         "linear_random_all": sc.random_linear_suite("quadrotor_20hz", B=4, seed=21),
         "linear_random_rocket_soc": sc.random_linear_suite("rocket_landing_20hz", B=4, seed=22, soc=True),
         "linear_random_tv_only": sc.random_linear_suite("cartpole", B=4, seed=23, static=False, box=False),
@@ -90,6 +95,8 @@ def single_solve_suites(only=None):
         if name.startswith("random_state"):
             fields += ["q", "r", "p", "d", "sol_x", "sol_u"]
         out = sc.run_cases(RefSolver, suite, fields=fields)
+        if suite["config"].get("adaptive_rho"):
+            print(f"{name:26s} rho after the solve: {np.round(out['rho'], 4).tolist()}")
         sc.save_suite(os.path.join(OUT, name + ".npz"), suite, out)
         ep = suite.get("episode")
         print(f"{name:26s} B={len(out['iter'])} iters={out['iter'].astype(int).tolist()}"

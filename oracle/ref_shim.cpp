@@ -188,13 +188,26 @@ int ref_init_sensitivity(void* hv) {
     return 0;
 }
 
+// other shapes than the quadrotor's: size the four tables (zero), the caller fills them through ref_ptr
+void ref_alloc_sensitivity(void* hv) {
+    TinySolver* s = static_cast<RefHandle*>(hv)->solver;
+    const int nx = s->work->nx, nu = s->work->nu;
+    s->cache->dKinf_drho = tinyMatrix::Zero(nu, nx);
+    s->cache->dPinf_drho = tinyMatrix::Zero(nx, nx);
+    s->cache->dC1_drho = tinyMatrix::Zero(nu, nu);
+    s->cache->dC2_drho = tinyMatrix::Zero(nx, nx);
+}
+
 int ref_solve(void* hv) {
     TinySolver* s = static_cast<RefHandle*>(hv)->solver;
     if (s->settings->adaptive_rho) ref_stack_fill(0, 1 << 16);
     return tiny_solve(s);
 }
-// the same without scrubbing the stack first (the probe fills it with something else)
-int ref_solve_raw(void* hv) { return tiny_solve(static_cast<RefHandle*>(hv)->solver); }
+// the probe's variants: paint the stack with `byte` right before the solve (nothing runs in between), or not at all (< 0)
+int ref_solve_fill(void* hv, int byte) {
+    if (byte >= 0) ref_stack_fill(byte, 1 << 16);
+    return tiny_solve(static_cast<RefHandle*>(hv)->solver);
+}
 
 int ref_phase(void* hv, const char* name) {
     TinySolver* s = static_cast<RefHandle*>(hv)->solver;

@@ -35,6 +35,8 @@ def assert_outputs_match(out, ref, rtol, what=""):
                 assert e <= rtol, f"{what}: field {k} case {b} rel err {e:.3e} > {rtol}"
         elif k.startswith(("primal_", "dual_")):
             assert np.allclose(out[k], v, rtol=1e-7, atol=1e-12), f"{what}: {k}"
+        elif k == "rho":                                        # adaptive rho: cache->rho after the solve
+            assert np.allclose(out[k], v, rtol=rtol, atol=0.0), f"{what}: rho {out[k]} vs {v}"
 
 
 def test_suites_present():
