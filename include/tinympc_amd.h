@@ -131,6 +131,22 @@ int tiny_batch_update_settings(TinyBatch* b, double abs_pri_tol, double abs_dua_
                                int check_termination, int en_state_bound, int en_input_bound,
                                int en_state_soc, int en_input_soc, int en_state_linear,
                                int en_input_linear, int en_tv_state_linear, int en_tv_input_linear);
+/* == settings->adaptive_rho, adaptive_rho_min, adaptive_rho_max, adaptive_rho_enable_clipping (types.hpp:75-79).  With it on,
+ * every 5th ADMM iteration re-estimates rho from the residuals of an OSQP-style restatement of the problem and moves Kinf,
+ * Pinf (and the dead copies C1, C2) by a first-order Taylor step, as admm.cpp:397-423 / rho_benchmark.cpp:14-249 do -- NOT
+ * Quu_inv, AmBKt, APf, BPf, Q, R, which the reference keeps as they were.  The cache then is per-instance STATE that persists
+ * from solve to solve (tiny_batch_reset puts tiny_setup's cache back).  The reference's RhoAdapter flag is read uninitialised
+ * upstream; the behaviour reproduced is the one with that flag false ("matrices sized by the first adaptation of every
+ * solve"), which is also the only one that does not crash (profiles/r02_adaptive_rho_probe.txt).  One-row kernel only. */
+int tiny_batch_set_adaptive_rho(TinyBatch* b, int enable, double rho_min, double rho_max, int enable_clipping);
+/* == cache->dKinf_drho (nu x nx), dPinf_drho (nx x nx), dC1_drho (nu x nu), dC2_drho (nx x nx): column-major, shared by every
+ * instance; dC1 / dC2 may be NULL (zero).  tiny_initialize_sensitivity_matrices (tiny_api.cpp:479-540) is the quadrotor's set. */
+int tiny_batch_set_sensitivity(TinyBatch* b, const double* dKinf_drho, const double* dPinf_drho, const double* dC1_drho,
+                               const double* dC2_drho);
+/* per-instance cache state of an adaptive batch, host arrays with a leading batch axis, column-major matrices: which =
+ * "rho" [batch], "Kinf" [batch][nu*nx], "Pinf" [batch][nx*nx], "C1" [batch][nu*nu], "C2" [batch][nx*nx] */
+int tiny_batch_set_cache_state(TinyBatch* b, const char* which, const double* src);
+int tiny_batch_get_cache_state(TinyBatch* b, const char* which, double* dst);
 /* Read back one cache matrix (TinyCache, types.hpp:43-59) by name: "Kinf" (nu x nx), "Pinf",
  * "Quu_inv", "AmBKt", "APf", "BPf", or "Q"/"R" (work->Q/R = user + rho).  Returns element count. */
 int tiny_batch_get_cache(TinyBatch* b, const char* name, double* out, int capacity);

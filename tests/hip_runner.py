@@ -33,6 +33,9 @@ def make_batch(suite, batch=None, replicate=1):
                       cfg["en_state_bound"], cfg["en_input_bound"], cfg["en_state_soc"], cfg["en_input_soc"],
                       cfg.get("en_state_linear", 0), cfg.get("en_input_linear", 0), cfg.get("en_tv_state_linear", 0),
                       cfg.get("en_tv_input_linear", 0))
+    if cfg.get("adaptive_rho"):                       # adaptive rho: sensitivity tables + settings (types.hpp:75-79)
+        s.set_sensitivity(*[cfg["sensitivity." + k] for k in ("dKinf_drho", "dPinf_drho", "dC1_drho", "dC2_drho")])
+        s.set_adaptive_rho(1, cfg.get("adaptive_rho_min", 1.0), cfg.get("adaptive_rho_max", 100.0), cfg.get("adaptive_rho_enable_clipping", 1))
     for kv in filter(None, os.environ.get("TINYMPC_TEST_OPTS", "").split(",")):     # rerun the suite under any option set
         k, v = kv.split("=")
         s.set_option(k, int(v))
@@ -55,9 +58,17 @@ def run_cases_hip(suite, replicate=1, debug=False, options=None):
     for f in IN_FIELDS + (LIN_IN if lin else ()) + (TV_IN if tvl else ()):
         if f in cases:
             s.set(f, rep(cases[f]))
+    adaptive = bool(cfg.get("adaptive_rho"))
+    if adaptive:                                      # the cache is per-instance state: each case's own, else tiny_setup's
+        for k in ("rho", "Kinf", "Pinf", "C1", "C2"):
+            if "cache_" + k in cases:
+                s.set_cache_state(k, rep(cases["cache_" + k]))
     ret = s.solve()
     soc = cfg["en_state_soc"] or cfg["en_input_soc"]
     out = {f: s.get(f) for f in OUT_FIELDS + (SOC_OUT if soc else ()) + (LIN_OUT if lin else ()) + (TV_OUT if tvl else ())}
+    if adaptive:
+        for k in ("rho", "Kinf", "Pinf", "C1", "C2"):
+            out[k] = s.get_cache_state(k)
     general = s.kernel_path() == "cover"          # the coverage kernel always leaves q|r and p|d behind
     if debug or general:
         for f in ("q", "r", "p", "d"):

@@ -167,7 +167,7 @@ def test_headline_kernel_register_budget():
     assert p.returncode == 0, p.stderr[-2000:]
     blocks = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                         p.stderr, re.S)
-    head = [b for b in blocks if "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0E" in b[0]]
+    head = [b for b in blocks if "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0EE" in b[0]]     # <12,4,10, box only, dpp_mode 2, plain>
     assert len(head) == 1, [b[0] for b in blocks][:4]
     _, vgpr, agpr, scratch, occ = head[0]
     assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, head[0]

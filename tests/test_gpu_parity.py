@@ -48,6 +48,10 @@ def assert_match(out, ref, rtol, what):
                 assert e <= rtol, f"{what}: field {k} case {b} rel err {e:.3e} > {rtol}"
     for k in ("primal_residual_state", "primal_residual_input", "dual_residual_state", "dual_residual_input"):
         assert np.allclose(out[k], ref[k], rtol=1e-6, atol=1e-11), f"{what}: {k}: {out[k]} vs {ref[k]}"
+    if "rho" in ref:                                  # adaptive rho: cache->rho after the solve (Kinf, Pinf, C1, C2 are matrices: above)
+        assert "rho" in out and np.allclose(out["rho"], ref["rho"], rtol=rtol, atol=0.0), f"{what}: rho {out['rho']} vs {ref['rho']}"
+        for k in ("Kinf", "Pinf", "C1", "C2"):
+            assert k in out, k
     return worst
 
 

@@ -42,7 +42,8 @@ BATCH_SYMBOLS = (
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
-    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy")
+    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy",
+    "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -119,6 +120,10 @@ def lib():
         L.tiny_jit_compile.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
+        L.tiny_batch_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.tiny_batch_set_sensitivity.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.tiny_batch_set_cache_state.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.tiny_batch_get_cache_state.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.tiny_rccl_unique_id.argtypes = [C.c_void_p]
         L.tiny_rccl_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.tiny_rccl_comm_destroy.argtypes = [C.c_void_p]
@@ -404,6 +409,34 @@ class TinyBatchSolver:
 
     def reduce_stats_async(self, device_out):
         self._check(lib().tiny_batch_reduce_stats(self._h, None, C.c_void_p(device_out)), "reduce_stats")
+
+    # ---- adaptive rho (types.hpp:75-79; admm.cpp:397-423; rho_benchmark.cpp)
+    def set_adaptive_rho(self, enable=1, rho_min=1.0, rho_max=100.0, clip=1):
+        self._check(lib().tiny_batch_set_adaptive_rho(self._h, int(enable), float(rho_min), float(rho_max), int(clip)), "set_adaptive_rho")
+
+    def set_sensitivity(self, dKinf, dPinf, dC1=None, dC2=None):
+        """(rows, cols) arrays: dKinf_drho (nu, nx), dPinf_drho (nx, nx), dC1_drho (nu, nu), dC2_drho (nx, nx)"""
+        nx, nu = self.nx, self.nu
+        a = [_colmajor(dKinf, (nu, nx)), _colmajor(dPinf, (nx, nx)), None if dC1 is None else _colmajor(dC1, (nu, nu)),
+             None if dC2 is None else _colmajor(dC2, (nx, nx))]
+        self._check(lib().tiny_batch_set_sensitivity(self._h, *[None if v is None else v.ctypes.data_as(_dp) for v in a]), "set_sensitivity")
+
+    _CACHE_SHAPES = {"rho": lambda s: (1, 1), "Kinf": lambda s: (s.nu, s.nx), "Pinf": lambda s: (s.nx, s.nx),
+                     "C1": lambda s: (s.nu, s.nu), "C2": lambda s: (s.nx, s.nx)}
+
+    def set_cache_state(self, which, value):
+        """per-instance cache state of an adaptive batch: value [batch] for 'rho', [batch, rows, cols] otherwise"""
+        r, c = self._CACHE_SHAPES[which](self)
+        a = np.asarray(value, dtype=np.float64).reshape(self.batch, r, c)
+        flat = np.ascontiguousarray(a.transpose(0, 2, 1)).ravel()
+        self._check(lib().tiny_batch_set_cache_state(self._h, which.encode(), flat.ctypes.data_as(_dp)), f"set_cache_state({which})")
+
+    def get_cache_state(self, which):
+        r, c = self._CACHE_SHAPES[which](self)
+        out = np.zeros((self.batch, c, r))
+        self._check(lib().tiny_batch_get_cache_state(self._h, which.encode(), out.ctypes.data_as(_dp)), f"get_cache_state({which})")
+        out = out.transpose(0, 2, 1)
+        return out[:, 0, 0] if which == "rho" else out
 
     def allreduce_stats(self, comm, n_ranks, rank, total_batch):
         """the path's one exchange on an RCCL communicator the caller owns (tiny_batch_allreduce_stats); returns the

@@ -68,6 +68,15 @@ enum : int {
 // Alin_u[k][j-nx]), the offset b_k and ||a_k||^2 of this lane's family (b = +inf where there is no constraint k).
 // The time-varying tables carry one such block per slot (input lanes shifted by one knot, like the bounds).
 enum : int { LIN_KMAX = 4, LIN_KMAX_BIG = 32 };      // half-spaces per knot and family: compiled-in variants / largest run-time instantiated one
+// Lane tables of the adaptive-rho variant (ADAPT; SolveArgs::atab), [column k][16 lanes] each:
+enum : int {
+    ATAB_AT = 0,         // cols k<nx multiply g_{i+1}[k]: state lanes A[k][j] (A' g), input lanes B[k][j-nx] (B' g)
+    ATAB_DK = 256,       // dKinf_drho: state lanes cols k<nu dK[k][j] (their -Kinf' entries), input lanes cols k<nx dK[j-nx][k]
+    ATAB_DP = 512,       // dPinf_drho: state lanes cols k<nx dP[k][j] (column j, the one lane j keeps up to date)
+    ATAB_DC1 = 768,      // dC1_drho:   lanes j<nu cols k<nu dC1[k][j]
+    ATAB_DC2 = 1024,     // dC2_drho:   state lanes cols k<nx dC2[k][j]
+    ATAB_DOUBLES = 1280,
+};
 static inline int tab_lin_offset(int N) { return TAB_BOUNDS + 2 * N * 16; }
 static inline int tab_tlin_offset(int N, int kmax = LIN_KMAX) { return tab_lin_offset(N) + 3 * kmax * 16; }
 static inline int tab_doubles(int N, int kmax = LIN_KMAX) { return tab_tlin_offset(N, kmax) + 3 * N * kmax * 16; }
@@ -122,6 +131,13 @@ struct SolveArgs {
     int iter_base;
     int* next_index;
     int* next_count;
+    // Adaptive rho (ADAPT variants; admm.cpp:397-423 + rho_benchmark.cpp): the cache is per-instance STATE -- rho, Kinf, Pinf
+    // (and the dead copies C1, C2) move every 5th iteration and persist from solve to solve.  arho [batch]; aK [batch][nu*nx],
+    // aP [batch][nx*nx], aC1 [batch][nu*nu], aC2 [batch][nx*nx] column-major (aC1 / aC2 may be null); atab: ATAB_* lane tables.
+    double *arho, *aK, *aP, *aC1, *aC2;
+    const double* atab;
+    double arho_min, arho_max;
+    int aclip;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -313,6 +329,14 @@ __device__ __forceinline__ double soc_component(double s0, double s1, double s2,
     return r;
 }
 
+// a + d * b with the product rounded before the sum, as the reference's x86-64 build (no FMA contraction) evaluates
+// `Kinf + delta_rho * dKinf_drho` (rho_benchmark.cpp:201-204)
+__device__ __forceinline__ double taylor_step(double a, double d, double b) {
+#pragma clang fp contract(off)
+    const double t = d * b;
+    return a + t;
+}
+
 // ---- the kernel -------------------------------------------------------------------------------
 // Slot convention: lane j keeps N-long register arrays indexed by "slot" s.  State lanes (j < NX):
 // slot s = knot s.  Input lanes: slot s = knot s-1 (slot 0 is a neutral dummy), because the forward
@@ -326,9 +350,10 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
 
 // LIN: bit 0 = static half-spaces (admm.cpp:137-173), bit 1 = time-varying ones (:176-211); 0 = neither
 // HET: per-instance problem data (riccati_kernel.hip.h): the matrix rows are re-loaded for every instance
-template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX>
+// ADAPT: adaptive rho (admm.cpp:397-423): per-instance rho / Kinf / Pinf, re-estimated every 5th iteration
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(LIN ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC), LIN ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC))))
+__attribute__((amdgpu_waves_per_eu((LIN || ADAPT) ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC), (LIN || ADAPT) ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC))))
 void admm_solve_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
@@ -345,6 +370,7 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sHi[N * 16];
     __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
     __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
+    __shared__ double sP[ADAPT ? 4 * NX * NX : 1];            // ADAPT: each row's own Pinf, column-major (lane j keeps column j current)
     if constexpr (LS) for (int e = lane; e < 3 * KMAX * 16; e += 64) sLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + e];
     if constexpr (LT) for (int e = lane; e < 3 * N * KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * KMAX * 16 + e];
     for (int e = lane; e < NX * 16; e += 64) sPt[e] = P.tab[TAB_PT + e];
@@ -408,6 +434,21 @@ void admm_solve_kernel(const SolveArgs P) {
                 qr = het[TAB_VEC + VEC_QR * 16 + j];
                 rho = het[TAB_VEC + 8 * 16 + j];               // VEC_RHO (riccati_kernel.hip.h)
             }
+            if constexpr (ADAPT) {                             // this instance's own rho / Kinf / Pinf (they persist from solve to solve)
+                rho = P.arho[b];
+                const double* aK = P.aK + (size_t)b * (NU * NX);
+                if (is_state) {
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) mb[NX + k] = -aK[k + NU * j];            // -Kinf'[j][k]
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) sP[grp * NX * NX + k + NX * j] = P.aP[(size_t)b * (NX * NX) + k + NX * j];
+                } else if (is_input) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) mf1[k] = -aK[(j - NX) + NU * k];         // -Kinf[j-nx][k]
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             // record base of this lane: input lanes read knot s-1 at slot s
             const size_t lbase = (size_t)b * (N * NZ) + j - (is_input ? NZ : 0);
             double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
@@ -446,7 +487,8 @@ void admm_solve_kernel(const SolveArgs P) {
             auto terminal_term = [&]() {   // -(Xref[:,N-1]^T Pinf) (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
-                for (int k = 0; k < NX; ++k) pt[k] = HET ? het[TAB_PT + k * 16 + j] : sPt[k * 16 + j];
+                for (int k = 0; k < NX; ++k)
+                    pt[k] = ADAPT ? sP[grp * NX * NX + k + NX * (is_state ? j : 0)] : (HET ? het[TAB_PT + k * 16 + j] : sPt[k * 16 + j]);
                 const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
                 QX[N - 1] = is_state ? -xp : QX[N - 1];
@@ -609,6 +651,97 @@ void admm_solve_kernel(const SolveArgs P) {
                     }
                     slot_update(N - 1, lo_c, hi_c);
                     iter += 1;                                                      // :394
+                    if constexpr (ADAPT) {
+                        // ---- adaptive rho, admm.cpp:397-423: every 5th pass of the loop index (after iterations 6, 11, ...).
+                        // benchmark_rho_adaptation (rho_benchmark.cpp:207-249) builds dense OSQP-style matrices and multiplies
+                        // them out; every entry it multiplies by zero is skipped here, what is left is evaluated block by block:
+                        //   rows of A x - z:  u_i - znew_i  and  (A x_i + B u_i - x_{i+1}) - vnew_{i+1}          (:78-102, :144-150)
+                        //   P x + q + A' y:   (Q x_i | Pinf x_{N-1}) + Q x_i + (A' g_{i+1} - g_i),  R u_i + R u_i + (y_i + B' g_{i+1})   (:107-168)
+                        if (it > 0 && it % 5 == 0) {
+                            double at[NX];
+#pragma unroll
+                            for (int k = 0; k < NX; ++k) at[k] = P.atab[ATAB_AT + k * 16 + j];
+                            double pri_res = 0.0, ax_max = 0.0, z_max = 0.0, dual_res = 0.0, px_max = 0.0, aty_max = 0.0, q_max = 0.0;
+                            double pxq_max = 0.0;              // max |Q x_i|, |R u_i| over the knots before the last: entries of P x AND of q
+#pragma unroll
+                            for (int i = 0; i < N - 1; ++i) {
+                                // primal rows of knot i live in slot i+1: input lanes u_i, state lanes the dynamics defect
+                                const double axs = ring_sum<MODE, 0, NX>(0.0, X[i], mf1);            // state lanes: A x_i
+                                const double dyn = ring_short<MODE, NX, NU>(axs, is_input ? X[i + 1] : 0.0, mf2) - X[i + 1];
+                                const double a = is_state ? dyn : X[i + 1];
+                                const double zz = VN[i + 1];
+                                const bool on = is_state || is_input;
+                                pri_res = fmax(pri_res, on ? fabs(a - zz) : 0.0);
+                                ax_max = fmax(ax_max, on ? fabs(a) : 0.0);
+                                z_max = fmax(z_max, on ? fabs(zz) : 0.0);
+                                // dual rows: state lanes knot i, input lanes knot i (slot i+1); A' g_{i+1} | B' g_{i+1} from one chain
+                                const double init = is_state ? (i >= 1 ? -G[i] : 0.0) : G[i + 1];
+                                const double aty = ring_sum<MODE, 0, NX>(init, G[i + 1], at);
+                                const double xs = is_state ? X[i] : X[i + 1];
+                                const double px = qr * xs;                                          // P block = Q | R (:114, :119)
+                                dual_res = fmax(dual_res, on ? fabs((px + px) + aty) : 0.0);       // q = Q x | R u (:132, :137)
+                                pxq_max = fmax(pxq_max, on ? fabs(px) : 0.0);
+                                aty_max = fmax(aty_max, on ? fabs(aty) : 0.0);
+                            }
+                            {   // last knot (state lanes): P block = the CURRENT Pinf (:112), A' y = -g_{N-1}
+                                double prow[NX];
+#pragma unroll
+                                for (int k = 0; k < NX; ++k) prow[k] = sP[grp * NX * NX + (is_state ? j : 0) + NX * k];   // Pinf[j][k]
+                                const double pxl = ring_sum<MODE, 0, NX>(0.0, X[N - 1], prow);
+                                const double ql = qr * X[N - 1];
+                                const double atyl = -G[N - 1];
+                                dual_res = fmax(dual_res, is_state ? fabs((pxl + ql) + atyl) : 0.0);
+                                px_max = fmax(pxq_max, is_state ? fabs(pxl) : 0.0);
+                                aty_max = fmax(aty_max, is_state ? fabs(atyl) : 0.0);
+                                q_max = fmax(pxq_max, is_state ? fabs(ql) : 0.0);                  // q uses Q at the last knot too (:132)
+                            }
+                            pri_res = grp_max16(pri_res); ax_max = grp_max16(ax_max); z_max = grp_max16(z_max);
+                            dual_res = grp_max16(dual_res); px_max = grp_max16(px_max); aty_max = grp_max16(aty_max); q_max = grp_max16(q_max);
+                            // predict_rho, rho_benchmark.cpp:174-194
+                            const double pri_norm = fmax(ax_max, z_max);
+                            const double dual_norm = fmax(fmax(px_max, aty_max), q_max);
+                            const double eps = 1e-10;
+                            const double normalized_pri = pri_res / (pri_norm + eps);
+                            const double normalized_dual = dual_res / (dual_norm + eps);
+                            const double ratio = normalized_pri / (normalized_dual + eps);
+                            double new_rho = rho * sqrt(ratio);
+                            if (P.aclip) new_rho = fmin(fmax(new_rho, P.arho_min), P.arho_max);
+                            // update_matrices_with_derivatives, rho_benchmark.cpp:196-210 (the second call at admm.cpp:421 adds 0)
+                            const double delta = new_rho - rho;
+                            if (is_state) {
+#pragma unroll
+                                for (int k = 0; k < NU; ++k) mb[NX + k] = -taylor_step(-mb[NX + k], delta, P.atab[ATAB_DK + k * 16 + j]);
+#pragma unroll
+                                for (int k = 0; k < NX; ++k) {
+                                    const int e = grp * NX * NX + k + NX * j;
+                                    sP[e] = taylor_step(sP[e], delta, P.atab[ATAB_DP + k * 16 + j]);
+                                }
+                                if (P.aC2) {
+#pragma unroll
+                                    for (int k = 0; k < NX; ++k) {
+                                        double* c2 = P.aC2 + (size_t)b * (NX * NX) + k + NX * j;
+                                        *c2 = taylor_step(*c2, delta, P.atab[ATAB_DC2 + k * 16 + j]);
+                                    }
+                                }
+                            } else if (is_input) {
+#pragma unroll
+                                for (int k = 0; k < NX; ++k) mf1[k] = -taylor_step(-mf1[k], delta, P.atab[ATAB_DK + k * 16 + j]);
+                            }
+                            if (P.aC1 && j < NU) {
+#pragma unroll
+                                for (int k = 0; k < NU; ++k) {
+                                    double* c1 = P.aC1 + (size_t)b * (NU * NU) + k + NU * j;
+                                    *c1 = taylor_step(*c1, delta, P.atab[ATAB_DC1 + k * 16 + j]);
+                                }
+                            }
+                            rho = new_rho;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            // p[:,N-1] = -(Xref[:,N-1]' Pinf) - ... is evaluated with the Pinf of the moment (admm.cpp:292)
+                            QX[N - 1] = qx_last_plain;
+                            terminal_term();
+                        }
+                    }
                     // ---- termination_condition, admm.cpp:310-328
                     bool conv = false;
                     if (countdown > 0 && --countdown == 0) {
@@ -659,6 +792,15 @@ void admm_solve_kernel(const SolveArgs P) {
                             P.dbg_pd[off] = is_state ? Pd[s] : Dd[s];       // work->p | work->d
                         }
                     }
+                }
+            }
+            if constexpr (ADAPT) {
+                if (j == 0) P.arho[b] = rho;
+                if (is_state) {
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) P.aK[(size_t)b * (NU * NX) + k + NU * j] = -mb[NX + k];
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) P.aP[(size_t)b * (NX * NX) + k + NX * j] = sP[grp * NX * NX + k + NX * j];
                 }
             }
             if (P.x0_next && acc_iter > 0 && is_state) P.x0_next[(size_t)b * NX + j] = X[1];     // x1 = A x0 + B u0 + f (needs a forward pass)

@@ -366,7 +366,7 @@ static int tile_lin_variant(const TinyBatch* b) {
 static bool use_tile(const TinyBatch* b) {
     if (linear_active(b) && (tile_lin_variant(b) == 0 || b->no_jit || b->tile_soc_failed)) return false;
     // (a cone on a tile shape needs the SOC variant, which only exists through run-time instantiation)
-    return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile) && !b->no_tile && !b->hetero && !b->force_general && !b->debug &&
+    return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile) && !b->no_tile && !b->hetero && !b->adaptive && !b->force_general && !b->debug &&
            !b->d_traj && !b->reset_duals && !b->one_shot;
 }
 
@@ -407,6 +407,7 @@ static int launch_tile(TinyBatch* b) {
         HIP_TRY(b, hipMemcpyAsync(b->d_ttab, b->h_ttab.data(), b->h_ttab.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
     SolveArgs a;
+    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0;
     memset(&a, 0, sizeof(a));
     a.tab = b->d_ttab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack; a.dual = b->d_dual;
     a.slack_prev = b->d_slack_prev; a.status = b->d_status; a.resid = b->d_resid; a.accum = b->d_accum;
@@ -457,6 +458,7 @@ static int lin_variant(const TinyBatch* b) {
     return ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
 }
 static bool use_general(const TinyBatch* b) {
+    if (b->adaptive) return false;                    // adaptive rho lives on the one-row kernel only (launch_solve refuses the rest)
     if (linear_active(b)) return lin_variant(b) == 0;
     return !b->hetero && (!has_regs(b) || b->force_general);
 }
@@ -602,6 +604,76 @@ static int upload_tables(TinyBatch* b) {
     return TINY_OK;
 }
 
+// ---- adaptive rho: per-instance cache state + the lane tables of the adaptation step -----------------------------------
+static __global__ void broadcast_vec_kernel(double* __restrict__ dst, const double* __restrict__ src, long n, int per) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i % per];
+}
+
+// every instance's cache state <- the family's cache (rho, Kinf, Pinf, C1 = Quu_inv, C2 = AmBKt: tiny_api.cpp:375-376)
+static int adaptive_fresh_state(TinyBatch* b) {
+    const int nx = b->nx, nu = b->nu;
+    std::vector<double> h;
+    h.push_back(b->cache.rho);
+    h.insert(h.end(), b->cache.Kinf.a.begin(), b->cache.Kinf.a.end());
+    h.insert(h.end(), b->cache.Pinf.a.begin(), b->cache.Pinf.a.end());
+    h.insert(h.end(), b->cache.Quu_inv.a.begin(), b->cache.Quu_inv.a.end());
+    h.insert(h.end(), b->cache.AmBKt.a.begin(), b->cache.AmBKt.a.end());
+    double* tmp = nullptr;
+    HIP_TRY(b, hipMalloc(&tmp, h.size() * sizeof(double)));
+    if (hipMemcpyAsync(tmp, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, b->stream) != hipSuccess ||
+        hipStreamSynchronize(b->stream) != hipSuccess) { (void)hipFree(tmp); return fail(b, TINY_ERR_HIP, "upload of the cache state failed"); }
+    struct { double* dst; int per; size_t off; } parts[] = {{b->d_arho, 1, 0}, {b->d_aK, nu * nx, 1}, {b->d_aP, nx * nx, (size_t)1 + nu * nx},
+                                                            {b->d_aC1, nu * nu, (size_t)1 + nu * nx + nx * nx},
+                                                            {b->d_aC2, nx * nx, (size_t)1 + nu * nx + nx * nx + nu * nu}};
+    for (auto& p : parts) {
+        hipLaunchKernelGGL(broadcast_vec_kernel, dim3(512), dim3(256), 0, b->stream, p.dst, tmp + p.off, (long)b->batch * p.per, p.per);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(tmp); return fail(b, TINY_ERR_HIP, "broadcast of the cache state failed"); }
+    }
+    const hipError_t e = hipStreamSynchronize(b->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(b, TINY_ERR_HIP, "broadcast of the cache state failed");
+    b->astate_fresh = true;
+    return TINY_OK;
+}
+
+static int ensure_adaptive(TinyBatch* b, bool need_tables = true) {
+    const int nx = b->nx, nu = b->nu;
+    const size_t B = b->batch;
+    if (!b->d_arho) {
+        HIP_TRY(b, hipMalloc(&b->d_arho, B * sizeof(double)));
+        HIP_TRY(b, hipMalloc(&b->d_aK, B * nu * nx * sizeof(double)));
+        HIP_TRY(b, hipMalloc(&b->d_aP, B * nx * nx * sizeof(double)));
+        HIP_TRY(b, hipMalloc(&b->d_aC1, B * nu * nu * sizeof(double)));
+        HIP_TRY(b, hipMalloc(&b->d_aC2, B * nx * nx * sizeof(double)));
+        HIP_TRY(b, hipMalloc(&b->d_atab, ATAB_DOUBLES * sizeof(double)));
+        if (int rc = adaptive_fresh_state(b)) return rc;
+        b->atab_dirty = true;
+    }
+    if (b->atab_dirty && need_tables) {
+        if ((int)b->dKinf.size() != nu * nx || (int)b->dPinf.size() != nx * nx)
+            return fail(b, TINY_ERR_DIM, "adaptive rho is on but the sensitivity tables are not set (tiny_batch_set_sensitivity)");
+        std::vector<double> t(ATAB_DOUBLES, 0.0);
+        auto at = [&](int base, int k, int j) -> double& { return t[(size_t)base + k * 16 + j]; };
+        for (int j = 0; j < nx; ++j) {                       // state lanes
+            for (int k = 0; k < nx; ++k) at(ATAB_AT, k, j) = b->A(k, j);                        // (A' g)_j = sum_k A[k][j] g_k
+            for (int k = 0; k < nu; ++k) at(ATAB_DK, k, j) = b->dKinf[k + (size_t)nu * j];      // dK[k][j]
+            for (int k = 0; k < nx; ++k) at(ATAB_DP, k, j) = b->dPinf[k + (size_t)nx * j];      // dP[k][j]
+            for (int k = 0; k < nx; ++k) at(ATAB_DC2, k, j) = b->dC2.empty() ? 0.0 : b->dC2[k + (size_t)nx * j];
+        }
+        for (int r = 0; r < nu; ++r) {                       // input lanes
+            const int j = nx + r;
+            for (int k = 0; k < nx; ++k) at(ATAB_AT, k, j) = b->B(k, r);                        // (B' g)_r = sum_k B[k][r] g_k
+            for (int k = 0; k < nx; ++k) at(ATAB_DK, k, j) = b->dKinf[r + (size_t)nu * k];      // dK[r][k]
+        }
+        for (int j = 0; j < nu; ++j)                          // C1 is nu x nu: its column j is kept by lane j
+            for (int k = 0; k < nu; ++k) at(ATAB_DC1, k, j) = b->dC1.empty() ? 0.0 : b->dC1[k + (size_t)nu * j];
+        HIP_TRY(b, hipMemcpyAsync(b->d_atab, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(b, hipStreamSynchronize(b->stream));
+        b->atab_dirty = false;
+    }
+    return TINY_OK;
+}
+
 int launch_projection(int which, double* v, const double* a, int n, float mu, double bb) {
     if (which == 0) hipLaunchKernelGGL(project_soc_kernel, dim3(1), dim3(64), 0, nullptr, v, n, mu);
     else hipLaunchKernelGGL(project_hyperplane_kernel, dim3(1), dim3(64), 0, nullptr, v, a, n, bb);
@@ -616,6 +688,8 @@ bool soc_active(const TinyBatch* b) {
 int launch_solve(TinyBatch* b) {
     if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
         return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous problem data needs the register-resident kernel (nx+nu <= 16, at most 4 half-spaces per knot and family)");
+    if (b->adaptive && !has_regs(b))
+        return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho needs the register-resident kernel (nx+nu <= 16, horizon within the register file)");
     const int path = use_tile(b) ? 1 : (use_general(b) ? 2 : 0);
     if (path != b->last_path) { b->tab_dirty = true; b->last_path = path; }   // each path has its own table layout
     if (path == 1) {
@@ -633,6 +707,7 @@ int launch_solve(TinyBatch* b) {
     if (int rc = upload_tables(b)) return rc;
     const bool soc = soc_active(b);
     SolveArgs a;
+    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0;
     a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
@@ -668,7 +743,7 @@ int launch_solve(TinyBatch* b) {
     // (every soc x debug x mode; LIN and HET without debug at mode 2); anything else -- an unseen shape, or debug outputs
     // together with half-spaces / per-instance data, or both of those -- is instantiated now (jit.hpp).
     const int mode = (b->dpp_mode >= 0 && b->dpp_mode <= 2) ? b->dpp_mode : 0;
-    JitKey jk = {b->nx, b->nu, b->N, soc ? 1 : 0, b->debug ? 1 : 0, mode, 0, b->hetero ? 1 : 0, LIN_KMAX};
+    JitKey jk = {b->nx, b->nu, b->N, soc ? 1 : 0, b->debug ? 1 : 0, mode, 0, b->hetero ? 1 : 0, LIN_KMAX, 0};
     a.lslack = a.ldual = a.tlslack = a.tldual = nullptr;
     a.n_lin = a.n_tlin = 0;
     if (const int lv = lin_variant(b)) {
@@ -681,10 +756,20 @@ int launch_solve(TinyBatch* b) {
         jk.lin = lv;
         jk.kmax = lin_kmax(b);
     }
-    if (jk.lin || jk.het) jk.mode = 2;               // those variants exist on the single-chain FMA blocks only
+    if (b->adaptive) {
+        if (b->hetero || jk.lin || b->one_shot || b->repack_after)
+            return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho does not combine with heterogeneous data / half-spaces / one_shot / repack_after");
+        if (int rc = ensure_adaptive(b)) return rc;
+        a.arho = b->d_arho; a.aK = b->d_aK; a.aP = b->d_aP; a.aC1 = b->d_aC1; a.aC2 = b->d_aC2; a.atab = b->d_atab;
+        a.arho_min = b->adaptive_min; a.arho_max = b->adaptive_max; a.aclip = b->adaptive_clip ? 1 : 0;
+        b->astate_fresh = false;
+        jk.adapt = 1;
+    }
+    if (jk.lin || jk.het || jk.adapt) jk.mode = 2;   // those variants exist on the single-chain FMA blocks only
     SolveKernel k = nullptr;
     if (b->kernel) {
-        if (!jk.lin && !jk.het) k = b->kernel->k[jk.soc][jk.dbg][jk.mode];
+        if (jk.adapt) k = jk.soc ? nullptr : b->kernel->kadapt[jk.dbg];
+        else if (!jk.lin && !jk.het) k = b->kernel->k[jk.soc][jk.dbg][jk.mode];
         else if (jk.lin && !jk.het && !jk.dbg && jk.kmax == LIN_KMAX) k = b->kernel->klin[jk.soc][jk.lin];
         else if (jk.het && !jk.lin && !jk.dbg) k = b->kernel->khet[jk.soc];
     }
@@ -702,6 +787,7 @@ int launch_solve(TinyBatch* b) {
                 }
                 return fail(b, TINY_ERR_UNSUPPORTED, "this combination of debug outputs / half-spaces / per-instance data needs hipRTC: %s", why.c_str());
             }
+            if (b->adaptive) return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho kernel for (nx,nu,N)=(%d,%d,%d) could not be instantiated: %s", b->nx, b->nu, b->N, why.c_str());
             b->jit_failed = true;                    // has_regs() turns false: the coverage kernel takes over
             b->tab_dirty = true;
             if (b->hetero || b->steps_per_launch > 1 || b->d_traj || b->reset_duals || b->one_shot)
@@ -968,7 +1054,7 @@ int tiny_batch_destroy(TinyBatch* b) {
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
                     b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count,
-                    b->d_wire};
+                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab};
     for (void* p : bufs)
         if (p) hipFree(p);
     if (b->h_wire) hipHostFree(b->h_wire);
@@ -1153,6 +1239,63 @@ int tiny_batch_reset(TinyBatch* b) {
     for (double* p : z)
         if (p) HIP_TRY(b, hipMemsetAsync(p, 0, kpi_bytes, b->stream));
     HIP_TRY(b, hipMemsetAsync(b->d_accum, 0, (size_t)b->batch * sizeof(uint2), b->stream));
+    if (b->d_arho && !b->astate_fresh)               // adaptive rho: every instance's cache back to the one tiny_setup computed
+        if (int rc = adaptive_fresh_state(b)) return rc;
+    return TINY_OK;
+}
+
+// == settings->adaptive_rho, adaptive_rho_min / _max / _enable_clipping (types.hpp:75-79)
+int tiny_batch_set_adaptive_rho(TinyBatch* b, int enable, double rho_min, double rho_max, int enable_clipping) {
+    if (!b) return TINY_ERR_NULL;
+    b->adaptive = enable != 0; b->adaptive_min = rho_min; b->adaptive_max = rho_max; b->adaptive_clip = enable_clipping != 0;
+    return TINY_OK;
+}
+
+// == cache->dKinf_drho (nu x nx), dPinf_drho (nx x nx), dC1_drho (nu x nu), dC2_drho (nx x nx), column-major, shared by every
+// instance (what tiny_initialize_sensitivity_matrices fills, tiny_api.cpp:479-540); dC1 / dC2 may be NULL (taken as zero)
+int tiny_batch_set_sensitivity(TinyBatch* b, const double* dKinf, const double* dPinf, const double* dC1, const double* dC2) {
+    if (!b || !dKinf || !dPinf) return TINY_ERR_NULL;
+    const size_t nx = b->nx, nu = b->nu;
+    b->dKinf.assign(dKinf, dKinf + nu * nx);
+    b->dPinf.assign(dPinf, dPinf + nx * nx);
+    if (dC1) b->dC1.assign(dC1, dC1 + nu * nu); else b->dC1.clear();
+    if (dC2) b->dC2.assign(dC2, dC2 + nx * nx); else b->dC2.clear();
+    b->atab_dirty = true;
+    return TINY_OK;
+}
+
+// Per-instance cache state of an adaptive batch, host arrays with a leading batch axis (column-major matrices): which =
+// "rho" [batch], "Kinf" [batch][nu*nx], "Pinf" [batch][nx*nx], "C1" [batch][nu*nu], "C2" [batch][nx*nx].
+static int cache_state_array(TinyBatch* b, const char* which, double** arr, size_t* per) {
+    if (!strcmp(which, "rho")) { *arr = b->d_arho; *per = 1; }
+    else if (!strcmp(which, "Kinf")) { *arr = b->d_aK; *per = (size_t)b->nu * b->nx; }
+    else if (!strcmp(which, "Pinf")) { *arr = b->d_aP; *per = (size_t)b->nx * b->nx; }
+    else if (!strcmp(which, "C1")) { *arr = b->d_aC1; *per = (size_t)b->nu * b->nu; }
+    else if (!strcmp(which, "C2")) { *arr = b->d_aC2; *per = (size_t)b->nx * b->nx; }
+    else return fail(b, TINY_ERR_ARG, "unknown cache state %s", which);
+    return TINY_OK;
+}
+int tiny_batch_set_cache_state(TinyBatch* b, const char* which, const double* src) {
+    if (!b || !which || !src) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    if (!b->adaptive) return fail(b, TINY_ERR_ARG, "the cache is per-instance state only with adaptive rho on (tiny_batch_set_adaptive_rho)");
+    if (!b->d_arho) { if (int rc = ensure_adaptive(b, false)) return rc; }
+    double* arr; size_t per;
+    if (int rc = cache_state_array(b, which, &arr, &per)) return rc;
+    HIP_TRY(b, hipMemcpyAsync(arr, src, (size_t)b->batch * per * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+    b->astate_fresh = false;
+    return TINY_OK;
+}
+int tiny_batch_get_cache_state(TinyBatch* b, const char* which, double* dst) {
+    if (!b || !which || !dst) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    if (!b->adaptive) return fail(b, TINY_ERR_ARG, "the cache is per-instance state only with adaptive rho on (tiny_batch_set_adaptive_rho)");
+    if (!b->d_arho) { if (int rc = ensure_adaptive(b, false)) return rc; }
+    double* arr; size_t per;
+    if (int rc = cache_state_array(b, which, &arr, &per)) return rc;
+    HIP_TRY(b, hipMemcpyAsync(dst, arr, (size_t)b->batch * per * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
     return TINY_OK;
 }
 

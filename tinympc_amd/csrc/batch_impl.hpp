@@ -90,6 +90,11 @@ struct TinyBatch {
     int* d_traj_offsets = nullptr;
     int traj_points = 0;
     long traj_step = 0;
+    // adaptive rho (admm.cpp:397-423, rho_benchmark.cpp): settings, sensitivity tables (column-major), per-instance cache state
+    bool adaptive = false, adaptive_clip = true, atab_dirty = true, astate_fresh = false;
+    double adaptive_min = 1.0, adaptive_max = 100.0;
+    std::vector<double> dKinf, dPinf, dC1, dC2;
+    double *d_arho = nullptr, *d_aK = nullptr, *d_aP = nullptr, *d_aC1 = nullptr, *d_aC2 = nullptr, *d_atab = nullptr;
     // tiny_batch_allreduce_stats (group_api.hip): the gather table of the 64-byte statistics messages, device + pinned host
     double *d_wire = nullptr, *h_wire = nullptr;
     int wire_ranks = 0;

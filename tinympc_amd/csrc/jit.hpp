@@ -10,10 +10,10 @@
 namespace tinympc_amd {
 
 struct JitKey {
-    int nx, nu, N, soc, dbg, mode, lin, het, kmax;
+    int nx, nu, N, soc, dbg, mode, lin, het, kmax, adapt;
     bool operator<(const JitKey& o) const {
-        const int a[9] = {nx, nu, N, soc, dbg, mode, lin, het, kmax}, b[9] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het, o.kmax};
-        for (int i = 0; i < 9; ++i)
+        const int a[10] = {nx, nu, N, soc, dbg, mode, lin, het, kmax, adapt}, b[10] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het, o.kmax, o.adapt};
+        for (int i = 0; i < 10; ++i)
             if (a[i] != b[i]) return a[i] < b[i];
         return false;
     }

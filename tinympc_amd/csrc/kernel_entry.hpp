@@ -9,6 +9,7 @@ struct KernelEntry {
     SolveKernel k[2][2][3];   // [soc][dbg][dpp_mode]
     SolveKernel klin[2][4];   // [soc][LIN 1..3]: register-resident linear constraints (dpp_mode 2, no debug outputs)
     SolveKernel khet[2];      // [soc]: per-instance problem data (dpp_mode 2, no debug outputs)
+    SolveKernel kadapt[2];    // [dbg]: adaptive rho (dpp_mode 2, no cone)
 };
 struct TileEntry {
     int nx, nu, N, W, R;
@@ -27,4 +28,6 @@ struct TileEntry {
                     { KERNELS_MODES(NX, NU, NN, true, false), KERNELS_MODES(NX, NU, NN, true, true) } },    \
       { KERNELS_LIN(NX, NU, NN, false), KERNELS_LIN(NX, NU, NN, true) },                                    \
       { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, true>,                               \
-        tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, true> } }
+        tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, true> },                              \
+      { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, true>, \
+        tinympc_amd::admm_solve_kernel<NX, NU, NN, false, true, 2, 0, false, tinympc_amd::LIN_KMAX, true> } }
