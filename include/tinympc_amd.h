@@ -424,6 +424,10 @@ int tiny_set_default_settings(TinySettings* settings);
 int tiny_set_x0(TinySolver* solver, const TinyVectorPOD* x0);
 int tiny_set_x_ref(TinySolver* solver, const TinyMatrixPOD* x_ref);
 int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref);
+/* tiny_api.hpp:54: fills cache->dKinf_drho (4 x 12), dPinf_drho (12 x 12), dC1_drho (4 x 4), dC2_drho (12 x 12) with the
+ * reference's quadrotor tables (tiny_api.cpp:479-540).  With settings->adaptive_rho = 1 tiny_solve then re-estimates rho
+ * every 5th iteration (admm.cpp:397-423) and writes the moved cache (rho, Kinf, Pinf, C1, C2) back into the TinyCache. */
+void tiny_initialize_sensitivity_matrices(TinySolver* solver);
 /* admm.hpp:12-17: the individual phases of one ADMM iteration on a solver's workspace.  Each uploads the workspace,
  * runs the phase on the GPU (tiny_batch_phase with a batch of one) and writes the fields the reference function
  * writes back into the workspace. */

@@ -22,11 +22,17 @@ done
 # our own caller of the exported phase functions (admm.hpp:12-34), real Eigen types across the boundary
 g++ $CXXFLAGS $INC -o "$OUT/phase_driver" "$HERE/phase_driver.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
     -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
+# our own caller of the adaptive-rho path (settings->adaptive_rho = 1 + tiny_initialize_sensitivity_matrices)
+g++ $CXXFLAGS $INC -o "$OUT/adaptive_driver" "$HERE/adaptive_driver.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
+    -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
 wait
 if [ "$1" = "--golden" ]; then
   g++ $CXXFLAGS $INC -o "$OUT/ref_phase_driver" "$HERE/phase_driver.cpp" "$REF/src/tinympc/admm.cpp" \
       "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp"
   (cd "$OUT" && ./ref_phase_driver > "$ROOT/tests/golden/stdout_phase_driver.txt"); rm -f "$OUT/ref_phase_driver"
+  g++ $CXXFLAGS $INC -o "$OUT/ref_adaptive_driver" "$HERE/adaptive_driver.cpp" "$REF/src/tinympc/admm.cpp" \
+      "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp"
+  (cd "$OUT" && ./ref_adaptive_driver > "$ROOT/tests/golden/stdout_adaptive_driver.txt"); rm -f "$OUT/ref_adaptive_driver"
   for ex in $EXAMPLES; do
     g++ $CXXFLAGS $INC -o "$OUT/ref_$ex" "$REF/examples/$ex.cpp" "$REF/src/tinympc/admm.cpp" \
         "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp" &

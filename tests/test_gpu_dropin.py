@@ -65,3 +65,30 @@ def test_plain_c_example_of_the_batched_abi():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, (p.stdout, p.stderr[-500:])
     assert "4096 instances x 60 MPC steps" in p.stdout and "kernel path 0" in p.stdout
+
+
+def test_adaptive_rho_through_the_reference_structs():
+    """tests/dropin/adaptive_driver.cpp (our caller, the reference's headers): settings->adaptive_rho = 1 and the
+    reference's own tiny_initialize_sensitivity_matrices, 60 closed-loop hover steps through tiny_solve(TinySolver*).  Per
+    step the iteration count and solved flag must be identical to the real reference's, cache->rho and the moved
+    Kinf / Pinf / C2 entries and the applied control within 1e-7 of the line's largest magnitude (they are printed after 6+
+    Taylor steps of a closed loop; the batched tests hold single solves to 1e-9)."""
+    exe = os.path.join(BUILD, "adaptive_driver")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    gold = open(os.path.join(ROOT, "tests", "golden", "stdout_adaptive_driver.txt")).read().splitlines()
+    got = p.stdout.splitlines()
+    assert len(got) == len(gold) == 61 and got[-1] == gold[-1] and gold[-1] == "total iterations 735"
+    for a, b in zip(got[:-1], gold[:-1]):
+        wa, wb = a.split(), b.split()
+        assert wa[:6] == wb[:6], (a[:60], b[:60])                  # step k iter n solved s
+        na = [float(w) for w in wa[6:] if w[0] in "-0123456789"]
+        nb = [float(w) for w in wb[6:] if w[0] in "-0123456789"]
+        assert len(na) == len(nb) == 9
+        assert abs(na[0] - nb[0]) <= 1e-9 * abs(nb[0]), (a[:80], b[:80])          # rho
+        for x, y in zip(na[1:5], nb[1:5]):                                          # cache entries: relative
+            assert abs(x - y) <= 1e-9 * max(abs(y), 1e-300), (a[:120], b[:120])
+        scale = max(abs(v) for v in nb[5:])
+        assert max(abs(x - y) for x, y in zip(na[5:], nb[5:])) <= 1e-7 * scale, (a[-80:], b[-80:])

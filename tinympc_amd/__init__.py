@@ -54,7 +54,7 @@ REFERENCE_SYMBOLS = (
     "tiny_setup", "tiny_set_bound_constraints", "tiny_set_cone_constraints", "tiny_set_linear_constraints",
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
     "tiny_solve", "solve", "tiny_update_settings", "tiny_set_default_settings", "tiny_set_x0", "tiny_set_x_ref",
-    "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy",
+    "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy", "tiny_initialize_sensitivity_matrices",
     # the phase functions of admm.hpp:12-34
     "update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual", "termination_condition",
     "project_soc", "project_hyperplane")

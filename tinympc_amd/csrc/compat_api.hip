@@ -25,6 +25,7 @@
 using namespace tinympc_amd;
 
 namespace {
+#include "_gen/sensitivity.inc"      // k_dKinf_drho[48], k_dPinf_drho[144], k_dC1_drho[16], k_dC2_drho[144], column-major
 
 // ---- Eigen-compatible storage: with default x86-64 flags Eigen allocates with plain malloc/free
 // (EIGEN_MALLOC_ALREADY_ALIGNED, Eigen/src/Core/util/Memory.h:23-57), so buffers made here can be
@@ -132,8 +133,14 @@ int sync_family(TinyBatch* b, const TinySolver* s) {
     const TinyCache* c = s->cache;
     const TinySettings* st = s->settings;
     const int nx = w->nx, nu = w->nu, N = w->N;
-    if (st->adaptive_rho)
-        return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho is outside the accelerated hot path (SURVEY.md section 2 row 4)");
+    if (st->adaptive_rho) {                          // admm.cpp:397-423: needs the d(.)/d(rho) tables in the cache
+        if (!shaped(c->dKinf_drho, nu, nx) || !shaped(c->dPinf_drho, nx, nx))
+            return fail(b, TINY_ERR_DIM, "adaptive_rho is set but cache->dKinf_drho / dPinf_drho are not %d x %d / %d x %d "
+                                         "(tiny_initialize_sensitivity_matrices)", nu, nx, nx, nx);
+        if (int rc = tiny_batch_set_sensitivity(b, c->dKinf_drho.data, c->dPinf_drho.data, shaped(c->dC1_drho, nu, nu) ? c->dC1_drho.data : nullptr,
+                                                shaped(c->dC2_drho, nx, nx) ? c->dC2_drho.data : nullptr)) return rc;
+    }
+    tiny_batch_set_adaptive_rho(b, st->adaptive_rho, st->adaptive_rho_min, st->adaptive_rho_max, st->adaptive_rho_enable_clipping);
     if (!shaped(c->Kinf, nu, nx) || !shaped(c->Pinf, nx, nx) || !shaped(c->Quu_inv, nu, nu) || !shaped(c->AmBKt, nx, nx) ||
         c->APf.rows != nx || c->BPf.rows != nu || !shaped(w->Adyn, nx, nx) || !shaped(w->Bdyn, nx, nu))
         return fail(b, TINY_ERR_DIM, "cache / dynamics have unexpected shapes");
@@ -263,6 +270,7 @@ uint64_t family_hash(const TinySolver* s) {
     h = fnv(h, s->settings, sizeof(TinySettings));
     h = fnv(h, &c->rho, 8);
     mat(c->Kinf); mat(c->Pinf); mat(c->Quu_inv); mat(c->AmBKt); vec(c->APf); vec(c->BPf);
+    if (s->settings->adaptive_rho) { mat(c->dKinf_drho); mat(c->dPinf_drho); mat(c->dC1_drho); mat(c->dC2_drho); }
     mat(w->Adyn); mat(w->Bdyn); vec(w->fdyn); vec(w->Q); vec(w->R);
     mat(w->x_min); mat(w->x_max); mat(w->u_min); mat(w->u_max);
     h = fnv(h, &w->numStateCones, 8); vec(w->cx); vec(w->cu); ivec(w->Acx); ivec(w->Acu); ivec(w->qcx); ivec(w->qcu);
@@ -343,8 +351,40 @@ int solve_group(TinySolver** solvers, int n) {
         off += (size_t)n * fsize(fm);
     }
     if (int rc = tiny_batch_set(b, TINY_F_X0, ctx.d_xfer + off, TINY_DEVICE)) return rc;
+    // adaptive rho: every solver's own cache is state (rho, Kinf, Pinf and the dead copies C1, C2 move during the solve and
+    // persist, rho_benchmark.cpp:196-210): up before the launch, back into the caller's TinyCache after it
+    struct CachePart { const char* name; size_t per; TinyMatrixPOD TinyCache::*m; };
+    const CachePart cparts[] = {{"Kinf", (size_t)nu * nx, &TinyCache::Kinf}, {"Pinf", (size_t)nx * nx, &TinyCache::Pinf},
+                                {"C1", (size_t)nu * nu, &TinyCache::C1}, {"C2", (size_t)nx * nx, &TinyCache::C2}};
+    const bool adaptive = st0->adaptive_rho != 0;
+    std::vector<double> cbuf;
+    if (adaptive) {
+        cbuf.resize((size_t)n);
+        for (int k = 0; k < n; ++k) cbuf[k] = solvers[k]->cache->rho;
+        if (int rc = tiny_batch_set_cache_state(b, "rho", cbuf.data())) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        for (const CachePart& cp : cparts) {
+            cbuf.assign((size_t)n * cp.per, 0.0);
+            for (int k = 0; k < n; ++k) {
+                const TinyMatrixPOD& m = solvers[k]->cache->*(cp.m);
+                if ((size_t)(m.rows * m.cols) != cp.per || !m.data) return fail(b, TINY_ERR_DIM, "cache->%s of solver %d has the wrong size", cp.name, k);
+                memcpy(cbuf.data() + (size_t)k * cp.per, m.data, cp.per * sizeof(double));
+            }
+            if (int rc = tiny_batch_set_cache_state(b, cp.name, cbuf.data())) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        }
+    }
 
     if (int rc = launch_solve(b)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    if (adaptive) {
+        cbuf.resize((size_t)n);
+        if (int rc = tiny_batch_get_cache_state(b, "rho", cbuf.data())) return rc;
+        for (int k = 0; k < n; ++k) solvers[k]->cache->rho = cbuf[k];
+        for (const CachePart& cp : cparts) {
+            cbuf.resize((size_t)n * cp.per);
+            if (int rc = tiny_batch_get_cache_state(b, cp.name, cbuf.data())) return rc;
+            for (int k = 0; k < n; ++k) memcpy((solvers[k]->cache->*(cp.m)).data, cbuf.data() + (size_t)k * cp.per, cp.per * sizeof(double));
+        }
+        ctx.family_valid = false;                    // the caches moved: the next solve re-reads the family
+    }
 
     off = 0;
     for (const FieldMap& fm : out) {
@@ -702,6 +742,18 @@ int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref) {   // tiny_a
 
 int solve(TinySolver* solver) { return solve_group(&solver, 1); }          // admm.cpp:331
 int tiny_solve(TinySolver* solver) { return solve(solver); }               // tiny_api.cpp:384-386
+// tiny_api.hpp:54 / tiny_api.cpp:479-540: the quadrotor's hard-coded d(.)/d(rho) tables.  The reference assigns fixed-size
+// 4 x 12 / 12 x 12 / 4 x 4 / 12 x 12 maps whatever the solver's nx, nu are; so does this (the values are the ones the real
+// function leaves behind -- read through column-major maps over row-major literals --, kept as data: tinympc_amd/data/).
+void tiny_initialize_sensitivity_matrices(TinySolver* solver) {
+    if (!solver || !solver->cache) return;
+    TinyCache* c = solver->cache;
+    mat_assign(&c->dKinf_drho, k_dKinf_drho, 4, 12);
+    mat_assign(&c->dPinf_drho, k_dPinf_drho, 12, 12);
+    mat_assign(&c->dC1_drho, k_dC1_drho, 4, 4);
+    mat_assign(&c->dC2_drho, k_dC2_drho, 12, 12);
+}
+
 int tiny_solve_batch(TinySolver** solvers, int n) { return solve_group(solvers, n); }
 
 // ---- admm.hpp:12-17: the phases of one iteration, each on the GPU ------------------------------
