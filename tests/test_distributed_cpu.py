@@ -23,6 +23,66 @@ def test_sharding_covers_everything_once():
                 assert inter == list(range(total))
 
 
+def _suite(kind):
+    import scenarios as sc
+    # the recipes of BASELINE configs[2] (tracking, per-instance random references) and configs[4] (a sweep cell)
+    return sc.tracking_random_suite(B=23, seed=4100) if kind == "config3" else sc.sweep_suite(4, 2, 10, B=17, max_iter=200)
+
+
+def _shard_worker(rank, world, port, q, kind):
+    """one rank of a sharded config driver (tools/config_bench.py / sweep_bench.py --gpus N): round-robin shard of the same
+    seeded inputs, the solver played by the oracle, the one statistics exchange over gloo"""
+    import torch
+    import torch.distributed as dist
+    import scenarios as sc
+    from cpu_solvers import OracleSolver
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    suite = _suite(kind)
+    B = suite["cases"]["x0"].shape[0]
+    idx = np.array(shard_indices(B, rank, world, interleaved=True))
+    out = sc.run_cases(OracleSolver, dict(suite, cases={k: v[idx] for k, v in suite["cases"].items()}))
+    stats = torch.tensor([out["iter"].sum(), out["sol_solved"].sum(), len(idx), out["primal_residual_state"].max(),
+                          out["primal_residual_input"].max(), out["dual_residual_state"].max(), out["dual_residual_input"].max(),
+                          out["iter"].sum(), out["sol_solved"].sum(), 0.0], dtype=torch.float64)
+    total = allreduce_stats(stats, dist, total_batch=B)
+    q.put((rank, idx.tolist(), out["iter"].tolist(), out["x"].tolist(), total.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["config3", "config5"])
+def test_round_robin_shards_of_the_config_drivers_equal_the_single_process_run(kind):
+    import torch.multiprocessing as mp
+    import scenarios as sc
+    from cpu_solvers import OracleSolver
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q, kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = sc.run_cases(OracleSolver, _suite(kind))
+    B = len(ref["iter"])
+    seen = []
+    for rank, idx, its, xs, total in res:
+        seen += idx
+        assert np.array_equal(np.array(its), ref["iter"][idx])                  # per instance: identical iteration counts
+        assert np.array_equal(np.array(xs), ref["x"][idx])                      # ... and bit-identical trajectories
+        expect = [ref["iter"].sum(), ref["sol_solved"].sum(), B, ref["primal_residual_state"].max(), ref["primal_residual_input"].max(),
+                  ref["dual_residual_state"].max(), ref["dual_residual_input"].max(), ref["iter"].sum(), ref["sol_solved"].sum(), 0.0]
+        assert np.array_equal(total, expect)                                    # the reduced 64-byte messages = the unsharded statistics
+    assert sorted(seen) == list(range(B)) and len(np.unique(ref["iter"])) > 2    # every instance once; the batch does diverge
+
+
 def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

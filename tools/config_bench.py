@@ -1,5 +1,15 @@
 #!/usr/bin/env python3
-"""Throughput of BASELINE configs 3 and 4 at full size on one GPU (config 2 = bench.py, config 5 = sweep_bench.py).
+"""Throughput of BASELINE configs 3 and 4 at full size (config 2 = bench.py, config 5 = sweep_bench.py), on one GPU or
+sharded over the GPUs of a node:
+
+    python tools/config_bench.py out.json [config3,config4,...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+           tools/config_bench.py out.json config3,config4
+
+Under torch.distributed.run the TOTAL batch of the config is sharded round-robin by instance index
+(tinympc_amd.distributed.shard_indices(interleaved=True): iteration counts diverge) -- every rank draws
+the same seeded inputs and keeps its own instances --, there is no data-path collective, the timed region is closed by
+the one 64-byte statistics exchange (RCCL) and the slowest rank's clock counts.
 
   config 3: quadrotor_tracking (12,4,10), 262 144 instances, per-instance random references around the y-axis line
             (SURVEY.md section 8(d) recipe), duals zeroed, ONE cold solve per instance (divergent iteration counts).
@@ -16,6 +26,67 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_amd as tm  # noqa: E402
+from tinympc_amd.distributed import shard_indices  # noqa: E402
+
+RANK = int(os.environ.get("RANK", "0"))
+LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
+WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+_dist = None
+
+
+def dist_init():
+    """one process per GPU under torch.distributed.run; a no-op for a plain `python tools/config_bench.py`"""
+    global _dist
+    if WORLD > 1 or os.environ.get("TINYMPC_FORCE_DIST"):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(LOCAL_RANK)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", LOCAL_RANK))
+        _dist = dist
+    return _dist
+
+
+class Job:
+    """The sharded form of one config: this rank's instance ids, a barrier, the statistics exchange and the slowest
+    rank's wall clock -- all of them trivial when there is one rank."""
+
+    def __init__(self, total):
+        self.total = total
+        self.idx = np.array(shard_indices(total, RANK, WORLD, interleaved=True))
+        self.exchange = None
+        if _dist is not None:
+            import torch
+            self.one = torch.zeros(1, device=f"cuda:{LOCAL_RANK}")
+
+    def attach(self, solver):
+        if _dist is not None:
+            from tinympc_amd.distributed import StatsExchange
+            self.exchange = StatsExchange(solver, _dist, LOCAL_RANK, total_batch=self.total)
+        self.solver = solver
+
+    def barrier(self):
+        self.solver.synchronize()
+        if _dist is not None:
+            import torch
+            _dist.all_reduce(self.one)
+            torch.cuda.synchronize()
+
+    def stats(self):
+        """job-wide statistics (the one exchange of the path when sharded)"""
+        return self.exchange().numpy() if self.exchange is not None else self.solver.reduce_stats()
+
+    def slowest(self, seconds):
+        if _dist is None:
+            return seconds
+        import torch
+        t = torch.tensor([seconds], dtype=torch.float64, device=f"cuda:{LOCAL_RANK}")
+        _dist.all_reduce(t, op=_dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.exchange is not None:
+            self.exchange.close()
 
 
 def apply_opts(s):
@@ -35,6 +106,9 @@ def config3(B=262144, reps=3):
     Uref = rng.normal(0, 0.05, (B, nu, N - 1))
     x0 = Xref[:, :, 0].copy()
     x0[:, :3] += rng.normal(0, 0.1, (B, 3))
+    job = Job(B)
+    if WORLD > 1:
+        return config3_sharded(job, prob, Xref[job.idx], Uref[job.idx], x0[job.idx], reps)
     s = tm.TinyBatchSolver.from_problem(prob, B)
     apply_opts(s)
     s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
@@ -90,6 +164,36 @@ def config3(B=262144, reps=3):
                 hbm_frac=alg * B / t / 8e12, fp64_frac=st[0] * tm.flops_per_iter(nx, nu, N) / t / 78.6e12)
 
 
+def config3_sharded(job, prob, Xref, Uref, x0, reps):
+    """config 3 on WORLD GPUs: the total batch sharded round-robin, one cold solve per instance, wall clock of the slowest rank
+    around launch + statistics exchange"""
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    s = tm.TinyBatchSolver.from_problem(prob, len(job.idx), device=LOCAL_RANK)
+    apply_opts(s)
+    s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+    s.update_settings(max_iter=100)
+    s.set_x_ref(Xref)
+    s.set_u_ref(Uref)
+    job.attach(s)
+    best, st = None, None
+    for _ in range(reps + 1):
+        s.reset()
+        s.set_x0(x0)
+        job.barrier()
+        t0 = time.perf_counter()
+        s.solve_async()
+        st = job.stats()
+        job.barrier()
+        dt = job.slowest(time.perf_counter() - t0)
+        best = dt if best is None else min(best, dt)
+    job.close()
+    s.close()
+    return dict(config=f"quadrotor_tracking x{job.total}, per-instance random refs, one cold solve, sharded round-robin over {WORLD} GPUs",
+                batch=job.total, n_gpus=WORLD, batch_this_rank=len(job.idx), seconds=best, solves_per_s=job.total / best,
+                admm_iters_per_s=st[0] / best, iters_per_solve=st[0] / job.total, solved_fraction=st[1] / job.total,
+                fp64_frac_per_gpu=st[0] * tm.flops_per_iter(nx, nu, N) / best / 78.6e12 / WORLD)
+
+
 def config4(B=65536):
     prob, extra = tm.load_problem("rocket_landing_20hz")
     m = extra["mpc"]
@@ -98,7 +202,10 @@ def config4(B=65536):
     x0 = 1.1 * np.array(m["xinit"]) * (1 + 0.05 * rng.uniform(-1, 1, (B, nx)))
     xinit, xg = np.array(m["xinit"], dtype=float), np.array(m["xg"], dtype=float)
     traj = np.stack([xinit + (xg - xinit) * float(i) / (m["NTOTAL"] - 1) for i in range(m["NTOTAL"])])   # Xref window source
-    s = tm.TinyBatchSolver.from_problem(prob, B)
+    job = Job(B)                                  # BASELINE: "batch 64k, sharded 8 x MI355X" = 8 192 instances per GPU
+    x0 = x0[job.idx]
+    s = tm.TinyBatchSolver.from_problem(prob, len(job.idx), device=LOCAL_RANK)
+    job.attach(s)
     apply_opts(s)
     s.set_bound_constraints(np.array(m["x_min"]), np.array(m["x_max"]), np.full((nu, 1), m["u_min"]), np.full((nu, 1), m["u_max"]))
     s.set_cone_constraints(m["state_cone"]["A"], m["state_cone"]["q"], m["state_cone"]["c"],
@@ -114,17 +221,19 @@ def config4(B=65536):
         s.set_x0(x0)
         s.set_option("advance_x0", 1)
         s.set_option("steps_per_launch", T)
-        s.synchronize()
+        job.barrier()
         t0 = time.perf_counter()
         for _ in range(steps // T):
             s.solve_async()
-        s.synchronize()
-        dt = time.perf_counter() - t0
-        st = s.reduce_stats()
+        st = job.stats()                          # (sharded: the one 64-byte exchange closes the timed region)
+        job.barrier()
+        dt = job.slowest(time.perf_counter() - t0)
         out[f"steps_per_launch={T}"] = dict(seconds=dt, solves_per_s=B * steps / dt, admm_iters_per_s=st[7] / dt,
                                             iters_per_solve=st[7] / (B * steps), solved_fraction=st[8] / (B * steps))
+    job.close()
     s.close()
-    return dict(config="rocket_landing x65536, input SOC on, 90-step closed loop (wall clock incl. launches)", batch=B, **out)
+    return dict(config=f"rocket_landing x{B}, input SOC on, 90-step closed loop (wall clock incl. launches), sharded round-robin over {WORLD} GPU(s)",
+                batch=B, n_gpus=WORLD, batch_this_rank=len(job.idx), **out)
 
 
 def linear_example(B=65536, tv=False):
@@ -165,10 +274,15 @@ def linear_example(B=65536, tv=False):
 
 
 if __name__ == "__main__":
+    dist_init()
     runs = {"config3": config3, "config4": config4, "linear_static": lambda: linear_example(tv=False),
             "linear_tv": lambda: linear_example(tv=True)}
-    pick = sys.argv[2].split(",") if len(sys.argv) > 2 else list(runs)
+    default = ["config3", "config4"] if WORLD > 1 else list(runs)      # the linear examples are single-GPU experiments
+    pick = sys.argv[2].split(",") if len(sys.argv) > 2 else default
     res = {k: runs[k]() for k in pick}
-    print(json.dumps(res, indent=1))
-    if len(sys.argv) > 1:
-        json.dump(res, open(sys.argv[1], "w"), indent=1)
+    if RANK == 0:
+        print(json.dumps(res, indent=1))
+        if len(sys.argv) > 1:
+            json.dump(res, open(sys.argv[1], "w"), indent=1)
+    if _dist is not None:
+        _dist.destroy_process_group()

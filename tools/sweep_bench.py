@@ -3,6 +3,13 @@
 x0 / Xref, max_iter 500, u in [-0.5, 0.5].  Prints a markdown roofline table and writes JSON.
 
     python tools/sweep_bench.py --batch 131072 --out profiles/r01_sweep.json
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+           tools/sweep_bench.py --batch 1048576 --out sweep_8gpu.json        # BASELINE: batch 1M over 8 x MI355X
+
+Under torch.distributed.run --batch is the TOTAL batch of a cell: it is sharded round-robin by instance index over the
+ranks (every rank draws the same seeded inputs and keeps its own instances; iteration counts diverge), each
+cell's timed region is one launch per GPU closed by the one 64-byte statistics exchange (RCCL), the slowest rank's wall
+clock counts.  On one GPU the kernel time of the launch (HIP events) is reported instead.
 
 Which kernel serves a cell is reported: "regs" = one-row register-resident kernel (admm_kernel.hip.h), "tile" =
 W x R-row tile kernel (tile_kernel.hip.h), "cover" = coverage kernel (general_kernel.hip.h).
@@ -16,9 +23,63 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_amd as tm  # noqa: E402
+from tinympc_amd.distributed import shard_indices  # noqa: E402
+
+RANK = int(os.environ.get("RANK", "0"))
+LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
+WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+_dist = None
+
+
+def run_cell_sharded(nx, nu, N, B, reps):
+    """one cell on WORLD GPUs: total batch B, this rank's round-robin shard, wall clock of the slowest rank"""
+    import time
+    import torch
+    from tinympc_amd.distributed import StatsExchange
+    prob, rng = tm.random_problem(nx, nu, N)
+    idx = np.array(shard_indices(B, RANK, WORLD, interleaved=True))
+    s = tm.TinyBatchSolver.from_problem(prob, len(idx), device=LOCAL_RANK)
+    for kv in filter(None, os.environ.get("TINYMPC_OPTS", "").split(",")):
+        s.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    s.set_bound_constraints(np.full((nx, 1), -1e17), np.full((nx, 1), 1e17), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+    s.update_settings(max_iter=500)
+    x0 = rng.uniform(-1, 1, (B, nx))[idx]                       # the same draws as the unsharded cell, this rank's rows
+    xr = np.repeat(rng.uniform(-0.2, 0.2, (B, nx, 1))[idx], N, axis=2)
+    exchange = StatsExchange(s, _dist, LOCAL_RANK, total_batch=B)
+    one = torch.zeros(1, device=f"cuda:{LOCAL_RANK}")
+
+    def barrier():
+        s.synchronize()
+        _dist.all_reduce(one)
+        torch.cuda.synchronize()
+    best, st = None, None
+    for _ in range(reps + 1):
+        s.reset()
+        s.set_x0(x0)
+        s.set_x_ref(xr)
+        barrier()
+        t0 = time.perf_counter()
+        s.solve_async()
+        st = exchange().numpy()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{LOCAL_RANK}")
+        _dist.all_reduce(t, op=_dist.ReduceOp.MAX)
+        best = float(t.item()) if best is None else min(best, float(t.item()))
+    path = s.kernel_path()
+    alg = s.algorithmic_bytes()
+    exchange.close()
+    s.close()
+    fl = tm.flops_per_iter(nx, nu, N)
+    iters, solved = st[0], st[1]
+    return dict(nx=nx, nu=nu, N=N, batch=B, n_gpus=WORLD, kernel=path, ms=best * 1e3, solves_per_s=B / best, iters_per_s=iters / best,
+                iters_per_solve=iters / B, solved_fraction=solved / B, fp64_tflops=iters * fl / best / 1e12,
+                fp64_frac=iters * fl / best / 78.6e12 / WORLD, hbm_gbs=alg * B / best / 1e9, hbm_frac=alg * B / best / 8e12 / WORLD,
+                bytes_per_solve=alg, flops_per_iter=fl)
 
 
 def run_cell(nx, nu, N, B, reps):
+    if _dist is not None:
+        return run_cell_sharded(nx, nu, N, B, reps)
     prob, rng = tm.random_problem(nx, nu, N)
     s = tm.TinyBatchSolver.from_problem(prob, B)
     for kv in filter(None, os.environ.get("TINYMPC_OPTS", "").split(",")):       # experiments: prefer_tile=1 ...
@@ -56,18 +117,29 @@ def main():
     ap.add_argument("--cells", default="")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
+    global _dist
+    if WORLD > 1 or os.environ.get("TINYMPC_FORCE_DIST"):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(LOCAL_RANK)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", LOCAL_RANK))
+        _dist = dist
+    say = print if RANK == 0 else (lambda *a, **k: None)
     cells = ([tuple(int(v) for v in c.split(",")) for c in args.cells.split(";")] if args.cells else
              [(nx, nu, N) for nx in (4, 8, 12, 20) for nu in (2, 4, 8) for N in (10, 30, 50)])
     rows = []
-    print("| nx | nu | N | kernel | ms | solves/s | ADMM it/s | it/solve | solved | FP64 frac | HBM frac |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    say("| nx | nu | N | kernel | ms | solves/s | ADMM it/s | it/solve | solved | FP64 frac | HBM frac |")
+    say("|---|---|---|---|---|---|---|---|---|---|---|")
     for nx, nu, N in cells:
         r = run_cell(nx, nu, N, args.batch, args.reps)
         rows.append(r)
-        print(f"| {nx} | {nu} | {N} | {r['kernel']} | {r['ms']:.3f} | {r['solves_per_s']:.3e} | {r['iters_per_s']:.3e} | "
+        say(f"| {nx} | {nu} | {N} | {r['kernel']} | {r['ms']:.3f} | {r['solves_per_s']:.3e} | {r['iters_per_s']:.3e} | "
               f"{r['iters_per_solve']:.1f} | {r['solved_fraction']:.3f} | {r['fp64_frac']:.3f} | {r['hbm_frac']:.4f} |", flush=True)
-    if args.out:
+    if args.out and RANK == 0:
         json.dump(rows, open(args.out, "w"), indent=1)
+    if _dist is not None:
+        _dist.destroy_process_group()
 
 
 if __name__ == "__main__":
