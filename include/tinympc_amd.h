@@ -214,6 +214,8 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * "store_primal" (default 1; 0: launches do not write work->x|u back -- between closed-loop steps with "advance_x0" it has
  * no consumer, the plant step and solution->x|u = vnew|znew are still written; tiny_batch_get(TINY_F_X / TINY_F_U) then
  * returns stale data.  Ignored while a cone / half-space family is enabled, whose slack the next solve initialises from x|u).
+ * "share_ref" (default 1: when Xref and Uref were set with TINY_BROADCAST -- or never -- every instance reads ONE reference
+ * record instead of its own copy; 0 switches that off).
  * A solve that converges at its first termination check never stores v|z: the reference returns before v = vnew. */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */

@@ -273,6 +273,25 @@ def test_fused_closed_loop_steps(T):
     for k in fa:
         assert np.array_equal(ff[k], fa[k]), f"fused launch left a different {k}"
     assert sf[7] == sa[7] == 882.0 * B and sf[8] == sa[8] == 95.0 * B
+    # the byte-saving launch forms: no x|u write-back ("store_primal" = 0), per-instance reference records instead of the
+    # shared one ("share_ref" = 0) and the v|z store that first-check convergence skips -- everything a later solve or the
+    # caller can see (slack, duals, v|z, plant state, statistics) must stay bit-identical, one launch per step
+    for opts in (dict(store_primal=0), dict(share_ref=0), dict(store_primal=0, share_ref=0)):
+        c = make_batch(suite, batch=B)
+        c.set_option("advance_x0", 1)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_x_ref(xref, broadcast=True)
+        c.set_x0(x0, broadcast=True)
+        for _ in range(100):
+            c.solve_async()
+        for k in fa:
+            if k in ("x", "u") and not opts.get("store_primal", 1):
+                continue
+            assert np.array_equal(c.get(k), fa[k]), (opts, k)
+        sc_ = c.reduce_stats()
+        assert np.array_equal(sc_, sa), opts
+        c.close()
 
 
 @pytest.mark.parametrize("T", [97, 1])

@@ -138,6 +138,9 @@ struct SolveArgs {
     const double* atab;
     double arho_min, arho_max;
     int aclip;
+    // 1: every instance has the same Xref | Uref record (set with TINY_BROADCAST, or never set): all rows read instance 0's
+    // record -- one L2-resident line set instead of 8S bytes of HBM per instance
+    int ref_shared;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -462,7 +465,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
                 const bool warm = valid && !P.cold;
-                const double r = valid ? P.ref[off] : 0.0;
+                const double r = valid ? P.ref[P.ref_shared ? (off - (size_t)b * (N * NZ)) : off] : 0.0;
                 VN[s] = warm ? P.slack[off] : 0.0;
                 G[s] = warm ? P.dual[off] : 0.0;
                 VP[s] = warm ? P.slack_prev[off] : 0.0;

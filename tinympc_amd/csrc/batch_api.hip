@@ -407,7 +407,7 @@ static int launch_tile(TinyBatch* b) {
         HIP_TRY(b, hipMemcpyAsync(b->d_ttab, b->h_ttab.data(), b->h_ttab.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
     SolveArgs a;
-    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0;
+    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0;
     memset(&a, 0, sizeof(a));
     a.tab = b->d_ttab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack; a.dual = b->d_dual;
     a.slack_prev = b->d_slack_prev; a.status = b->d_status; a.resid = b->d_resid; a.accum = b->d_accum;
@@ -707,7 +707,7 @@ int launch_solve(TinyBatch* b) {
     if (int rc = upload_tables(b)) return rc;
     const bool soc = soc_active(b);
     SolveArgs a;
-    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0;
+    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0;
     a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
@@ -720,6 +720,7 @@ int launch_solve(TinyBatch* b) {
     a.traj = b->d_traj; a.traj_offsets = b->d_traj_offsets; a.traj_points = b->traj_points;
     a.traj_step0 = (int)b->traj_step; a.reset_duals = b->reset_duals ? 1 : 0;
     a.cold = b->one_shot ? 1 : 0;
+    a.ref_shared = (b->share_ref && b->xref_shared && b->uref_shared) ? 1 : 0;
     a.store_mask = b->one_shot == 2 ? 1 : (b->one_shot == 1 ? 3 : 31);
     // "store_primal" = 0: work->x|u is not written back.  A cone / half-space slack is initialised from it by the next
     // solve (admm.cpp:352-374) and the debug outputs belong to it, so those launches keep the store.
@@ -1194,6 +1195,8 @@ int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags) 
     }
     double* kpi; int rows, row_off, cols;
     if (field_geometry(b, field, &kpi, &rows, &row_off, &cols)) return fail(b, TINY_ERR_ARG, "bad field %d", (int)field);
+    if (field == TINY_F_XREF) b->xref_shared = bc;          // one reference for every instance: launches read one record
+    if (field == TINY_F_UREF) b->uref_shared = bc;
     const size_t n = (size_t)(bc ? 1 : b->batch) * rows * cols;
     const double* s = src;
     if (!dev) { HIP_TRY(b, hipMemcpyAsync(b->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream)); s = b->d_stage; }
@@ -1377,6 +1380,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
     else if (!strcmp(name, "store_primal")) b->store_primal = value != 0;
+    else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
     else if (!strcmp(name, "repack_after")) { if (value < 0) return fail(b, TINY_ERR_ARG, "repack_after: >= 0"); b->repack_after = (int)value; }
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);

@@ -78,6 +78,8 @@ struct TinyBatch {
     int repack_after = 0;
     int repack_waves_per_cu = 8, repack_growth = 2;   // grid of the follow-up stages; stage s runs to K * growth^s (measured best: 8, 2)
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
+    bool xref_shared = true, uref_shared = true;   // the Xref / Uref records of all instances are identical (broadcast, or still zero)
+    bool share_ref = true;                         // option "share_ref": let launches exploit that
     bool store_primal = true;            // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)
     int one_shot = 0;                    // 1: cold state assumed, x|u + vnew|znew written; 2: x|u only (bytes_cold of SURVEY.md 8(d))
     double* d_traj = nullptr;

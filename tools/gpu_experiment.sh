@@ -1,4 +1,14 @@
 #!/bin/bash
-# scratch stage of tools/gpu_stage.sh ("exp"): whatever is being debugged / measured at the moment
 O=$1; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_adaptive.py "tests/test_gpu_parity.py::test_hip_matches_reference_golden" -m gpu -q -x > $O/adaptive_pytest.txt 2>&1; tail -25 $O/adaptive_pytest.txt | cut -c1-300
+for g in 0 8 16; do
+  python bench.py --no-cpu-baseline --no-regimes --grid-waves-per-cu $g --min-seconds 0.3 > $O/bench_g$g.json 2>/dev/null
+  python bench.py --no-cpu-baseline --no-regimes --grid-waves-per-cu $g --min-seconds 0.3 --steps 20 --warmup 5 > $O/bench20_g$g.json 2>/dev/null
+  TINYMPC_OPTS=grid_waves_per_cu=$g python tools/config_bench.py $O/cfg_g$g.json config3,config4 > /dev/null 2>&1
+  python - <<PY
+import json
+a=json.load(open("$O/bench_g$g.json")); b=json.load(open("$O/bench20_g$g.json")); c=json.load(open("$O/cfg_g$g.json"))
+print("grid $g: fused100 %.4g solves/s (%.3f ms) | steps20 %.4g (%.3f ms) | config3 %.3f ms repack10 %.3f | config4 per-step %.4f s fused %.4f s" % (
+  a["value"], a["timed_region"]["ms"]["median"], b["value"], b["timed_region"]["ms"]["median"], c["config3"]["kernel_ms"], c["config3"]["repack"]["repack_after=10"]["kernel_ms"],
+  c["config4"]["steps_per_launch=1"]["seconds"], c["config4"]["steps_per_launch=90"]["seconds"]))
+PY
+done
