@@ -204,7 +204,9 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * tiny_batch_reset -- WITHOUT being read, and only the results are written: 1 = x|u and vnew|znew (solution->x|u),
  * 2 = x|u only, the bytes_cold = 8(nx+2S)+44 traffic of a solve that is not going to be warm-started; the other
  * warm-start records are left as they were.  Register-resident shapes only),
- * "repack_after" (K > 0: split solve for batches whose iteration counts diverge -- the launch stops at iteration K, the
+ * "repack_after" (-1, the default: automatic -- K is derived from the iteration histogram of the batch's previous solve by a
+ * cost model, 0 (a plain launch) when the counts are uniform enough that splitting would not pay 5 %; 0: never split;
+ * K > 0: split solve for batches whose iteration counts diverge -- the launch stops at iteration K, the
  * instances still open are listed by the kernel itself and carried on to 2K, 4K, ... max_iter by follow-up launches, four
  * open instances per wave at every stage, so that a slow instance no longer holds a wave by itself.  Results are
  * bit-identical to the unsplit solve; K is rounded down to a multiple of check_termination.  Worth it for cold solves
@@ -218,6 +220,9 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * record instead of its own copy; 0 switches that off).
  * A solve that converges at its first termination check never stores v|z: the reference returns before v = vnew. */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
+/* derived state: "auto_split_k" (the K the automatic split solve derived from the last iteration histogram; 0 = plain launch),
+ * "auto_split_permille" (its predicted time, in 1/1000 of the plain launch's), "repack_after" */
+long tiny_batch_get_option(TinyBatch* b, const char* name);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
 /* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state
  * vectors ([n_points][nx] doubles), shared by every instance.  While it is set, the state reference of a solve

@@ -132,3 +132,39 @@ def test_split_solve_keeps_heterogeneous_and_windowed_solves_intact():
     a, b = windowed({}), windowed({"repack_after": 6})
     for i in range(3):
         same(a[i], b[i], ("window", i))
+
+
+def test_automatic_split_picks_a_cap_for_divergent_batches_only():
+    """"repack_after" = -1 (the default): eligible solves of a batch are timed and leave an iteration histogram behind; a cost
+    model turns it into a cap K when the counts diverge (the config-3 recipe: mode 9, a tail to 100), the first split solve is
+    then held against the plain one's clock and kept only if it was faster.  Identical instances never split.  Results are
+    bit-identical whatever is decided."""
+    base = sc.tracking_random_suite(B=2048, seed=321)
+    rep = 128                                                 # 262 144 instances (BASELINE config 3): the follow-up stages fill the wave slots
+    cases = {k: np.concatenate([v] * rep, axis=0) for k, v in base["cases"].items()}
+    suite = dict(base, cases=cases)
+    ref = run_cases_hip(dict(base), options={"repack_after": 0})
+    s = make_batch(suite)
+    assert s.get_option("repack_after") == -1
+    for k in range(6):
+        s.reset()
+        s.set_x0(cases["x0"]); s.set_x_ref(cases["Xref"]); s.set_u_ref(cases["Uref"])
+        s.solve()
+        it = s.status()["iter"]
+        assert np.array_equal(it[:2048], ref["iter"].astype(int)) and np.array_equal(it[-2048:], ref["iter"].astype(int))
+        for f in ("x", "g", "v"):
+            assert np.array_equal(s.get(f)[:2048], ref[f]), (k, f)
+    K = s.get_option("auto_split_k")
+    assert 5 <= K <= 24, K                                    # the measured optimum on this distribution is K = 9 ... 16
+    assert s.get_option("auto_split_permille") < 950
+    assert s.get_option("auto_split_verdict") == 1 and 0 < s.get_option("auto_split_measured_permille") < 970
+    s.close()
+    # uniform batch: every instance identical -> no split proposed
+    one = {k: np.concatenate([v[:1]] * 65536, axis=0) for k, v in base["cases"].items()}
+    u = make_batch(dict(base, cases=one))
+    for _ in range(3):
+        u.reset()
+        u.set_x0(one["x0"]); u.set_x_ref(one["Xref"]); u.set_u_ref(one["Uref"])
+        u.solve()
+    assert u.get_option("auto_split_k") == 0 and u.get_option("auto_split_verdict") == 0
+    u.close()

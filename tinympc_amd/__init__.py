@@ -43,7 +43,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
     "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy",
-    "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
+    "tiny_batch_get_option", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -120,6 +120,8 @@ def lib():
         L.tiny_jit_compile.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
+        L.tiny_batch_get_option.argtypes = [C.c_void_p, C.c_char_p]
+        L.tiny_batch_get_option.restype = C.c_long
         L.tiny_batch_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
         L.tiny_batch_set_sensitivity.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.tiny_batch_set_cache_state.argtypes = [C.c_void_p, C.c_char_p, _dp]
@@ -445,6 +447,9 @@ class TinyBatchSolver:
         self._check(lib().tiny_batch_allreduce_stats(self._h, C.c_void_p(comm), int(n_ranks), int(rank), int(total_batch),
                                                      out.ctypes.data_as(_dp)), "allreduce_stats")
         return out
+
+    def get_option(self, name) -> int:
+        return int(lib().tiny_batch_get_option(self._h, name.encode()))
 
     def stats_message_async(self, device_out):
         """the batch's 64-byte statistics message (8 doubles) -> device memory, on the batch's stream behind the solve"""

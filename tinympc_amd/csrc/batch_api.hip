@@ -435,6 +435,7 @@ static int launch_tile(TinyBatch* b) {
     }
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
+
     if (jit_fn) {
         void* params[] = {&a};
         HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, b->stream, params, nullptr));
@@ -581,6 +582,7 @@ static int launch_general(TinyBatch* b, int phase = 0) {
     }
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
+
     hipLaunchKernelGGL(admm_general_kernel, dim3(grid), dim3(64), lds, b->stream, a);
     HIP_TRY(b, hipGetLastError());
     if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
@@ -602,6 +604,85 @@ static int upload_tables(TinyBatch* b) {
     // h_tab is pageable: the copy above is staged synchronously, so reusing h_tab later is safe
     b->tab_dirty = false;
     return TINY_OK;
+}
+
+// ---- automatic split solves ("repack_after" = -1): histogram of the iteration counts + a cost model ----------------------
+static __global__ __launch_bounds__(256) void iter_hist_kernel(const int4* __restrict__ status, int batch, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[TinyBatch::HIST_BINS];
+    for (int e = threadIdx.x; e < TinyBatch::HIST_BINS; e += blockDim.x) h[e] = 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < batch; i += gridDim.x * blockDim.x) {
+        int it = status[i].x;
+        it = it < 0 ? 0 : (it >= TinyBatch::HIST_BINS ? TinyBatch::HIST_BINS - 1 : it);
+        atomicAdd(&h[it], 1u);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TinyBatch::HIST_BINS; e += blockDim.x)
+        if (h[e]) atomicAdd(&hist[e], h[e]);
+}
+
+// Predicted launch time (arbitrary units: wave-iterations per wave slot) of a solve whose instances need hist[i] iterations,
+// four instances per wave in lock step (a wave runs to the slowest of its rows: E[max of 4] under independence), split at
+// `cap` (0 = plain) with the stage schedule of launch_solve (cap, 2 cap, 4 cap, ... max_iter).  A stage costs its work
+// spread over the wave slots, or -- when it has fewer waves than slots -- the depth of its longest wave at a lone wave's
+// pace (half the paired pace), plus a launch and one record reload / store per instance it carries.
+static double predicted_time(const unsigned* hist, int max_iter, int cap, int growth, double slots, double launch_iters, double reload_iters) {
+    const int M = std::min(max_iter, (int)TinyBatch::HIST_BINS - 1);
+    std::vector<double> cum(M + 2, 0.0);                     // cum[i] = instances with iter <= i
+    double n = 0.0;
+    for (int i = 0; i <= M; ++i) { n += hist[i]; cum[i] = n; }
+    if (n <= 0.0) return 0.0;
+    auto stage = [&](int lo, int hi, bool first) {           // iterations lo+1 .. hi for the instances with iter > lo
+        const double open = first ? n : n - cum[lo];
+        if (open <= 0.0) return 0.0;
+        double work = 0.0, second = 0.0;                     // E[d], E[d^2] of a wave's depth d: sum_j P(d > j), sum_j (2j+1) P(d > j)
+        int depth = 0;
+        for (int i = lo; i < hi; ++i) {
+            const double F = (cum[i] - (first ? 0.0 : cum[lo])) / open;          // P(iter <= i | open)
+            const double p = 1.0 - F * F * F * F;
+            work += p;
+            second += (2.0 * (i - lo) + 1.0) * p;
+            if (p > 1e-12) depth = i + 1 - lo;
+        }
+        const double waves = open / 4.0, per_slot = waves / slots;
+        // a follow-up stage walks its list with a fixed grid stride: a slot's time is the SUM of its waves' depths, the stage
+        // ends with the slowest slot (mean + 2.5 sigma of that sum); the first stage is balanced by the dispatcher
+        const double imbalance = first ? 0.0 : 2.5 * sqrt(std::max(per_slot, 1e-9) * std::max(second - work * work, 0.0));
+        const double t = std::max(work * per_slot + imbalance, 0.5 * depth);
+        return t + launch_iters + (first ? 0.0 : reload_iters * std::max(1.0, waves / slots));
+    };
+    if (cap <= 0 || cap >= M) return stage(0, M, true);
+    double t = stage(0, cap, true);
+    for (long base = cap; base < M; base *= growth) {
+        const int hi = (int)std::min<long>(M, base * growth);
+        t += stage((int)base, hi, false);
+        if (hi >= M) break;
+    }
+    return t;
+}
+
+// the K (multiple of check_termination) with the smallest predicted time, 0 when a plain launch is within 5 % of it
+static int choose_split(const TinyBatch* b, const unsigned* hist, double* ratio) {
+    const int M = b->set.max_iter, ct = std::max(1, b->set.check_termination), gr = std::max(2, b->repack_growth);
+    const int wps = solve_kernel_waves_per_simd(b->nx + b->nu, b->N, soc_active(b));
+    const double slots = (double)b->num_cus * 4.0 * wps;      // wave slots of the chip
+    // one wave-iteration (4 instances) in microseconds: its FLOPs at ~75 % of a SIMD's FP64 issue rate (76.8 GFLOP/s per SIMD),
+    // shared by the waves of the SIMD -- 1.7 us for the quadrotor at two waves (measured 1.64); the fixed costs of a
+    // stage in that unit: ~8 us of launch latency, and the record reload + store (2.45 us per wave for the quadrotor's 156 slots)
+    const double S = (double)b->nx * b->N + (double)b->nu * (b->N - 1);
+    const double fl = 4.0 * S + 2.0 * b->nx * b->nx + 3.0 * b->nx + (b->N - 1.0) * (4.0 * b->nx * b->nx + 8.0 * b->nx * b->nu + 2.0 * b->nu * b->nu + 4.0 * b->nu + 5.0 * b->nx) + 11.0 * S;
+    const double t_it = 4.0 * fl * wps / (76.8e3 * (wps == 2 ? 0.75 : 0.45));
+    const double launch_iters = 8.0 / t_it, reload_iters = 2.45 * (S / 156.0) / t_it;
+    const double plain = predicted_time(hist, M, 0, gr, slots, launch_iters, reload_iters);
+    double best = plain;
+    int best_k = 0;
+    for (int k = std::max(ct, 4 - 4 % ct); k <= M / 2; k += ct) {
+        if (k > 64 && k % 8) continue;                        // coarser steps far out
+        const double t = predicted_time(hist, M, k, gr, slots, launch_iters, reload_iters);
+        if (t < best) { best = t; best_k = k; }
+    }
+    if (ratio) *ratio = plain > 0.0 ? best / plain : 1.0;
+    return (plain > 0.0 && best < 0.95 * plain) ? best_k : 0;
 }
 
 // ---- adaptive rho: per-instance cache state + the lane tables of the adaptation step -----------------------------------
@@ -758,7 +839,7 @@ int launch_solve(TinyBatch* b) {
         jk.kmax = lin_kmax(b);
     }
     if (b->adaptive) {
-        if (b->hetero || jk.lin || b->one_shot || b->repack_after)
+        if (b->hetero || jk.lin || b->one_shot || b->repack_after > 0)
             return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho does not combine with heterogeneous data / half-spaces / one_shot / repack_after");
         if (int rc = ensure_adaptive(b)) return rc;
         a.arho = b->d_arho; a.aK = b->d_aK; a.aP = b->d_aP; a.aC1 = b->d_aC1; a.aC2 = b->d_aC2; a.atab = b->d_atab;
@@ -796,8 +877,40 @@ int launch_solve(TinyBatch* b) {
             return launch_solve(b);
         }
     }
+    // "repack_after" = -1 (the default): K comes from the iteration histogram of the previous eligible solve of this batch
+    // (collected asynchronously; a solve never waits for it) through the cost model above -- a batch whose iteration
+    // counts are uniform gets K = 0, i.e. the plain launch.
+    const bool split_ok = steps == 1 && !a.x0_next && !b->one_shot && !b->adaptive && a.check_termination > 0 && a.max_iter >= 16;
+    const bool auto_split = b->repack_after < 0 && split_ok && b->batch >= 8192;
+    if (auto_split && b->hist_pending && hipEventQuery(b->hist_ev) == hipSuccess) {
+        b->hist_pending = false;
+        // the clock's word on the previous eligible solve: microseconds per instance-iteration, plain or split
+        float ms = 0.0f;
+        double iters = 0.0;
+        for (int i = 0; i < TinyBatch::HIST_BINS; ++i) iters += (double)i * b->h_hist[i];
+        if (++b->auto_probes > 1 && iters > 0.0 && hipEventElapsedTime(&ms, b->auto_ev0, b->auto_ev1) == hipSuccess && ms > 0.0f) {
+            const double rate = (double)ms / iters;
+            if (b->auto_last_cap > 0) b->auto_split_rate = rate; else b->auto_plain_rate = rate;
+            if (b->auto_last_cap > 0 && b->auto_plain_rate > 0.0 && b->auto_verdict == 0)
+                b->auto_verdict = b->auto_split_rate < 0.97 * b->auto_plain_rate ? 1 : -1;
+        }
+        if (b->auto_verdict == 0) {                   // (a kept split keeps its K; a rejected one stays rejected until the options change)
+            b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
+            b->auto_cap_max_iter = a.max_iter;
+        }
+    }
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
+    if (auto_split && b->auto_verdict != 0 && ++b->auto_since >= 32) {      // distributions drift: ask the clock again now and then
+        b->auto_since = 0; b->auto_verdict = 0; b->auto_plain_rate = 0.0;
+    }
+    // this solve is timed and leaves its iteration histogram behind -- while the question is open; a decided batch launches
+    // without the two event records (each costs the next launch a dispatch bubble) and without the histogram pass
+    const bool auto_probe = auto_split && !b->hist_pending && b->auto_verdict == 0;
+    if (auto_probe) {
+        if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
+        HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
+    }
     auto launch = [&](const int g) -> int {
         if (jit_fn) {
             void* params[] = {&a};
@@ -813,9 +926,10 @@ int launch_solve(TinyBatch* b) {
     // ... max_iter (repack_growth = 2) -- four open instances per wave at every stage, and within a stage nearly all of them run the same number
     // of iterations.  K is a multiple of check_termination so that the termination countdown of every stage is in phase.
     // Two index lists alternate; every stage has its own counter, all of them zeroed by one memset.
-    int cap = b->repack_after;
+    int cap = b->repack_after > 0 ? b->repack_after
+            : ((auto_split && b->auto_cap_max_iter == a.max_iter && b->auto_verdict >= 0 && b->auto_plain_rate > 0.0) ? b->auto_cap : 0);
     if (a.check_termination > 1) cap -= cap % a.check_termination;
-    if (cap > 0 && cap < a.max_iter && steps == 1 && !a.x0_next && !b->one_shot) {
+    if (cap > 0 && cap < a.max_iter && split_ok) {
         enum { MAX_STAGES = 32 };
         if (!b->d_repack_index) {
             HIP_TRY(b, hipMalloc(&b->d_repack_index, 2 * (size_t)b->batch * sizeof(int)));
@@ -844,6 +958,20 @@ int launch_solve(TinyBatch* b) {
         HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream));
         b->timing_n++;
         b->timing_left--;
+    }
+    if (auto_probe) { HIP_TRY(b, hipEventRecord(b->auto_ev1, b->stream)); b->auto_last_cap = (cap > 0 && cap < b->set.max_iter && split_ok) ? cap : 0; }
+    if (auto_probe) {                                 // feed the next solve's decision: histogram of THIS solve's iteration counts
+        if (!b->d_hist) {
+            HIP_TRY(b, hipMalloc(&b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned)));
+            HIP_TRY(b, hipHostMalloc(reinterpret_cast<void**>(&b->h_hist), TinyBatch::HIST_BINS * sizeof(unsigned), hipHostMallocDefault));
+            HIP_TRY(b, hipEventCreateWithFlags(&b->hist_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(b, hipMemsetAsync(b->d_hist, 0, TinyBatch::HIST_BINS * sizeof(unsigned), b->stream));
+        hipLaunchKernelGGL(iter_hist_kernel, dim3(64), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_hist);
+        HIP_TRY(b, hipGetLastError());
+        HIP_TRY(b, hipMemcpyAsync(b->h_hist, b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(b, hipEventRecord(b->hist_ev, b->stream));
+        b->hist_pending = true;
     }
     if (b->d_traj) b->traj_step += steps;            // the window moves one knot per MPC step
     return TINY_OK;
@@ -1059,6 +1187,11 @@ int tiny_batch_destroy(TinyBatch* b) {
     for (void* p : bufs)
         if (p) hipFree(p);
     if (b->h_wire) hipHostFree(b->h_wire);
+    if (b->d_hist) hipFree(b->d_hist);
+    if (b->h_hist) hipHostFree(b->h_hist);
+    if (b->hist_ev) hipEventDestroy(b->hist_ev);
+    if (b->auto_ev0) hipEventDestroy(b->auto_ev0);
+    if (b->auto_ev1) hipEventDestroy(b->auto_ev1);
     for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
     for (hipEvent_t e : b->ev_stop) hipEventDestroy(e);
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
@@ -1382,7 +1515,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "store_primal")) b->store_primal = value != 0;
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
-    else if (!strcmp(name, "repack_after")) { if (value < 0) return fail(b, TINY_ERR_ARG, "repack_after: >= 0"); b->repack_after = (int)value; }
+    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_pending = false; b->auto_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);
     else if (!strcmp(name, "repack_growth")) b->repack_growth = (int)value;
     else if (!strcmp(name, "traj_step")) b->traj_step = value;
@@ -1460,6 +1593,25 @@ int tiny_jit_used(char* out, int out_len) {
     const int n = jit_used_names(&names);
     if (out && out_len > 0) snprintf(out, (size_t)out_len, "%s", names.c_str());
     return n;
+}
+
+// read-back of derived state: "auto_split_k" (the K the automatic split picked from the last histogram, 0 = plain launch),
+// "auto_split_permille" (its predicted time in 1/1000 of the plain launch's), "repack_after"
+long tiny_batch_get_option(TinyBatch* b, const char* name) {
+    if (!b || !name) return TINY_ERR_NULL;
+    if (!strcmp(name, "auto_split_k")) {
+        if (b->hist_pending && hipEventSynchronize(b->hist_ev) == hipSuccess) {      // (a diagnostic may wait; a solve never does)
+            b->hist_pending = false;
+            b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
+            b->auto_cap_max_iter = b->set.max_iter;
+        }
+        return b->auto_cap;
+    }
+    if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
+    if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
+    if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;
+    if (!strcmp(name, "repack_after")) return b->repack_after;
+    return fail(b, TINY_ERR_ARG, "unknown option %s", name);
 }
 
 int tiny_batch_kernel_path(TinyBatch* b) {

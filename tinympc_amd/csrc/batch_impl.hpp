@@ -75,7 +75,23 @@ struct TinyBatch {
     // repack_after = K > 0: a solve is split at iterations K, 2K, 4K, ... -- the instances that have not converged by then are
     // compacted and carried on by the next launch with four of them per wave again (divergent cold batches: a slow
     // instance no longer holds a wave by itself).  Results are bit-identical to the unsplit solve.
-    int repack_after = 0;
+    int repack_after = -1;               // K > 0: split at K; 0: never; -1 (default): K picked from the previous solve's iteration histogram
+    // automatic split: histogram of the per-instance iteration counts of the last eligible solve (device -> pinned host,
+    // asynchronous), and the K the cost model derived from it (0 = a plain launch is predicted to be as fast)
+    enum { HIST_BINS = 1024 };
+    unsigned *d_hist = nullptr, *h_hist = nullptr;
+    hipEvent_t hist_ev = nullptr;
+    bool hist_pending = false;
+    int auto_cap = 0, auto_cap_max_iter = 0;
+    // the model's proposal is then checked against the clock: time per instance-iteration of the last plain and the last split
+    // launch (HIP events around the launches of an eligible solve, read when the histogram arrives)
+    hipEvent_t auto_ev0 = nullptr, auto_ev1 = nullptr;
+    int auto_last_cap = 0;               // the cap the timed launch ran with
+    int auto_probes = 0;                 // timed solves so far (the first one carries one-time costs -- code object load -- and is not used)
+    double auto_plain_rate = 0.0, auto_split_rate = 0.0;
+    int auto_since = 0;                  // eligible solves since the last verdict: every 32nd one re-opens the question (plain + split timed again)
+    int auto_verdict = 0;                // 0 undecided, 1 the split was measured faster (kept), -1 measured slower (plain launches from now on)
+    double auto_gain = 0.0;              // predicted time of the split solve / plain solve (diagnostics)
     int repack_waves_per_cu = 8, repack_growth = 2;   // grid of the follow-up stages; stage s runs to K * growth^s (measured best: 8, 2)
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
     bool xref_shared = true, uref_shared = true;   // the Xref / Uref records of all instances are identical (broadcast, or still zero)

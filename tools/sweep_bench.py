@@ -101,13 +101,16 @@ def run_cell(nx, nu, N, B, reps):
     st = s.reduce_stats()
     iters, solved = st[0], st[1]
     alg = s.algorithmic_bytes()
+    auto_k, auto_pm = s.get_option("auto_split_k"), s.get_option("auto_split_permille")
+    hv, hc = np.unique(s.status()["iter"], return_counts=True)
     s.close()
     fl = tm.flops_per_iter(nx, nu, N)
     t = best * 1e-3
     return dict(nx=nx, nu=nu, N=N, batch=B, kernel=path,
                 ms=best, solves_per_s=B / t, iters_per_s=iters / t, iters_per_solve=iters / B, solved_fraction=solved / B,
                 fp64_tflops=iters * fl / t / 1e12, fp64_frac=iters * fl / t / 78.6e12,
-                hbm_gbs=alg * B / t / 1e9, hbm_frac=alg * B / t / 8e12, bytes_per_solve=alg, flops_per_iter=fl)
+                hbm_gbs=alg * B / t / 1e9, hbm_frac=alg * B / t / 8e12, bytes_per_solve=alg, flops_per_iter=fl,
+                auto_split_k=auto_k, auto_split_predicted=auto_pm / 1000.0, iter_histogram={int(v): int(c) for v, c in zip(hv, hc)})
 
 
 def main():
