@@ -150,6 +150,9 @@ int tiny_batch_get_cache_state(TinyBatch* b, const char* which, double* dst);
 /* Read back one cache matrix (TinyCache, types.hpp:43-59) by name: "Kinf" (nu x nx), "Pinf",
  * "Quu_inv", "AmBKt", "APf", "BPf", or "Q"/"R" (work->Q/R = user + rho).  Returns element count. */
 int tiny_batch_get_cache(TinyBatch* b, const char* name, double* out, int capacity);
+/* Overwrite one of them (same names and sizes, plus "rho": one double): a caller's own cache instead of the Riccati recursion of
+ * tiny_batch_setup -- what the code generated by tiny_codegen uses to restore a frozen TinyCache. */
+int tiny_batch_set_cache(TinyBatch* b, const char* name, const double* src);
 
 /* ---- per-instance data ------------------------------------------------------------------- */
 /* tiny_set_x0 / tiny_set_x_ref / tiny_set_u_ref and direct workspace pokes of the examples
@@ -435,6 +438,18 @@ int tiny_set_u_ref(TinySolver* solver, const TinyMatrixPOD* u_ref);
  * reference's quadrotor tables (tiny_api.cpp:479-540).  With settings->adaptive_rho = 1 tiny_solve then re-estimates rho
  * every 5th iteration (admm.cpp:397-423) and writes the moved cache (rho, Kinf, Pinf, C1, C2) back into the TinyCache. */
 void tiny_initialize_sensitivity_matrices(TinySolver* solver);
+/* codegen.hpp:9-18.  The reference freezes one TinySolver into Eigen-initialised C++ for microcontrollers; these freeze the
+ * solver's PROBLEM FAMILY (dimensions, settings, the cache as it stands, dynamics, costs, bounds, cones, half-spaces,
+ * references; with adaptive_rho on also the sensitivity tables) into a plain-C project for this library:
+ * <dir>/tinympc/tiny_data.h, <dir>/src/tiny_data.c (round-trip literals + tiny_generated_batch / tiny_generated_group, which
+ * rebuild the device-resident batch -- or the multi-GPU group -- of any size from the data), <dir>/src/tiny_main.c, <dir>/Makefile. */
+int tiny_codegen(TinySolver* solver, const char* output_dir, int verbose);
+int tiny_codegen_with_sensitivity(TinySolver* solver, const char* output_dir, TinyMatrixPOD* dK, TinyMatrixPOD* dP,
+                                  TinyMatrixPOD* dC1, TinyMatrixPOD* dC2, int verbose);
+int codegen_create_directories(const char* output_dir, int verbose);
+int codegen_data_header(const char* output_dir, int verbose);
+int codegen_data_source(TinySolver* solver, const char* output_dir, int verbose);
+int codegen_example(const char* output_dir, int verbose);
 /* admm.hpp:12-17: the individual phases of one ADMM iteration on a solver's workspace.  Each uploads the workspace,
  * runs the phase on the GPU (tiny_batch_phase with a batch of one) and writes the fields the reference function
  * writes back into the workspace. */

@@ -23,7 +23,7 @@ def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     phases = "update_linear_cost|backward_pass_grad|forward_pass|update_slack|update_dual|termination_condition|project_soc|project_hyperplane"
-    return sorted(set(re.findall(r"\b((?:tiny_\w+)|solve|" + phases + r")\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:tiny_\w+)|(?:codegen_\w+)|solve|" + phases + r")\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -43,7 +43,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
     "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy",
-    "tiny_batch_get_option", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
+    "tiny_batch_get_option", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -55,6 +55,8 @@ REFERENCE_SYMBOLS = (
     "tiny_set_tv_linear_constraints", "tiny_precompute_and_set_cache",
     "tiny_solve", "solve", "tiny_update_settings", "tiny_set_default_settings", "tiny_set_x0", "tiny_set_x_ref",
     "tiny_set_u_ref", "tiny_solve_batch", "tiny_destroy", "tiny_initialize_sensitivity_matrices",
+    "tiny_codegen", "tiny_codegen_with_sensitivity", "codegen_create_directories", "codegen_data_header", "codegen_data_source",
+    "codegen_example",
     # the phase functions of admm.hpp:12-34
     "update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual", "termination_condition",
     "project_soc", "project_hyperplane")
@@ -120,6 +122,7 @@ def lib():
         L.tiny_jit_compile.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
+        L.tiny_batch_set_cache.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.tiny_batch_get_option.argtypes = [C.c_void_p, C.c_char_p]
         L.tiny_batch_get_option.restype = C.c_long
         L.tiny_batch_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]

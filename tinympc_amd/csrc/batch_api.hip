@@ -1301,6 +1301,28 @@ int tiny_batch_get_cache(TinyBatch* b, const char* name, double* out, int capaci
     return (int)v->size();
 }
 
+// Overwrite one cache member of the family (names as tiny_batch_get_cache, plus "rho": one double): for callers that bring
+// their own cache instead of tiny_setup's Riccati recursion -- generated code (tiny_codegen) restores a frozen TinyCache with it.
+int tiny_batch_set_cache(TinyBatch* b, const char* name, const double* src) {
+    if (!b || !name || !src) return TINY_ERR_NULL;
+    std::vector<double>* v = nullptr;
+    if (!strcmp(name, "rho")) { b->cache.rho = src[0]; }
+    else if (!strcmp(name, "Kinf")) v = &b->cache.Kinf.a;
+    else if (!strcmp(name, "Pinf")) v = &b->cache.Pinf.a;
+    else if (!strcmp(name, "Quu_inv")) v = &b->cache.Quu_inv.a;
+    else if (!strcmp(name, "AmBKt")) v = &b->cache.AmBKt.a;
+    else if (!strcmp(name, "APf")) v = &b->cache.APf.a;
+    else if (!strcmp(name, "BPf")) v = &b->cache.BPf.a;
+    else if (!strcmp(name, "Q")) v = &b->Qw;
+    else if (!strcmp(name, "R")) v = &b->Rw;
+    else return fail(b, TINY_ERR_ARG, "unknown cache member %s", name);
+    if (v) memcpy(v->data(), src, v->size() * sizeof(double));
+    b->tab_dirty = true;
+    if (b->hetero) return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous batches keep per-instance caches (tiny_batch_setup_hetero)");
+    if (b->d_arho) { HIP_TRY(b, hipSetDevice(b->device)); if (int rc = adaptive_fresh_state(b)) return rc; }   // adaptive state restarts from it
+    return TINY_OK;
+}
+
 int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags) {
     if (!b || !src) return TINY_ERR_NULL;
     HIP_TRY(b, hipSetDevice(b->device));

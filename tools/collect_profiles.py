@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""gpurun_out/final (tools/gpu_final.sh) -> profiles/<tag>_* and profiles/traffic.json.
-    python tools/collect_profiles.py [tag = r01_final]"""
+"""gpurun_out/<stage>/ (tools/gpu_stage.sh) -> profiles/<tag>_* and profiles/traffic.json.
+    python tools/collect_profiles.py [tag = r02]
+
+Stages read: tests (pytest + smoke), bench (driver flags / default / per-step / torchrun-1), prof (rocprofv3 kernel stats
+and the FETCH_SIZE / WRITE_SIZE PMC passes of the driver-flags, default and per-step commands), configs, sweep."""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final")
+OUT = os.path.join(ROOT, "gpurun_out")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
-def find(pattern):
-    hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
+def find(stage, pattern):
+    hits = glob.glob(os.path.join(OUT, stage, pattern), recursive=True)
     return hits[0] if hits else None
 
 
 def pmc_per_launch(dirname, counter, kernel="admm_solve_kernel"):
-    f = find(f"{dirname}/**/*counter_collection.csv")
+    f = find("prof", f"{dirname}/**/*counter_collection.csv")
     if not f:
         return None, 0
     tot, launches = 0.0, set()
@@ -25,31 +28,40 @@ def pmc_per_launch(dirname, counter, kernel="admm_solve_kernel"):
     return (tot / max(len(launches), 1)), len(launches)
 
 
-for name in ("pytest_gpu.txt", "smoke.txt", "bench_default.json", "bench_per_step.json", "bench_regimes.json", "bench_torchrun1.json",
-             "configs_3_4.json", "phase_clocks.txt", "sweep_config5.json", "sweep_config5.md", "sweep_config5_split_solve.json",
-             "sweep_config5_split_solve.md"):
-    if os.path.exists(os.path.join(SRC, name)):
-        shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{TAG}_{name}"))
-for mode in ("fused", "step"):
-    f = find(f"prof_{mode}_trace/**/*kernel_stats.csv")
+copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", "smoke.txt"),
+          ("bench", "bench_driver_flags.json", "bench_driver_flags.json"), ("bench", "bench_default.json", "bench_default.json"),
+          ("bench", "bench_per_step.json", "bench_per_step.json"), ("bench", "bench_torchrun1.json", "bench_torchrun1.json"),
+          ("configs", "configs_3_4.json", "configs_3_4.json"), ("sweep", "sweep_config5.json", "sweep_config5.json"),
+          ("sweep", "sweep_config5.md", "sweep_config5.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt")]
+for stage, name, dst in copies:
+    src = os.path.join(OUT, stage, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(DST, f"{TAG}_{dst}"))
+for mode in ("driver", "default", "step"):
+    f = find("prof", f"prof_{mode}_trace/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{TAG}_{mode}_kernel_stats.csv"))
+    b = os.path.join(OUT, "prof", f"rocprof_{mode}_bench.json")
+    if os.path.exists(b) and os.path.getsize(b):
+        shutil.copy(b, os.path.join(DST, f"{TAG}_{mode}_bench_under_rocprof.json"))
 traffic = {}
-for mode, key, steps in (("step", "per_step_launch", 1), ("fused", "fused_100_steps_launch", 100)):
+for mode, key, what in (("step", "per_step_launch", "one launch per MPC step, the 100-step episode from cold"),
+                        ("default", "fused_launch", "100 MPC steps fused per launch"),
+                        ("driver", "fused_launch_5_steps", "5 MPC steps fused per launch (--steps 20 --warmup 5)")):
     fetch, n1 = pmc_per_launch(f"prof_{mode}_fetch", "FETCH_SIZE")
     write, n2 = pmc_per_launch(f"prof_{mode}_write", "WRITE_SIZE")
     if fetch is None or write is None:
         continue
-    alg = 10124 * 65536 * steps
+    alg = 10124 * 65536
     hbm = fetch * 1024 * 2 + write * 1024
     traffic[key] = {
-        "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around bench.py ({mode} mode), tools/gpu_final.sh",
+        "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around bench.py ({what}), tools/gpu_stage.sh prof",
         "launches": n1, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio_traffic_over_algorithmic": hbm / alg,
-        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of a coalesced stream)"
-                + ("; the ADMM state stays in registers between the fused MPC steps: real traffic = one load + one store of the records" if steps > 1 else "")}
+        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of a coalesced stream); algorithmic = "
+                "bytes_warm = 10124 B per instance and LAUNCH: a launch loads and stores the records once however many MPC steps it "
+                "fuses.  Below 1.0: the hover references are one shared record (share_ref) and a solve that converges at its first "
+                "check does not store v|z again"}
 if traffic:
-    old = json.load(open(os.path.join(DST, "traffic.json"))) if os.path.exists(os.path.join(DST, "traffic.json")) else {}
-    old.update(traffic)
-    json.dump(old, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print("collected into", DST, "traffic keys:", list(traffic))
