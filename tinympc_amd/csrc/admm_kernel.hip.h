@@ -332,6 +332,33 @@ __device__ __forceinline__ double soc_component(double s0, double s1, double s2,
     return r;
 }
 
+// The same projection for a whole 3-cone held by ONE lane (s0, s1, s2) -> (r0, r1, r2): the transposed form of the cone step
+// (one lane per (cone, knot) pair) pays the square root and the two divisions once per iteration instead of once per knot.
+__device__ __forceinline__ void soc_project3(double s0, double s1, double s2, float mu, double& r0, double& r1, double& r2) {
+#pragma clang fp contract(off)
+    const double u0 = s2 * (double)mu;                                  // :40
+    const double q0 = s0 * s0, q1 = s1 * s1;
+    const double q = q0 + q1;
+    r0 = s0; r1 = s1; r2 = s2;
+    const bool sure_inside = (u0 > 1e-30) && (q <= (u0 * u0) * (1.0 - 0x1p-20)) && (q < 1e70);     // see soc_component
+    if (__builtin_amdgcn_ballot_w64(!sure_inside) == 0ull) return;
+    const float a = (float)sqrt(q);                                     // :42
+    const double ad = (double)a;
+    const bool below = ad <= -u0, inside = ad <= u0;                    // :46 | :49
+    const bool outside = !below && !inside && (ad >= fabs(u0));         // :52 (else :58 -> 0)
+    const bool zero = below || !inside;
+    r0 = zero ? 0.0 : s0; r1 = zero ? 0.0 : s1; r2 = zero ? 0.0 : s2;
+    if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {
+        const double scale = 0.5 * (1.0 + u0 / ad);                     // :55
+        const double last = (double)(a / mu);                           // :54
+        r0 = outside ? scale * s0 : r0;
+        r1 = outside ? scale * s1 : r1;
+        r2 = outside ? scale * last : r2;
+    }
+}
+// passes of 16 (cone, knot) items a row needs when every lane triple of the state / input rows carries a cone
+constexpr int soc_item_passes(int nx, int nu, int n) { return ((nx / 3) * n + (nu / 3) * (n - 1) + 15) / 16; }
+
 // a + d * b with the product rounded before the sum, as the reference's x86-64 build (no FMA contraction) evaluates
 // `Kinf + delta_rho * dKinf_drho` (rho_benchmark.cpp:201-204)
 __device__ __forceinline__ double taylor_step(double a, double d, double b) {
@@ -373,6 +400,9 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sHi[N * 16];
     __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
     __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
+#ifndef TINYMPC_SOC_PER_KNOT
+    __shared__ double sT[SOC ? 4 * N * 16 : 1];               // SOC: x + gc of every slot, transposed through LDS for the cone step
+#endif
     __shared__ double sP[ADAPT ? 4 * NX * NX : 1];            // ADAPT: each row's own Pinf, column-major (lane j keeps column j current)
     if constexpr (LS) for (int e = lane; e < 3 * KMAX * 16; e += 64) sLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + e];
     if constexpr (LT) for (int e = lane; e < 3 * N * KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * KMAX * 16 + e];
@@ -406,6 +436,31 @@ void admm_solve_kernel(const SolveArgs P) {
         cone_c = (cone_base >= 0) ? (j - cone_base) : 0;
         proj_lane = soc_lane && cone_base >= 0;
     }
+#ifndef TINYMPC_SOC_PER_KNOT
+    // Transposed cone step: the (cone, knot) pairs of a row are dealt out to its lanes, 16 per pass -- lane j of pass p takes
+    // item 16 p + j, counted cone by cone (ascending base lane): a state cone has N items (slots 0..N-1), an input cone N-1
+    // (slots 1..N-1).  All four rows of a wave share the layout.
+    constexpr int SOC_PASSES = SOC ? (soc_item_passes(NX, NU, N) > 0 ? soc_item_passes(NX, NU, N) : 1) : 1;
+    int item_at[SOC_PASSES];                                   // LDS offset (slot * 16 + base lane) of the item's first component, -1: none
+    float item_mu[SOC_PASSES];
+    if constexpr (SOC) {
+        const unsigned heads = (unsigned)(__builtin_amdgcn_ballot_w64(proj_lane && cone_c == 0) & 0xFFFFull);   // row 0 speaks for all
+#pragma unroll
+        for (int p = 0; p < SOC_PASSES; ++p) {
+            int t = p * 16 + j;
+            item_at[p] = -1; item_mu[p] = 1.0f;
+            for (unsigned m = heads; m; m &= m - 1) {
+                const int hb = __builtin_ctz(m);
+                const int cnt = hb < NX ? N : N - 1;
+                if (t >= 0 && t < cnt) {
+                    item_at[p] = (t + (hb < NX ? 0 : 1)) * 16 + hb;
+                    item_mu[p] = (float)P.tab[TAB_VEC + VEC_CONE_MU * 16 + hb];
+                    t = -1;
+                } else if (t >= 0) t -= cnt;
+            }
+        }
+    }
+#endif
     bool lin_lane = false, tlin_lane = false;
     if constexpr (LS) lin_lane = P.tab[TAB_VEC + VEC_LINFLAG * 16 + j] != 0.0;
     if constexpr (LT) tlin_lane = P.tab[TAB_VEC + VEC_TLINFLAG * 16 + j] != 0.0;
@@ -598,6 +653,9 @@ void admm_solve_kernel(const SolveArgs P) {
                             // vcnew = x + gc on every row of a family whose cone slack is on (:102-109); GC is 0 on the
                             // other rows, so one FMA against the 0/1 mask does the add and the select
                             const double tc = fma(xi, socmask, GC[s]);
+#ifndef TINYMPC_SOC_PER_KNOT
+                            sT[(grp * N + s) * 16 + j] = tc;       // projected after the sweep, one lane per (cone, knot): cone_step()
+#else
                             const int base = (cone_base >= 0) ? cone_base : j;
                             const double s0 = __shfl(tc, base, 16);
                             const double s1 = __shfl(tc, base + 1, 16);
@@ -606,6 +664,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             if (proj_lane && (is_state || s >= 1)) vc = soc_component(s0, s1, s2, tc, cone_c, cone_mu);   // :112-135
                             GC[s] = tc - vc;                                        // :229 / :234  (gc + x) - vcnew
                             VC[s] = vc;
+#endif
                         }
                         // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over
                         // the row with the broadcast-FMA chain (against a vector of ones), separately for the state
@@ -653,6 +712,34 @@ void admm_solve_kernel(const SolveArgs P) {
                         lo_c = lo_n; hi_c = hi_n;
                     }
                     slot_update(N - 1, lo_c, hi_c);
+#ifndef TINYMPC_SOC_PER_KNOT
+                    if constexpr (SOC) {
+                        // ---- cone step (admm.cpp:112-135, 228-235), transposed: x + gc of every slot went to LDS above; lane j
+                        // of pass p gathers the three components of its (cone, knot) item, projects them -- ONE square root /
+                        // division sequence per pass instead of one per knot -- and puts the result back in place
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int p = 0; p < SOC_PASSES; ++p) {
+                            const bool has = item_at[p] >= 0;
+                            const int at = grp * N * 16 + (has ? item_at[p] : 0);
+                            const double s0 = has ? sT[at] : 0.0, s1 = has ? sT[at + 1] : 0.0, s2 = has ? sT[at + 2] : 1.0;
+                            double r0, r1, r2;
+                            soc_project3(s0, s1, s2, item_mu[p], r0, r1, r2);
+                            if (has) { sT[at] = r0; sT[at + 1] = r1; sT[at + 2] = r2; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int s = 0; s < N; ++s) {
+                            const double tc = fma(X[s], socmask, GC[s]);
+                            const double pv = sT[(grp * N + s) * 16 + j];
+                            const double vc = (proj_lane && (is_state || s >= 1)) ? pv : tc;
+                            GC[s] = tc - vc;                                        // :229 / :234  (gc + x) - vcnew
+                            VC[s] = vc;
+                        }
+                    }
+#endif
                     iter += 1;                                                      // :394
                     if constexpr (ADAPT) {
                         // ---- adaptive rho, admm.cpp:397-423: every 5th pass of the loop index (after iterations 6, 11, ...).
