@@ -1,8 +1,11 @@
 #!/bin/bash
 O=$1; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_variants.py tests/test_gpu_repack.py tests/test_gpu_jit.py tests/test_codegen.py -m gpu -q -x > $O/pytest.txt 2>&1; tail -6 $O/pytest.txt | cut -c1-300
-timeout 600 python tools/config_bench.py $O/cfg.json config4 > /dev/null 2>&1
-python -c "
-import json; c=json.load(open('$O/cfg.json'))['config4']
-print({k:(round(v['seconds'],4), '%.3e'%v['admm_iters_per_s'], '%.3e'%v['solves_per_s']) for k,v in c.items() if k.startswith('steps')})"
-timeout 300 python tools/soc_iter_cost.py 2>&1 | tail -12
+R=$PWD
+for lib in libtinympc_amd.so libtinympc_amd_w1.so; do
+  for rep in 1 2; do
+  TINYMPC_AMD_LIB=$R/tinympc_amd/$lib python bench.py --no-cpu-baseline --min-seconds 0.5 > $O/b_$lib.json 2>/dev/null
+  python -c "
+import json; d=json.load(open('$O/b_$lib.json'))
+print('$lib', 'fused100 %.4g solves/s  fp64 %.4f | cold step %.4f ms fp64 %.4f | steady %.4f ms' % (d['value'], d['roofline_fp64']['frac'], d['regimes']['cold']['ms_per_launch'], d['regimes']['cold']['fp64_frac'], d['regimes']['steady_state']['ms_per_launch']))"
+  done
+done
