@@ -381,7 +381,9 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
 // LIN: bit 0 = static half-spaces (admm.cpp:137-173), bit 1 = time-varying ones (:176-211); 0 = neither
 // HET: per-instance problem data (riccati_kernel.hip.h): the matrix rows are re-loaded for every instance
 // ADAPT: adaptive rho (admm.cpp:397-423): per-instance rho / Kinf / Pinf, re-estimated every 5th iteration
-template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false>
+// UB: the box is the same at every knot (the usual case: constant state / input limits): the two bounds of a lane live in
+// registers instead of being read from LDS slot by slot -- 18 LDS reads and as many waits less per iteration at N = 10
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((LIN || ADAPT) ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC), (LIN || ADAPT) ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC))))
 void admm_solve_kernel(const SolveArgs P) {
@@ -471,6 +473,8 @@ void admm_solve_kernel(const SolveArgs P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
 
+    // UB: slot 1 speaks for every slot (slot 0 of an input lane is the neutral dummy: its box stays (-inf, +inf))
+    const double lo_u = sLo[16 + j], hi_u = sHi[16 + j], lo_u0 = sLo[j], hi_u0 = sHi[j];
     const int ninst = P.index ? *P.count : P.batch;
     const int ntiles = (ninst + 3) >> 2;
     const bool resumed = P.index != nullptr;
@@ -702,9 +706,10 @@ void admm_solve_kernel(const SolveArgs P) {
                     // they are used (sched_barrier pins the reads above the step), and slot i's update is
                     // scheduled together with the FMA chain of step i -- both only need x_i.
                     double lo_c = sLo[j], hi_c = sHi[j];
+                    if constexpr (UB) { lo_c = lo_u0; hi_c = hi_u0; }
 #pragma unroll
                     for (int i = 0; i < N - 1; ++i) {
-                        const double lo_n = sLo[(i + 1) * 16 + j], hi_n = sHi[(i + 1) * 16 + j];
+                        const double lo_n = UB ? lo_u : sLo[(i + 1) * 16 + j], hi_n = UB ? hi_u : sHi[(i + 1) * 16 + j];
                         __builtin_amdgcn_sched_barrier(0);
                         const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
                         X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)

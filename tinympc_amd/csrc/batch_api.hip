@@ -254,6 +254,12 @@ static void build_tables(TinyBatch* b) {
                 lo[(i + 1) * 16 + nx + a] = b->u_min[(size_t)i * nu + a];
                 hi[(i + 1) * 16 + nx + a] = b->u_max[(size_t)i * nu + a];
             }
+    // knot-invariant box? (slot 0 of the input lanes is the dummy slot and keeps (-inf, +inf): slots 1.. must agree; state lanes: 0..)
+    bool uniform = N >= 2;
+    for (int j = 0; j < nx + nu && uniform; ++j)
+        for (int i = (j < nx ? 0 : 1); i < N && uniform; ++i)
+            uniform = lo[i * 16 + j] == lo[16 + j] && hi[i * 16 + j] == hi[16 + j];
+    b->bounds_uniform = uniform;
 }
 
 // Tables of the tile kernel (tile_kernel.hip.h): matrices [column k][LW = 16 W lanes], vectors [LW], bounds [N][LW]
@@ -851,6 +857,7 @@ int launch_solve(TinyBatch* b) {
     SolveKernel k = nullptr;
     if (b->kernel) {
         if (jk.adapt) k = jk.soc ? nullptr : b->kernel->kadapt[jk.dbg];
+        else if (!jk.lin && !jk.het && !jk.soc && !jk.dbg && jk.mode == 2 && b->bounds_uniform && b->use_ub) k = b->kernel->kub;
         else if (!jk.lin && !jk.het) k = b->kernel->k[jk.soc][jk.dbg][jk.mode];
         else if (jk.lin && !jk.het && !jk.dbg && jk.kmax == LIN_KMAX) k = b->kernel->klin[jk.soc][jk.lin];
         else if (jk.het && !jk.lin && !jk.dbg) k = b->kernel->khet[jk.soc];
@@ -1536,6 +1543,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
     else if (!strcmp(name, "store_primal")) b->store_primal = value != 0;
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
+    else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
     else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_pending = false; b->auto_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);

@@ -94,6 +94,8 @@ struct TinyBatch {
     double auto_gain = 0.0;              // predicted time of the split solve / plain solve (diagnostics)
     int repack_waves_per_cu = 8, repack_growth = 2;   // grid of the follow-up stages; stage s runs to K * growth^s (measured best: 8, 2)
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
+    bool use_ub = true;                            // option "uniform_bounds": take the UB kernel variant when the box allows it
+    bool bounds_uniform = false;                   // build_tables: every knot has the same box (admm_kernel.hip.h UB variant)
     bool xref_shared = true, uref_shared = true;   // the Xref / Uref records of all instances are identical (broadcast, or still zero)
     bool share_ref = true;                         // option "share_ref": let launches exploit that
     bool store_primal = true;            // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)

@@ -10,6 +10,7 @@ struct KernelEntry {
     SolveKernel klin[2][4];   // [soc][LIN 1..3]: register-resident linear constraints (dpp_mode 2, no debug outputs)
     SolveKernel khet[2];      // [soc]: per-instance problem data (dpp_mode 2, no debug outputs)
     SolveKernel kadapt[2];    // [dbg]: adaptive rho (dpp_mode 2, no cone)
+    SolveKernel kub;          // knot-invariant box in registers (plain variant, dpp_mode 2)
 };
 struct TileEntry {
     int nx, nu, N, W, R;
@@ -30,4 +31,5 @@ struct TileEntry {
       { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, true>,                               \
         tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, true> },                              \
       { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, true>, \
-        tinympc_amd::admm_solve_kernel<NX, NU, NN, false, true, 2, 0, false, tinympc_amd::LIN_KMAX, true> } }
+        tinympc_amd::admm_solve_kernel<NX, NU, NN, false, true, 2, 0, false, tinympc_amd::LIN_KMAX, true> },  \
+      tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true> }
