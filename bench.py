@@ -296,7 +296,8 @@ def main():
                                    "closed-loop MPC steps from a cold start (BASELINE configs[1])",
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}",
                        "grid_waves_per_cu": args.grid_waves_per_cu, "dpp_mode": args.dpp_mode,
-                       "mpc_steps_per_launch": T},
+                       "mpc_steps_per_launch": T,
+                       "stats_exchange": (exchange.kind if exchange is not None else "none (one rank)")},
             "timed_region": {"repeats": int(repeats), "seconds_total": float(rep_s.sum()),
                              "ms": {"median": elapsed * 1e3, "min": float(rep_s.min()) * 1e3, "max": float(rep_s.max()) * 1e3},
                              "value_min": solves / float(rep_s.max()), "value_max": solves / float(rep_s.min()),

@@ -26,6 +26,16 @@ def test_fuzz_hip_vs_oracle(first):
     assert not bad, bad[:5]
 
 
+def test_fuzz_adaptive_rho_vs_oracle():
+    """tools/fuzz_parity.py adaptive: random shapes of the one-row kernel (compiled-in and run-time instantiated ADAPT variants,
+    with and without cones), random sensitivity tables / clip ranges / per-instance cache state."""
+    import fuzz_parity
+    from cpu_solvers import build_oracle
+    assert build_oracle()
+    bad = [r for r in (fuzz_parity.adaptive_trial(seed) for seed in range(1, 91)) if r]
+    assert not bad, bad[:5]
+
+
 def test_input_field_larger_than_state_field():
     """(4, 8, 10): nu*(N-1) = 72 > nx*N = 40 -- every host-layout field must fit the staging buffer."""
     import scenarios as sc

@@ -94,12 +94,38 @@ class StatsExchange:
         import tinympc_amd as tm
         self.s, self.total = solver, int(total_batch)
         self.world, self.rank = _world_rank(dist, group)
-        box = [tm.rccl_unique_id() if self.rank == 0 else None]
+        self.dist, self.group, self.comm, self.kind = dist, group, None, "native"
+        try:
+            box = [tm.rccl_unique_id() if self.rank == 0 else None]
+        except Exception as e:                       # noqa: BLE001  (rank 0 could not even draw an id: every rank must learn it)
+            box = [repr(e)]
         dist.broadcast_object_list(box, src=0, group=group)
-        self.comm = tm.rccl_comm_init_rank(self.world, box[0], self.rank, device_index)
+        ok = isinstance(box[0], (bytes, bytearray))
+        if ok:
+            try:
+                self.comm = tm.rccl_comm_init_rank(self.world, bytes(box[0]), self.rank, device_index)
+            except Exception:                        # noqa: BLE001
+                ok = False
+        # all ranks or none: a rank that could not join must not leave the others waiting inside the collective
+        import torch
+        flag = torch.tensor([1.0 if ok else 0.0], device=f"cuda:{device_index}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag.item()) < 1.0:
+            # Still RCCL, through torch.distributed: the same 64-byte messages as a one-hot all-reduce (allreduce_stats)
+            if self.comm:
+                tm.rccl_comm_destroy(self.comm)
+            self.comm, self.kind = None, "torch.distributed"
+            self._stats = torch.zeros(10, dtype=torch.float64, device=f"cuda:{device_index}")
+            import sys
+            print("tinympc_amd: native RCCL communicator unavailable, statistics exchange through torch.distributed", file=sys.stderr)
 
     def __call__(self):
         import torch
+        if self.comm is None:
+            self.s.reduce_stats_async(self._stats.data_ptr())
+            torch.cuda.current_stream().synchronize()          # (the solver's stream is the current one in bench.py; harmless otherwise)
+            self.s.synchronize()
+            return allreduce_stats(self._stats, self.dist, self.group, total_batch=self.total)
         return torch.from_numpy(self.s.allreduce_stats(self.comm, self.world, self.rank, self.total))
 
     def close(self):

@@ -81,6 +81,64 @@ def trial(seed):
     return None
 
 
+ADAPT_SHAPES = [(4, 1, 10), (12, 4, 10), (6, 3, 10), (2, 2, 3), (8, 8, 10), (4, 8, 10), (12, 2, 10), (5, 3, 7), (9, 2, 12), (3, 1, 4), (7, 7, 5)]
+
+
+def adaptive_trial(seed):
+    """Adaptive rho (admm.cpp:397-423, rho_benchmark.cpp) on random shapes of the one-row kernel: random sensitivity tables,
+    clip range and per-instance cache state, optional cones; identical iteration counts, fields and the moved cache to 1e-7
+    (the re-estimated rho feeds back through a square root of a ratio of maxima: last-bit differences of the FMA-contracted
+    sweeps are amplified over the adaptations of a solve)."""
+    rng = np.random.default_rng(seed + 555_000)
+    nx, nu, N = ADAPT_SHAPES[rng.integers(len(ADAPT_SHAPES))]
+    M = rng.standard_normal((nx, nx))
+    A = M * rng.uniform(0.5, 1.0) / np.max(np.abs(np.linalg.eigvals(M)))
+    prob = dict(nx=nx, nu=nu, N=N, rho=float(rng.choice([1.0, 5.0, 17.3])), A=A, B=rng.standard_normal((nx, nu)) / np.sqrt(nx),
+                f=rng.normal(0, 0.05, nx) * rng.integers(0, 2), Q=rng.uniform(0.5, 10, nx), R=rng.uniform(0.1, 2, nu))
+    kw = dict(max_iter=int(rng.integers(0, 60)), check_termination=int(rng.integers(0, 4)), abs_pri_tol=float(10 ** rng.uniform(-4, -1)),
+              abs_dua_tol=float(10 ** rng.uniform(-4, -1)), en_state_bound=int(rng.integers(0, 2)), en_input_bound=int(rng.integers(0, 2)),
+              x_min=rng.uniform(-2.0, -0.1, (nx, N)), x_max=rng.uniform(0.1, 2.0, (nx, N)),
+              u_min=rng.uniform(-1.0, -0.05, (nu, N - 1)), u_max=rng.uniform(0.05, 1.0, (nu, N - 1)))
+    if nx >= 3 and nu >= 3 and rng.random() < 0.3:
+        kw.update(en_state_soc=int(rng.integers(0, 2)), en_input_soc=int(rng.integers(0, 2)),
+                  state_cone=([int(rng.integers(0, nx - 2))], [3], [float(rng.uniform(0.2, 1.5))]),
+                  input_cone=([int(rng.integers(0, nu - 2))], [3], [float(rng.uniform(0.2, 1.5))]))
+    sens = {"dKinf_drho": rng.normal(0, 2e-3, (nu, nx)), "dPinf_drho": rng.normal(0, 5e-2, (nx, nx)),
+            "dC1_drho": rng.normal(0, 1e-3, (nu, nu)), "dC2_drho": rng.normal(0, 1e-3, (nx, nx))}
+    lo = float(rng.uniform(0.3, 2.0))
+    cfg = sc.adaptive_cfg(sc.default_config(prob, **kw), rho_min=lo, rho_max=lo * float(rng.uniform(2, 50)), clip=int(rng.random() < 0.8), sensitivity=sens)
+    B = int(rng.integers(1, 9))
+    cases = sc.zero_cases(prob, B)
+    warm = rng.random() < 0.5
+    for k, v in cases.items():
+        if k in ("x0", "Xref", "Uref") or warm:
+            cases[k] = rng.normal(0.0, 0.4, v.shape)
+    suite = dict(problem=prob, config=cfg, cases=cases)
+    if rng.random() < 0.5:                               # every instance starts from its own rho (and slightly moved Kinf / Pinf)
+        o = sc.make_solver(OracleSolver, prob, cfg)
+        cases["cache_rho"] = prob["rho"] * rng.uniform(0.5, 2.0, B)
+        for k in sc.CACHE_STATE:
+            cases["cache_" + k] = o[k][None] * (1.0 + rng.normal(0, 1e-3, (B,) + o[k].shape))
+        o.close()
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite)
+    desc = f"seed {seed} adaptive shape {(nx, nu, N)} B {B} max_iter {kw['max_iter']} ct {kw['check_termination']} soc {cfg['en_state_soc']}{cfg['en_input_soc']}"
+    for k in ("iter", "sol_solved", "status"):
+        if not np.array_equal(out[k].astype(int), ref[k].astype(int)):
+            return f"{desc}: {k} {out[k].astype(int).tolist()} vs {ref[k].astype(int).tolist()}"
+    if not np.allclose(out["rho"], ref["rho"], rtol=1e-7, atol=0):
+        return f"{desc}: rho {out['rho']} vs {ref['rho']}"
+    worst, wk = 0.0, ""
+    for k, v in ref.items():
+        if v.ndim >= 2 and k in out:
+            e = rel_err(out[k], v)
+            if e > worst:
+                worst, wk = e, k
+    if worst > 1e-7:
+        return f"{desc}: worst field error {worst:.3e} in {wk}"
+    return None
+
+
 PHASES = ("update_linear_cost", "backward_pass_grad", "forward_pass", "update_slack", "update_dual")
 
 
@@ -137,6 +195,8 @@ def phase_trial(seed):
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "phases":
         trial = phase_trial
+    if len(sys.argv) > 3 and sys.argv[3] == "adaptive":
+        trial = adaptive_trial
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     assert build_oracle()
