@@ -284,6 +284,151 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
     else { double a0 = init; ring1<COL0, NCOL>(a0, src, m); return a0; }
 }
 
+
+// ---- fused sweep steps (single-chain mode, box-only variants) --------------------------------------------------------------
+// The leading `s_nop 1` of a DPP block only waits out the two wait states a DPP read needs after a VALU write of its source.
+// Here the lane-local instructions a sweep step needs anyway stand in front of the DPP chain INSIDE the same asm statement --
+// the linear-cost terms of the backward step, the first half of the slot update of the forward step -- so the wait states are
+// filled with work (38 s_nop per (12,4,10) iteration gone, +2.7 % measured as an upper bound with the nops simply deleted)
+// and no compiler-inserted copy can land between the producer of a source and its first DPP read.  Same instructions, same
+// operand order as the unfused code: bit-identical results.
+#define FCA1 "v_fmac_f64_dpp %[acc], %[sa], %[a0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA2 FCA1 "v_fmac_f64_dpp %[acc], %[sa], %[a1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA3 FCA2 "v_fmac_f64_dpp %[acc], %[sa], %[a2] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA4 FCA3 "v_fmac_f64_dpp %[acc], %[sa], %[a3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA5 FCA4 "v_fmac_f64_dpp %[acc], %[sa], %[a4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA6 FCA5 "v_fmac_f64_dpp %[acc], %[sa], %[a5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA7 FCA6 "v_fmac_f64_dpp %[acc], %[sa], %[a6] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA8 FCA7 "v_fmac_f64_dpp %[acc], %[sa], %[a7] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA9 FCA8 "v_fmac_f64_dpp %[acc], %[sa], %[a8] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA10 FCA9 "v_fmac_f64_dpp %[acc], %[sa], %[a9] row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA11 FCA10 "v_fmac_f64_dpp %[acc], %[sa], %[a10] row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA12 FCA11 "v_fmac_f64_dpp %[acc], %[sa], %[a11] row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA13 FCA12 "v_fmac_f64_dpp %[acc], %[sa], %[a12] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA14 FCA13 "v_fmac_f64_dpp %[acc], %[sa], %[a13] row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA15 FCA14 "v_fmac_f64_dpp %[acc], %[sa], %[a14] row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+#define FCA16 FCA15 "v_fmac_f64_dpp %[acc], %[sa], %[a15] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB1 "v_fmac_f64_dpp %[acc], %[sb], %[b0] row_newbcast:%[c0]+0 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB2 FCB1 "v_fmac_f64_dpp %[acc], %[sb], %[b1] row_newbcast:%[c0]+1 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB3 FCB2 "v_fmac_f64_dpp %[acc], %[sb], %[b2] row_newbcast:%[c0]+2 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB4 FCB3 "v_fmac_f64_dpp %[acc], %[sb], %[b3] row_newbcast:%[c0]+3 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB5 FCB4 "v_fmac_f64_dpp %[acc], %[sb], %[b4] row_newbcast:%[c0]+4 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB6 FCB5 "v_fmac_f64_dpp %[acc], %[sb], %[b5] row_newbcast:%[c0]+5 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB7 FCB6 "v_fmac_f64_dpp %[acc], %[sb], %[b6] row_newbcast:%[c0]+6 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB8 FCB7 "v_fmac_f64_dpp %[acc], %[sb], %[b7] row_newbcast:%[c0]+7 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB9 FCB8 "v_fmac_f64_dpp %[acc], %[sb], %[b8] row_newbcast:%[c0]+8 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB10 FCB9 "v_fmac_f64_dpp %[acc], %[sb], %[b9] row_newbcast:%[c0]+9 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB11 FCB10 "v_fmac_f64_dpp %[acc], %[sb], %[b10] row_newbcast:%[c0]+10 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB12 FCB11 "v_fmac_f64_dpp %[acc], %[sb], %[b11] row_newbcast:%[c0]+11 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB13 FCB12 "v_fmac_f64_dpp %[acc], %[sb], %[b12] row_newbcast:%[c0]+12 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB14 FCB13 "v_fmac_f64_dpp %[acc], %[sb], %[b13] row_newbcast:%[c0]+13 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB15 FCB14 "v_fmac_f64_dpp %[acc], %[sb], %[b14] row_newbcast:%[c0]+14 row_mask:0xf bank_mask:0xf\n\t"
+#define FCB16 FCB15 "v_fmac_f64_dpp %[acc], %[sb], %[b15] row_newbcast:%[c0]+15 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA1 "v_fmac_f64_dpp %[t], %[xi], %[a0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA2 FFA1 "v_fmac_f64_dpp %[t], %[xi], %[a1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA3 FFA2 "v_fmac_f64_dpp %[t], %[xi], %[a2] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA4 FFA3 "v_fmac_f64_dpp %[t], %[xi], %[a3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA5 FFA4 "v_fmac_f64_dpp %[t], %[xi], %[a4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA6 FFA5 "v_fmac_f64_dpp %[t], %[xi], %[a5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA7 FFA6 "v_fmac_f64_dpp %[t], %[xi], %[a6] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA8 FFA7 "v_fmac_f64_dpp %[t], %[xi], %[a7] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA9 FFA8 "v_fmac_f64_dpp %[t], %[xi], %[a8] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA10 FFA9 "v_fmac_f64_dpp %[t], %[xi], %[a9] row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA11 FFA10 "v_fmac_f64_dpp %[t], %[xi], %[a10] row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA12 FFA11 "v_fmac_f64_dpp %[t], %[xi], %[a11] row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA13 FFA12 "v_fmac_f64_dpp %[t], %[xi], %[a12] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA14 FFA13 "v_fmac_f64_dpp %[t], %[xi], %[a13] row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA15 FFA14 "v_fmac_f64_dpp %[t], %[xi], %[a14] row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+#define FFA16 FFA15 "v_fmac_f64_dpp %[t], %[xi], %[a15] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB1 "v_fmac_f64_dpp %[xn], %[t], %[b0] row_newbcast:%[c0]+0 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB2 FFB1 "v_fmac_f64_dpp %[xn], %[t], %[b1] row_newbcast:%[c0]+1 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB3 FFB2 "v_fmac_f64_dpp %[xn], %[t], %[b2] row_newbcast:%[c0]+2 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB4 FFB3 "v_fmac_f64_dpp %[xn], %[t], %[b3] row_newbcast:%[c0]+3 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB5 FFB4 "v_fmac_f64_dpp %[xn], %[t], %[b4] row_newbcast:%[c0]+4 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB6 FFB5 "v_fmac_f64_dpp %[xn], %[t], %[b5] row_newbcast:%[c0]+5 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB7 FFB6 "v_fmac_f64_dpp %[xn], %[t], %[b6] row_newbcast:%[c0]+6 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB8 FFB7 "v_fmac_f64_dpp %[xn], %[t], %[b7] row_newbcast:%[c0]+7 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB9 FFB8 "v_fmac_f64_dpp %[xn], %[t], %[b8] row_newbcast:%[c0]+8 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB10 FFB9 "v_fmac_f64_dpp %[xn], %[t], %[b9] row_newbcast:%[c0]+9 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB11 FFB10 "v_fmac_f64_dpp %[xn], %[t], %[b10] row_newbcast:%[c0]+10 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB12 FFB11 "v_fmac_f64_dpp %[xn], %[t], %[b11] row_newbcast:%[c0]+11 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB13 FFB12 "v_fmac_f64_dpp %[xn], %[t], %[b12] row_newbcast:%[c0]+12 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB14 FFB13 "v_fmac_f64_dpp %[xn], %[t], %[b13] row_newbcast:%[c0]+13 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB15 FFB14 "v_fmac_f64_dpp %[xn], %[t], %[b14] row_newbcast:%[c0]+14 row_mask:0xf bank_mask:0xf\n\t"
+#define FFB16 FFB15 "v_fmac_f64_dpp %[xn], %[t], %[b15] row_newbcast:%[c0]+15 row_mask:0xf bank_mask:0xf\n\t"
+#define FMA1 [a0] "v"(ma[0])
+#define FMA2 FMA1, [a1] "v"(ma[1])
+#define FMA3 FMA2, [a2] "v"(ma[2])
+#define FMA4 FMA3, [a3] "v"(ma[3])
+#define FMA5 FMA4, [a4] "v"(ma[4])
+#define FMA6 FMA5, [a5] "v"(ma[5])
+#define FMA7 FMA6, [a6] "v"(ma[6])
+#define FMA8 FMA7, [a7] "v"(ma[7])
+#define FMA9 FMA8, [a8] "v"(ma[8])
+#define FMA10 FMA9, [a9] "v"(ma[9])
+#define FMA11 FMA10, [a10] "v"(ma[10])
+#define FMA12 FMA11, [a11] "v"(ma[11])
+#define FMA13 FMA12, [a12] "v"(ma[12])
+#define FMA14 FMA13, [a13] "v"(ma[13])
+#define FMA15 FMA14, [a14] "v"(ma[14])
+#define FMA16 FMA15, [a15] "v"(ma[15])
+#define FMB1 [b0] "v"(mb_[0])
+#define FMB2 FMB1, [b1] "v"(mb_[1])
+#define FMB3 FMB2, [b2] "v"(mb_[2])
+#define FMB4 FMB3, [b3] "v"(mb_[3])
+#define FMB5 FMB4, [b4] "v"(mb_[4])
+#define FMB6 FMB5, [b5] "v"(mb_[5])
+#define FMB7 FMB6, [b6] "v"(mb_[6])
+#define FMB8 FMB7, [b7] "v"(mb_[7])
+#define FMB9 FMB8, [b8] "v"(mb_[8])
+#define FMB10 FMB9, [b9] "v"(mb_[9])
+#define FMB11 FMB10, [b10] "v"(mb_[10])
+#define FMB12 FMB11, [b11] "v"(mb_[11])
+#define FMB13 FMB12, [b12] "v"(mb_[12])
+#define FMB14 FMB13, [b13] "v"(mb_[13])
+#define FMB15 FMB14, [b14] "v"(mb_[14])
+#define FMB16 FMB15, [b15] "v"(mb_[15])
+#define FUSED_BWD_CASE(NA_, NB_)                                                                                        \
+    if constexpr (NA == NA_ && NB == NB_) {                                                                             \
+        asm("v_add_f64 %[tmp], %[vn], -%[g]\n\t"                                                                        \
+            "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
+            "v_fma_f64 %[acc], %[qlo], %[smask], %[cb]\n\t" FCA##NA_ FCB##NB_                                           \
+            : [qlo] "=&v"(qlo), [acc] "=&v"(acc), [tmp] "=&v"(tmp)                                                      \
+            : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
+              [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                                         \
+    }
+#define FUSED_FWD_CASE(NA_, NB_)                                                                                        \
+    if constexpr (NA == NA_ && NB == NB_) {                                                                             \
+        asm("v_add_f64 %[tt], %[xi], %[g]\n\t"                                                                          \
+            "v_max_f64 %[vm], %[lo], %[tt]\n\t" FFA##NA_                                                                \
+            "v_min_f64 %[vn], %[hi], %[vm]\n\t"                                                                         \
+            "v_mov_b64 %[xn], %[t]\n\t" FFB##NB_                                                                        \
+            : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t)                               \
+            : [xi] "v"(xi), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                  \
+    }
+// the (nx, nu) pairs of kernel_dims.txt: other shapes (run-time instantiated ones) keep the unfused blocks
+#define FUSED_SHAPES(CASE) CASE(4, 1) CASE(12, 4) CASE(6, 3) CASE(2, 2) CASE(4, 2) CASE(8, 2) CASE(12, 2) CASE(8, 4) CASE(8, 8) CASE(4, 4) CASE(4, 8)
+constexpr bool fused_shape(int na, int nb) {
+    return (na == 4 && nb == 1) || (na == 12 && nb == 4) || (na == 6 && nb == 3) || (na == 2 && nb == 2) || (na == 4 && nb == 2) || (na == 8 && nb == 2) ||
+           (na == 12 && nb == 2) || (na == 8 && nb == 4) || (na == 8 && nb == 8) || (na == 4 && nb == 4) || (na == 4 && nb == 8);
+}
+// backward step: qlo = fma(-rho, vn - g, qx); acc = fma(qlo, smask, cb) + sum_k bcast(sa, k) ma[k] + sum_k bcast(sb, NA + k) mb_[k]
+template <int NA, int NB>
+__device__ __forceinline__ void fused_backward_step(double& qlo, double& acc, double vn, double g, double qx, double rho, double smask, double cb,
+                                                    double sa, double sb, const double* ma, const double* mb_) {
+    double tmp;
+    FUSED_SHAPES(FUSED_BWD_CASE)
+    (void)tmp;
+}
+// forward step: tt = xi + g; vn = min(hi, max(lo, tt)); t += sum_k bcast(xi, k) ma[k]; xn = t + sum_k bcast(t, NA + k) mb_[k]
+template <int NA, int NB>
+__device__ __forceinline__ void fused_forward_step(double& tt, double& vn, double& t, double& xn, double xi, double g, double lo, double hi,
+                                                   const double* ma, const double* mb_) {
+    double vm;
+    FUSED_SHAPES(FUSED_FWD_CASE)
+    (void)vm;
+}
+
 // v_max_f64 / v_min_f64 without the canonicalising `v_max x, x` hipcc puts in front of fmax/fmin
 // operands that come from memory (the box bounds): the hardware quiets NaNs by itself.
 __device__ __forceinline__ double vmax64(double a, double b) {
@@ -390,6 +535,7 @@ void admm_solve_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
+    constexpr bool FUSED = MODE == 2 && !SOC && LIN == 0 && fused_shape(NX, NU);      // fused_backward_step / fused_forward_step
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
     const int grp = lane >> 4;
@@ -629,6 +775,15 @@ void admm_solve_kernel(const SolveArgs P) {
                     // ---- backward_pass_grad, admm.cpp:13-20
 #pragma unroll
                     for (int i = N - 2; i >= 0; --i) {
+                        if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
+                            double qlo, res;
+                            fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                            pcur = res;                                                 // p_i | d_i
+                            Dn[i] = fma(res, nim, cf);
+                            if constexpr (DBG) { Qd[i] = qlo; Pd[i] = res; Dd[i + 1] = res; }
+                            qhi = qlo;
+                            continue;
+                        }
                         double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
                         if constexpr (SOC) qlo = fma(-rho, VC[i] - GC[i], qlo);     // :269 | :282
                         if constexpr (LS) qlo = fma(-rho, VL[i] - GL[i], qlo);      // :272 | :285
@@ -711,6 +866,18 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int i = 0; i < N - 1; ++i) {
                         const double lo_n = UB ? lo_u : sLo[(i + 1) * 16 + j], hi_n = UB ? hi_u : sHi[(i + 1) * 16 + j];
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
+                            double tt, vn, xn, t = Dn[i];
+                            const double xi = X[i];
+                            fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
+                            X[i + 1] = xn;
+                            pmax = fmax(pmax, fabs(xi - vn));
+                            dmax = fmax(dmax, fabs(VP[i] - vn));
+                            G[i] = tt - vn;
+                            VN[i] = vn;
+                            lo_c = lo_n; hi_c = hi_n;
+                            continue;
+                        }
                         const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
                         X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)
                         slot_update(i, lo_c, hi_c);
