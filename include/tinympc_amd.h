@@ -226,6 +226,9 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 /* derived state: "auto_split_k" (the K the automatic split solve derived from the last iteration histogram; 0 = plain launch),
  * "auto_split_permille" (its predicted time, in 1/1000 of the plain launch's), "repack_after" */
 long tiny_batch_get_option(TinyBatch* b, const char* name);
+/* the cost model behind "repack_after" = -1 by itself (host arithmetic, no GPU): hist[1024], hist[i] = instances whose solve takes
+ * i iterations; returns the proposed K (0 = plain launch), *ratio = predicted time of the best split / of the plain launch */
+int tiny_predict_split(const unsigned* hist, int nx, int nu, int N, int max_iter, int check_termination, int num_cus, double* ratio);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
 /* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state
  * vectors ([n_points][nx] doubles), shared by every instance.  While it is set, the state reference of a solve

@@ -1,0 +1,37 @@
+"""CPU: the cost model behind the automatic split solve ("repack_after" = -1; tiny_predict_split, host arithmetic).
+Measured on one MI355X (profiles/r02_sweep_auto_split.md, r02_configs_3_4.json): the config-3 distribution (mode 9, tail to
+100) gains 16-19 % at K = 9 ... 16; a batch of identical instances, or one whose counts sit in a narrow band, gains nothing."""
+import numpy as np
+
+import tinympc_amd as tm
+
+
+def _hist(counts):
+    h = np.zeros(1024, dtype=np.int64)
+    for it, c in counts.items():
+        h[it] += c
+    return h
+
+
+def test_config3_distribution_gets_a_small_cap():
+    # iteration histogram of BASELINE config 3 (262 144 cold tracking solves), rounded
+    h = _hist({7: 9000, 8: 61000, 9: 98000, 10: 58000, 11: 14000, 12: 5000, 14: 3000, 18: 3000, 25: 3500, 40: 3500, 70: 3000, 100: 1144})
+    k, ratio = tm.predict_split(h, 12, 4, 10, max_iter=100)
+    assert 6 <= k <= 24 and 0.75 < ratio < 0.95, (k, ratio)
+
+
+def test_uniform_and_narrow_distributions_do_not_split():
+    assert tm.predict_split(_hist({9: 262144}), 12, 4, 10, 100)[0] == 0
+    assert tm.predict_split(_hist({100: 65536}), 12, 4, 10, 100)[0] == 0
+    k, ratio = tm.predict_split(_hist({104: 20000, 108: 60000, 110: 90000, 113: 60000, 118: 32144}), 12, 4, 10, 500)
+    assert k == 0 or ratio > 0.9, (k, ratio)
+
+
+def test_the_cap_respects_check_termination_and_small_batches_gain_less():
+    h = _hist({7: 9000, 8: 61000, 9: 98000, 10: 58000, 11: 14000, 12: 5000, 14: 3000, 18: 3000, 25: 3500, 40: 3500, 70: 3000, 100: 1144})
+    k, _ = tm.predict_split(h, 12, 4, 10, max_iter=100, check_termination=5)
+    assert k % 5 == 0
+    small = (h // 32).astype(np.int64)                        # 8 192 instances: the follow-up stages cannot fill the wave slots
+    _, r_small = tm.predict_split(small, 12, 4, 10, 100)
+    _, r_big = tm.predict_split(h, 12, 4, 10, 100)
+    assert r_small > r_big

@@ -43,7 +43,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
     "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy",
-    "tiny_batch_get_option", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
+    "tiny_batch_get_option", "tiny_predict_split", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -123,6 +123,7 @@ def lib():
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_set_cache.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.tiny_predict_split.argtypes = [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         L.tiny_batch_get_option.argtypes = [C.c_void_p, C.c_char_p]
         L.tiny_batch_get_option.restype = C.c_long
         L.tiny_batch_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -634,6 +635,17 @@ class TinyGroupSolver:
         self._check(lib().tiny_group_get_status(self._h, it.ctypes.data_as(_ip), so.ctypes.data_as(_ip), st.ctypes.data_as(_ip),
                                                 res.ctypes.data_as(_dp)), "get_status")
         return dict(iter=it, solved=so, status=st, residuals=res)
+
+
+def predict_split(hist, nx, nu, N, max_iter, check_termination=1, num_cus=256):
+    """(K, predicted time ratio) of the automatic split solve's cost model for an iteration-count histogram (hist[i] =
+    instances needing i iterations); K = 0: a plain launch is predicted to be within 5 %.  Host arithmetic, no GPU."""
+    h = np.zeros(1024, dtype=np.uint32)
+    hist = np.asarray(hist)
+    h[:min(len(hist), 1024)] = hist[:1024]
+    r = C.c_double(1.0)
+    k = lib().tiny_predict_split(h.ctypes.data_as(C.POINTER(C.c_uint)), nx, nu, N, max_iter, check_termination, num_cus, C.byref(r))
+    return int(k), float(r.value)
 
 
 def rccl_unique_id() -> bytes:

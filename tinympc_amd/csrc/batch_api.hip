@@ -668,15 +668,14 @@ static double predicted_time(const unsigned* hist, int max_iter, int cap, int gr
 }
 
 // the K (multiple of check_termination) with the smallest predicted time, 0 when a plain launch is within 5 % of it
-static int choose_split(const TinyBatch* b, const unsigned* hist, double* ratio) {
-    const int M = b->set.max_iter, ct = std::max(1, b->set.check_termination), gr = std::max(2, b->repack_growth);
-    const int wps = solve_kernel_waves_per_simd(b->nx + b->nu, b->N, soc_active(b));
-    const double slots = (double)b->num_cus * 4.0 * wps;      // wave slots of the chip
+static int choose_split_for(int nx, int nu, int N, bool soc, int M, int ct, int gr, int num_cus, const unsigned* hist, double* ratio) {
+    const int wps = solve_kernel_waves_per_simd(nx + nu, N, soc);
+    const double slots = (double)num_cus * 4.0 * wps;         // wave slots of the chip
     // one wave-iteration (4 instances) in microseconds: its FLOPs at ~75 % of a SIMD's FP64 issue rate (76.8 GFLOP/s per SIMD),
     // shared by the waves of the SIMD -- 1.7 us for the quadrotor at two waves (measured 1.64); the fixed costs of a
     // stage in that unit: ~8 us of launch latency, and the record reload + store (2.45 us per wave for the quadrotor's 156 slots)
-    const double S = (double)b->nx * b->N + (double)b->nu * (b->N - 1);
-    const double fl = 4.0 * S + 2.0 * b->nx * b->nx + 3.0 * b->nx + (b->N - 1.0) * (4.0 * b->nx * b->nx + 8.0 * b->nx * b->nu + 2.0 * b->nu * b->nu + 4.0 * b->nu + 5.0 * b->nx) + 11.0 * S;
+    const double S = (double)nx * N + (double)nu * (N - 1);
+    const double fl = 4.0 * S + 2.0 * nx * nx + 3.0 * nx + (N - 1.0) * (4.0 * nx * nx + 8.0 * nx * nu + 2.0 * nu * nu + 4.0 * nu + 5.0 * nx) + 11.0 * S;
     const double t_it = 4.0 * fl * wps / (76.8e3 * (wps == 2 ? 0.75 : 0.45));
     const double launch_iters = 8.0 / t_it, reload_iters = 2.45 * (S / 156.0) / t_it;
     const double plain = predicted_time(hist, M, 0, gr, slots, launch_iters, reload_iters);
@@ -689,6 +688,10 @@ static int choose_split(const TinyBatch* b, const unsigned* hist, double* ratio)
     }
     if (ratio) *ratio = plain > 0.0 ? best / plain : 1.0;
     return (plain > 0.0 && best < 0.95 * plain) ? best_k : 0;
+}
+static int choose_split(const TinyBatch* b, const unsigned* hist, double* ratio) {
+    return choose_split_for(b->nx, b->nu, b->N, soc_active(b), b->set.max_iter, std::max(1, b->set.check_termination), std::max(2, b->repack_growth),
+                            b->num_cus, hist, ratio);
 }
 
 // ---- adaptive rho: per-instance cache state + the lane tables of the adaptation step -----------------------------------
@@ -1623,6 +1626,14 @@ int tiny_jit_used(char* out, int out_len) {
     const int n = jit_used_names(&names);
     if (out && out_len > 0) snprintf(out, (size_t)out_len, "%s", names.c_str());
     return n;
+}
+
+// The cost model of the automatic split solve by itself (host arithmetic, no GPU): hist[i] = instances whose solve takes i
+// iterations (1024 bins).  Returns the proposed K (0: a plain launch is predicted within 5 %), *ratio = predicted time of the
+// best split / plain launch.  What launch_solve consults with the histogram of the previous solve.
+int tiny_predict_split(const unsigned* hist, int nx, int nu, int N, int max_iter, int check_termination, int num_cus, double* ratio) {
+    if (!hist || nx <= 0 || nu <= 0 || N < 2 || max_iter <= 0) return 0;
+    return choose_split_for(nx, nu, N, false, max_iter, std::max(1, check_termination), 2, num_cus > 0 ? num_cus : 256, hist, ratio);
 }
 
 // read-back of derived state: "auto_split_k" (the K the automatic split picked from the last histogram, 0 = plain launch),
