@@ -116,6 +116,7 @@ def config3(B=262144, reps=3):
     s.set_x_ref(Xref)
     s.set_u_ref(Uref)
     best, one_shot = None, {}
+    s.set_option("repack_after", 0)           # the plain launch (the default is the automatic split, measured below)
     for _ in range(reps):
         s.reset()
         s.set_x0(x0)
@@ -155,10 +156,23 @@ def config3(B=262144, reps=3):
         so = s.reduce_stats()
         assert so[0] == st[0] and so[1] == st[1] and np.array_equal(s.status()["iter"], it), "split solve differs"
         repack[f"repack_after={cap}"] = dict(kernel_ms=bm, solves_per_s=B / (bm * 1e-3), admm_iters_per_s=so[0] / (bm * 1e-3))
-    s.set_option("repack_after", 0)
+    # the default: automatic split -- plain solves first (timed, histogram), then the proposed K, kept if the clock confirms it
+    s.set_option("repack_after", -1)
+    auto_ms = []
+    for _ in range(10):
+        s.reset()
+        s.set_x0(x0)
+        s.set_option("timing", 1)
+        s.solve_async()
+        auto_ms.append(float(s.timing_ms()[0]))
+    so = s.reduce_stats()
+    assert so[0] == st[0] and np.array_equal(s.status()["iter"], it), "automatic split differs"
+    auto = dict(kernel_ms_per_solve=auto_ms, kernel_ms=min(auto_ms[4:]), admm_iters_per_s=so[0] / (min(auto_ms[4:]) * 1e-3),
+                K=s.get_option("auto_split_k"), predicted=s.get_option("auto_split_permille") / 1000.0,
+                measured=s.get_option("auto_split_measured_permille") / 1000.0, verdict=s.get_option("auto_split_verdict"))
     s.close()
     t = best * 1e-3
-    return dict(one_shot=one_shot, repack=repack, config="quadrotor_tracking x262144, per-instance random refs, one cold solve", batch=B, kernel_ms=best,
+    return dict(one_shot=one_shot, repack=repack, automatic_split=auto, config="quadrotor_tracking x262144, per-instance random refs, one cold solve (kernel_ms: plain launch, repack_after = 0)", batch=B, kernel_ms=best,
                 solves_per_s=B / t, admm_iters_per_s=st[0] / t, iters_per_solve=st[0] / B, solved_fraction=st[1] / B,
                 iter_histogram={int(v): int(c) for v, c in zip(*np.unique(it, return_counts=True))},
                 hbm_frac=alg * B / t / 8e12, fp64_frac=st[0] * tm.flops_per_iter(nx, nu, N) / t / 78.6e12)
