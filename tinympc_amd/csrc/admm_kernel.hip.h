@@ -388,7 +388,8 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
 #define FMB14 FMB13, [b13] "v"(mb_[13])
 #define FMB15 FMB14, [b14] "v"(mb_[14])
 #define FMB16 FMB15, [b15] "v"(mb_[15])
-#define FUSED_BWD_CASE(NA_, NB_)                                                                                        \
+#define FUSED_BWD_CASE(NA_, NB_) FUSED_BWD_CASE_(NA_, NB_)
+#define FUSED_BWD_CASE_(NA_, NB_)                                                                                       \
     if constexpr (NA == NA_ && NB == NB_) {                                                                             \
         asm("v_add_f64 %[tmp], %[vn], -%[g]\n\t"                                                                        \
             "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
@@ -397,7 +398,8 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
             : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
               [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                                         \
     }
-#define FUSED_FWD_CASE(NA_, NB_)                                                                                        \
+#define FUSED_FWD_CASE(NA_, NB_) FUSED_FWD_CASE_(NA_, NB_)
+#define FUSED_FWD_CASE_(NA_, NB_)                                                                                       \
     if constexpr (NA == NA_ && NB == NB_) {                                                                             \
         asm("v_add_f64 %[tt], %[xi], %[g]\n\t"                                                                          \
             "v_max_f64 %[vm], %[lo], %[tt]\n\t" FFA##NA_                                                                \
@@ -406,12 +408,15 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
             : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t)                               \
             : [xi] "v"(xi), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                  \
     }
-// the (nx, nu) pairs of kernel_dims.txt: other shapes (run-time instantiated ones) keep the unfused blocks
-#define FUSED_SHAPES(CASE) CASE(4, 1) CASE(12, 4) CASE(6, 3) CASE(2, 2) CASE(4, 2) CASE(8, 2) CASE(12, 2) CASE(8, 4) CASE(8, 8) CASE(4, 4) CASE(4, 8)
-constexpr bool fused_shape(int na, int nb) {
-    return (na == 4 && nb == 1) || (na == 12 && nb == 4) || (na == 6 && nb == 3) || (na == 2 && nb == 2) || (na == 4 && nb == 2) || (na == 8 && nb == 2) ||
-           (na == 12 && nb == 2) || (na == 8 && nb == 4) || (na == 8 && nb == 8) || (na == 4 && nb == 4) || (na == 4 && nb == 8);
-}
+// One (nx, nu) pair per translation unit: the Makefile (compiled-in shapes) and jit.hip (run-time instantiated ones) define
+// TINYMPC_FUSED_NX / _NU as plain numbers in front of this header, so that exactly one pair of asm statements is spelled out.
+#if defined(TINYMPC_FUSED_NX) && defined(TINYMPC_FUSED_NU)
+#define FUSED_SHAPES(CASE) CASE(TINYMPC_FUSED_NX, TINYMPC_FUSED_NU)
+constexpr bool fused_shape(int na, int nb) { return na == TINYMPC_FUSED_NX && nb == TINYMPC_FUSED_NU; }
+#else
+#define FUSED_SHAPES(CASE)
+constexpr bool fused_shape(int, int) { return false; }
+#endif
 // backward step: qlo = fma(-rho, vn - g, qx); acc = fma(qlo, smask, cb) + sum_k bcast(sa, k) ma[k] + sum_k bcast(sb, NA + k) mb_[k]
 template <int NA, int NB>
 __device__ __forceinline__ void fused_backward_step(double& qlo, double& acc, double vn, double g, double qx, double rho, double smask, double cb,

@@ -133,7 +133,13 @@ Code compile(const std::string& name_s, const bool tile) {
         const size_t p = hdr.find(inc);
         if (p != std::string::npos) hdr.replace(p, std::string(inc).size(), "");
     }
-    const std::string src = tile ? "#include \"tile_kernel.hip.h\"\n" : "#include \"admm_kernel.hip.h\"\n";
+    std::string src = tile ? "#include \"tile_kernel.hip.h\"\n" : "#include \"admm_kernel.hip.h\"\n";
+    if (!tile) {        // the fused sweep steps of admm_kernel.hip.h are spelled out for ONE (nx, nu) pair per compilation: this one's
+        int fnx = 0, fnu = 0;
+        const size_t lt = name_s.find('<');
+        if (lt != std::string::npos && sscanf(name_s.c_str() + lt + 1, "%d , %d", &fnx, &fnu) == 2 && fnx > 0 && fnu > 0 && fnx + fnu <= 16)
+            src = "#define TINYMPC_FUSED_NX " + std::to_string(fnx) + "\n#define TINYMPC_FUSED_NU " + std::to_string(fnu) + "\n" + src;
+    }
     const char* hn[] = {"admm_kernel.hip.h", "tile_kernel.hip.h"};
     const char* hs[] = {hdr.c_str(), kTileKernelSrc};
     Rtc::Program prog = nullptr;
