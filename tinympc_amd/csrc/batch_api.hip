@@ -37,6 +37,28 @@ __global__ void unpack_kpi_kernel(const double* __restrict__ kpi, double* __rest
         dst[e] = kpi[(b * N + i) * nz + row_off + r];
     }
 }
+// Many fields in ONE launch (the drop-in path moves 9-20 workspace fields per solve: one launch each way instead of one per field).
+// blockIdx.y = entry; an entry is a KPI field (rows x cols per instance at row_off) or, kpi == nullptr, a raw copy of `count` doubles.
+struct XferEntry { double* kpi; double* raw; long off; long count; int rows, row_off, cols; };
+struct XferTable { XferEntry e[24]; int n; };
+__global__ void xfer_fields_kernel(const XferTable t, double* __restrict__ buf, int batch, int N, int nz, int to_device) {
+    const XferEntry en = t.e[blockIdx.y];
+    double* x = buf + en.off;
+    if (!en.kpi) {
+        for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)en.count; e += (size_t)gridDim.x * blockDim.x) {
+            if (to_device) en.raw[e] = x[e]; else x[e] = en.raw[e];
+        }
+        return;
+    }
+    const size_t total = (size_t)batch * en.cols * en.rows;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % en.rows);
+        const int i = (int)((e / en.rows) % en.cols);
+        const size_t b = e / ((size_t)en.rows * en.cols);
+        double* rec = en.kpi + (b * N + i) * nz + en.row_off + r;
+        if (to_device) *rec = x[e]; else x[e] = *rec;
+    }
+}
 __global__ void broadcast_rows_kernel(double* __restrict__ dst, const double* __restrict__ src, int batch, int n) {
     const size_t total = (size_t)batch * n;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
@@ -1332,6 +1354,53 @@ int tiny_batch_set_cache(TinyBatch* b, const char* name, const double* src) {
     if (b->d_arho) { HIP_TRY(b, hipSetDevice(b->device)); if (int rc = adaptive_fresh_state(b)) return rc; }   // adaptive state restarts from it
     return TINY_OK;
 }
+
+static int prepare_field(TinyBatch* b, TinyField field, double** kpi, int* rows, int* row_off, int* cols) {
+    if (field >= TINY_F_Q && field <= TINY_F_D) {            // inputs of the single-phase entry points only (tiny_batch_phase)
+        if (int rc = ensure_debug_buffers(b)) return rc;
+    }
+    if (field >= TINY_F_VLNEW && field < TINY_F_COUNT) {     // linear-constraint records are allocated on first use
+        double** arr[] = {&b->d_lslack, &b->d_lslack, &b->d_ldual, &b->d_ldual, &b->d_tlslack, &b->d_tlslack, &b->d_tldual, &b->d_tldual};
+        if (int rc = ensure_kpi(b, arr[field - TINY_F_VLNEW])) return rc;
+    }
+    if (field_geometry(b, field, kpi, rows, row_off, cols)) return fail(b, TINY_ERR_ARG, "bad field %d", (int)field);
+    if (!*kpi) return fail(b, TINY_ERR_ARG, "field %d has no record yet (constraint family never enabled)", (int)field);
+    return TINY_OK;
+}
+
+}  // extern "C"
+namespace tinympc_amd {
+// fields[i] <-> d_buf + offsets[i] (device memory, host layout [batch][cols][rows]) in ONE launch; TINY_F_X0 is the nx-vector x0;
+// with_status (download only): status int4 [batch] and the residuals [batch][4] follow at off_status / off_resid
+int xfer_fields(TinyBatch* b, const TinyField* fields, const size_t* offsets, int n, double* d_buf, bool to_device,
+                bool with_status, size_t off_status, size_t off_resid) {
+    if (n + (with_status ? 2 : 0) > 24) return fail(b, TINY_ERR_ARG, "too many fields in one transfer");
+    HIP_TRY(b, hipSetDevice(b->device));
+    XferTable t;
+    t.n = 0;
+    for (int i = 0; i < n; ++i) {
+        XferEntry& e = t.e[t.n++];
+        e.off = (long)offsets[i];
+        if (fields[i] == TINY_F_X0) { e.kpi = nullptr; e.raw = b->d_x0; e.count = (long)b->batch * b->nx; e.rows = e.row_off = e.cols = 0; continue; }
+        if (int rc = prepare_field(b, fields[i], &e.kpi, &e.rows, &e.row_off, &e.cols)) return rc;
+        e.raw = nullptr; e.count = 0;
+        if (to_device && fields[i] == TINY_F_XREF) b->xref_shared = false;
+        if (to_device && fields[i] == TINY_F_UREF) b->uref_shared = false;
+    }
+    if (with_status && !to_device) {
+        XferEntry& s = t.e[t.n++];
+        s.kpi = nullptr; s.raw = reinterpret_cast<double*>(b->d_status); s.count = (long)b->batch * 2; s.off = (long)off_status; s.rows = s.row_off = s.cols = 0;
+        XferEntry& r = t.e[t.n++];
+        r.kpi = nullptr; r.raw = b->d_resid; r.count = (long)b->batch * 4; r.off = (long)off_resid; r.rows = r.row_off = r.cols = 0;
+    }
+    const size_t per = (size_t)b->batch * b->N * b->nx;
+    const int gx = (int)std::min<size_t>(512, (per + 255) / 256);
+    hipLaunchKernelGGL(xfer_fields_kernel, dim3(gx > 0 ? gx : 1, t.n), dim3(256), 0, b->stream, t, d_buf, b->batch, b->N, b->nx + b->nu, to_device ? 1 : 0);
+    HIP_TRY(b, hipGetLastError());
+    return TINY_OK;
+}
+}  // namespace tinympc_amd
+extern "C" {
 
 int tiny_batch_set(TinyBatch* b, TinyField field, const double* src, int flags) {
     if (!b || !src) return TINY_ERR_NULL;

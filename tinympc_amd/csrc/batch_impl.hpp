@@ -127,6 +127,8 @@ struct TinyBatch {
 namespace tinympc_amd {
 int fail(TinyBatch* b, int code, const char* fmt, ...);
 int launch_solve(TinyBatch* b);
+int xfer_fields(TinyBatch* b, const TinyField* fields, const size_t* offsets, int n, double* d_buf, bool to_device,
+                bool with_status, size_t off_status, size_t off_resid);
 // project_soc (which = 0) / project_hyperplane (1) of an n-vector in device memory, one GPU thread, synchronous
 int launch_projection(int which, double* v, const double* a, int n, float mu, double b);
 }  // namespace tinympc_amd

@@ -345,12 +345,14 @@ int solve_group(TinySolver** solvers, int n) {
     for (const FieldMap& fm : in) off += (size_t)n * fsize(fm);
     const double t1 = now();
     if (hipMemcpyAsync(ctx.d_xfer, ctx.h_pin, in_doubles * sizeof(double), hipMemcpyHostToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
-    off = 0;
-    for (const FieldMap& fm : in) {
-        if (int rc = tiny_batch_set(b, fm.f, ctx.d_xfer + off, TINY_DEVICE)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
-        off += (size_t)n * fsize(fm);
+    {   // device-side unpack of every uploaded field (+ x0) into the records: ONE launch
+        std::vector<TinyField> fs;
+        std::vector<size_t> offs;
+        off = 0;
+        for (const FieldMap& fm : in) { fs.push_back(fm.f); offs.push_back(off); off += (size_t)n * fsize(fm); }
+        fs.push_back(TINY_F_X0); offs.push_back(off);
+        if (int rc = xfer_fields(b, fs.data(), offs.data(), (int)fs.size(), ctx.d_xfer, true, false, 0, 0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
     }
-    if (int rc = tiny_batch_set(b, TINY_F_X0, ctx.d_xfer + off, TINY_DEVICE)) return rc;
     // adaptive rho: every solver's own cache is state (rho, Kinf, Pinf and the dead copies C1, C2 move during the solve and
     // persist, rho_benchmark.cpp:196-210): up before the launch, back into the caller's TinyCache after it
     struct CachePart { const char* name; size_t per; TinyMatrixPOD TinyCache::*m; };
@@ -387,21 +389,23 @@ int solve_group(TinySolver** solvers, int n) {
     }
 
     off = 0;
-    for (const FieldMap& fm : out) {
-        if (int rc = tiny_batch_get(b, fm.f, ctx.d_xfer + off, TINY_DEVICE)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
-        off += (size_t)n * fsize(fm);
-    }
+    for (const FieldMap& fm : out) off += (size_t)n * fsize(fm);
     const size_t off_status = off, off_resid = off + (size_t)n * 2;
-    if (hipMemcpyAsync(ctx.d_xfer + off_status, b->d_status, n * sizeof(int4), hipMemcpyDeviceToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
-    if (hipMemcpyAsync(ctx.d_xfer + off_resid, b->d_resid, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    {   // every downloaded field + status + residuals into the transfer buffer: ONE launch
+        std::vector<TinyField> fs;
+        std::vector<size_t> offs;
+        size_t o = 0;
+        for (const FieldMap& fm : out) { fs.push_back(fm.f); offs.push_back(o); o += (size_t)n * fsize(fm); }
+        if (int rc = xfer_fields(b, fs.data(), offs.data(), (int)fs.size(), ctx.d_xfer, false, true, off_status, off_resid)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+    }
     if (hipMemcpyAsync(ctx.h_pin, ctx.d_xfer, out_doubles * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
     const double t2 = now();
     if (hipStreamSynchronize(b->stream) != hipSuccess) return TINY_ERR_HIP;
     const double t3 = now();
     const int4* st = reinterpret_cast<const int4*>(ctx.h_pin + off_status);
     const double* res = ctx.h_pin + off_resid;
-    std::vector<std::string> lines(17);                       // "Solver converged ..." lines per thread, printed in solver order
-    std::vector<int> unsolved(17, 0);
+    std::vector<std::string> lines(33);                       // "Solver converged ..." lines per thread, printed in solver order
+    std::vector<int> unsolved(33, 0);
     parallel_solvers(n, [&](int lo, int hi, int t) {
         size_t o = 0;
         for (const FieldMap& fm : out) {
