@@ -398,6 +398,19 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
             : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
               [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                                         \
     }
+// the same with the cone slack's linear-cost term (admm.cpp:269 | :282 | :295): qlo = fma(-rho, vc - gc, fma(-rho, vn - g, qx))
+#define FUSED_BWD_SOC_CASE(NA_, NB_) FUSED_BWD_SOC_CASE_(NA_, NB_)
+#define FUSED_BWD_SOC_CASE_(NA_, NB_)                                                                                   \
+    if constexpr (NA == NA_ && NB == NB_) {                                                                             \
+        asm("v_add_f64 %[tmp], %[vn], -%[g]\n\t"                                                                        \
+            "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
+            "v_add_f64 %[tmp], %[vc], -%[gc]\n\t"                                                                       \
+            "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qlo]\n\t"                                                             \
+            "v_fma_f64 %[acc], %[qlo], %[smask], %[cb]\n\t" FCA##NA_ FCB##NB_                                           \
+            : [qlo] "=&v"(qlo), [acc] "=&v"(acc), [tmp] "=&v"(tmp)                                                      \
+            : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
+              [sb] "v"(sb), [vc] "v"(vc), [gc] "v"(gc), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                             \
+    }
 #define FUSED_FWD_CASE(NA_, NB_) FUSED_FWD_CASE_(NA_, NB_)
 #define FUSED_FWD_CASE_(NA_, NB_)                                                                                       \
     if constexpr (NA == NA_ && NB == NB_) {                                                                             \
@@ -423,6 +436,13 @@ __device__ __forceinline__ void fused_backward_step(double& qlo, double& acc, do
                                                     double sa, double sb, const double* ma, const double* mb_) {
     double tmp;
     FUSED_SHAPES(FUSED_BWD_CASE)
+    (void)tmp;
+}
+template <int NA, int NB>
+__device__ __forceinline__ void fused_backward_step_soc(double& qlo, double& acc, double vn, double g, double qx, double vc, double gc, double rho,
+                                                        double smask, double cb, double sa, double sb, const double* ma, const double* mb_) {
+    double tmp;
+    FUSED_SHAPES(FUSED_BWD_SOC_CASE)
     (void)tmp;
 }
 // forward step: tt = xi + g; vn = min(hi, max(lo, tt)); t += sum_k bcast(xi, k) ma[k]; xn = t + sum_k bcast(t, NA + k) mb_[k]
@@ -540,7 +560,11 @@ void admm_solve_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
-    constexpr bool FUSED = MODE == 2 && !SOC && LIN == 0 && fused_shape(NX, NU);      // fused_backward_step / fused_forward_step
+#ifdef TINYMPC_SOC_PER_KNOT
+    constexpr bool FUSED = MODE == 2 && !SOC && LIN == 0 && fused_shape(NX, NU);
+#else
+    constexpr bool FUSED = MODE == 2 && LIN == 0 && fused_shape(NX, NU);              // fused_backward_step(_soc) / fused_forward_step
+#endif
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
     const int grp = lane >> 4;
@@ -782,7 +806,8 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int i = N - 2; i >= 0; --i) {
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
-                            fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                            if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], VC[i], GC[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                            else fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             pcur = res;                                                 // p_i | d_i
                             Dn[i] = fma(res, nim, cf);
                             if constexpr (DBG) { Qd[i] = qlo; Pd[i] = res; Dd[i + 1] = res; }
@@ -880,6 +905,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             dmax = fmax(dmax, fabs(VP[i] - vn));
                             G[i] = tt - vn;
                             VN[i] = vn;
+                            if constexpr (SOC) sT[(grp * N + i) * 16 + j] = fma(xi, socmask, GC[i]);     // x + gc -> cone step (below)
                             lo_c = lo_n; hi_c = hi_n;
                             continue;
                         }

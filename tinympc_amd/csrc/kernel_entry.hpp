@@ -10,7 +10,7 @@ struct KernelEntry {
     SolveKernel klin[2][4];   // [soc][LIN 1..3]: register-resident linear constraints (dpp_mode 2, no debug outputs)
     SolveKernel khet[2];      // [soc]: per-instance problem data (dpp_mode 2, no debug outputs)
     SolveKernel kadapt[2];    // [dbg]: adaptive rho (dpp_mode 2, no cone)
-    SolveKernel kub;          // knot-invariant box in registers (plain variant, dpp_mode 2)
+    SolveKernel kub;          // knot-invariant box in registers (plain variant, dpp_mode 2; the cone variant spills with it: 516 B scratch, 5x slower)
 };
 struct TileEntry {
     int nx, nu, N, W, R;
