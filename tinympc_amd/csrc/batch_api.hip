@@ -1337,6 +1337,7 @@ int tiny_batch_get_cache(TinyBatch* b, const char* name, double* out, int capaci
 // their own cache instead of tiny_setup's Riccati recursion -- generated code (tiny_codegen) restores a frozen TinyCache with it.
 int tiny_batch_set_cache(TinyBatch* b, const char* name, const double* src) {
     if (!b || !name || !src) return TINY_ERR_NULL;
+    if (b->hetero) return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous batches keep per-instance caches (tiny_batch_setup_hetero)");
     std::vector<double>* v = nullptr;
     if (!strcmp(name, "rho")) { b->cache.rho = src[0]; }
     else if (!strcmp(name, "Kinf")) v = &b->cache.Kinf.a;
@@ -1350,7 +1351,6 @@ int tiny_batch_set_cache(TinyBatch* b, const char* name, const double* src) {
     else return fail(b, TINY_ERR_ARG, "unknown cache member %s", name);
     if (v) memcpy(v->data(), src, v->size() * sizeof(double));
     b->tab_dirty = true;
-    if (b->hetero) return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous batches keep per-instance caches (tiny_batch_setup_hetero)");
     if (b->d_arho) { HIP_TRY(b, hipSetDevice(b->device)); if (int rc = adaptive_fresh_state(b)) return rc; }   // adaptive state restarts from it
     return TINY_OK;
 }
