@@ -94,7 +94,9 @@ def test_fuzz_reference_entry_points_vs_oracle(capfd):
     import fuzz_compat
     from cpu_solvers import build_oracle
     assert build_oracle()
-    bad = [r for r in (fuzz_compat.trial(seed) for seed in range(1, 81)) if r]
+    # 5111, 5126, 5128: every slack family on at once (cones + static + time-varying half-spaces): 24 fields + status come
+    # back in one transfer -- found by a round-2 campaign when the single-launch transfer table held 24 entries
+    bad = [r for r in (fuzz_compat.trial(seed) for seed in list(range(1, 81)) + [5111, 5126, 5128]) if r]
     capfd.readouterr()                            # drop the "Solver converged in N iterations" lines
     assert not bad, bad[:5]
 

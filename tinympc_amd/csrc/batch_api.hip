@@ -40,7 +40,7 @@ __global__ void unpack_kpi_kernel(const double* __restrict__ kpi, double* __rest
 // Many fields in ONE launch (the drop-in path moves 9-20 workspace fields per solve: one launch each way instead of one per field).
 // blockIdx.y = entry; an entry is a KPI field (rows x cols per instance at row_off) or, kpi == nullptr, a raw copy of `count` doubles.
 struct XferEntry { double* kpi; double* raw; long off; long count; int rows, row_off, cols; };
-struct XferTable { XferEntry e[24]; int n; };
+struct XferTable { XferEntry e[40]; int n; };
 __global__ void xfer_fields_kernel(const XferTable t, double* __restrict__ buf, int batch, int N, int nz, int to_device) {
     const XferEntry en = t.e[blockIdx.y];
     double* x = buf + en.off;
@@ -1374,7 +1374,7 @@ namespace tinympc_amd {
 // with_status (download only): status int4 [batch] and the residuals [batch][4] follow at off_status / off_resid
 int xfer_fields(TinyBatch* b, const TinyField* fields, const size_t* offsets, int n, double* d_buf, bool to_device,
                 bool with_status, size_t off_status, size_t off_resid) {
-    if (n + (with_status ? 2 : 0) > 24) return fail(b, TINY_ERR_ARG, "too many fields in one transfer");
+    if (n + (with_status ? 2 : 0) > 40) return fail(b, TINY_ERR_ARG, "too many fields in one transfer");
     HIP_TRY(b, hipSetDevice(b->device));
     XferTable t;
     t.n = 0;

@@ -44,6 +44,22 @@ for mode in ("driver", "default", "step"):
     b = os.path.join(OUT, "prof", f"rocprof_{mode}_bench.json")
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(DST, f"{TAG}_{mode}_bench_under_rocprof.json"))
+# SQ counters of the fused launches: per-launch averages
+f = find("prof", "prof_default_sq/**/*counter_collection.csv")
+if f:
+    acc, n = {}, {}
+    for r in csv.DictReader(open(f)):
+        if "admm_solve_kernel" in r.get("Kernel_Name", ""):
+            k = r["Counter_Name"]
+            acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+            n[k] = n.get(k, 0) + 1
+    if acc:
+        avg = {k: acc[k] / n[k] for k in acc}
+        if avg.get("SQ_WAVE_CYCLES"):
+            avg["valu_insts_per_wave_cycle"] = avg.get("SQ_INSTS_VALU", 0.0) / avg["SQ_WAVE_CYCLES"]
+        json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES around `python bench.py` "
+                             "(100 MPC steps fused per launch), per launch of admm_solve_kernel<12,4,10>", "per_launch": avg},
+                  open(os.path.join(DST, f"{TAG}_sq_counters.json"), "w"), indent=1)
 traffic = {}
 for mode, key, what in (("step", "per_step_launch", "one launch per MPC step, the 100-step episode from cold"),
                         ("default", "fused_launch", "100 MPC steps fused per launch"),

@@ -38,6 +38,8 @@ for stage in "$@"; do
         timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_${mode}_fetch -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_fetch.err
         timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_${mode}_write -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_write.err
       done
+      # SQ counters of the fused launches (issue utilisation of the headline kernel): their own pass, kernel-trace only
+      timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $R/$O/prof_default_sq -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 > /dev/null 2> $R/$O/rocprof_default_sq.err
       cd $R; find $O -name "*kernel_stats.csv" | head ;;
     configs)
       timeout 900 python tools/config_bench.py $O/configs_3_4.json > $O/configs.out 2> $O/configs.err; tail -c 800 $O/configs.out ;;
