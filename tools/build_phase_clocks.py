@@ -36,7 +36,7 @@ rep("                double4 rr = make_double4(ps, pi, ds, di);",
 open(p, "w").write(s)
 flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-but-set-variable -Wno-unused-variable".split()
 subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", TMP + "/_gen/k_12_4_10.hip", "-o", TMP + "/k_clk.o"])
-objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != "k_12_4_10.o"]
+objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != "k_12_4_10.o" and "_chk" not in f]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-Wl,-Bsymbolic", "-o",
-                       os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_clk.so"), *objs, TMP + "/k_clk.o"])
+                       os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_clk.so"), *objs, TMP + "/k_clk.o", "-ldl"])
 print("built libtinympc_amd_clk.so")
