@@ -230,9 +230,9 @@ def main():
     fl = flops_per_iter(nx, nu, N)
     bytes_warm = s.algorithmic_bytes(cold=False)
     if rank == 0 and not args.no_regimes:
-        def replay(lean):
+        def replay(store_primal):
             runs = []
-            s.set_option("store_primal", 0 if lean else 1)
+            s.set_option("store_primal", store_primal)
             for _ in range(5):
                 cold_start()
                 s.set_option("timing", 100)
@@ -244,13 +244,15 @@ def main():
             return np.median(np.array(runs), axis=0)
         with torch.cuda.stream(stream):
             s.set_option("steps_per_launch", 1)
-            ms = replay(False)
-            ms_lean = replay(True)
+            ms = replay(1)
+            ms_lean = replay(0)
+            ms_u0 = replay(2)
             s.set_option("steps_per_launch", T)
         S = nx * N + nu * (N - 1)
         cold = float(ms[:5].mean()) * 1e-3
         warm = float(ms[70:].mean()) * 1e-3
         lean = float(ms_lean[70:].mean()) * 1e-3
+        first = float(ms_u0[70:].mean()) * 1e-3
         regimes = {
             "cold": {"steps": "0-4", "admm_iters_per_solve": 100, "ms_per_launch": cold * 1e3,
                      "fp64_tflops": 100 * B * fl / cold / 1e12, "fp64_frac": 100 * B * fl / cold / 1e12 / FP64_PEAK_TFLOPS},
@@ -263,6 +265,8 @@ def main():
             "steady_state_lean": {"steps": "70-99", "ms_per_launch": lean * 1e3, "ms_per_launch_min": float(ms_lean[70:].min()),
                                   "hbm_gbs": bytes_warm * B / lean / 1e9, "hbm_frac": bytes_warm * B / lean / 1e9 / HBM_PEAK_GBS,
                                   "bytes_moved_per_solve_max": bytes_warm - 8 * S,
+                                  "first_knot_only": {"ms_per_launch": first * 1e3, "hbm_frac": bytes_warm * B / first / 1e9 / HBM_PEAK_GBS,
+                                                      "note": "store_primal = 2: x[:,0], x[:,1], u[:,0] are still written (the control a caller applies)"},
                                   "note": "option store_primal = 0: x|u is not written back either (no consumer between steps: the "
                                           "plant step runs on the device, solution->x|u = vnew|znew is still stored); the figure is "
                                           "still bytes_warm / launch time, i.e. solves/s in the formula's units"}}

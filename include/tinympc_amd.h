@@ -218,7 +218,8 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * "repack_waves_per_cu" (default 8) tune the stage schedule and the grid of the follow-up launches),
  * "store_primal" (default 1; 0: launches do not write work->x|u back -- between closed-loop steps with "advance_x0" it has
  * no consumer, the plant step and solution->x|u = vnew|znew are still written; tiny_batch_get(TINY_F_X / TINY_F_U) then
- * returns stale data.  Ignored while a cone / half-space family is enabled, whose slack the next solve initialises from x|u).
+ * returns stale data; 2: only the first knot is written -- x[:,0], x[:,1] and u[:,0], the control a closed-loop caller applies.
+ * Ignored while a cone / half-space family is enabled, whose slack the next solve initialises from x|u).
  * "share_ref" (default 1: when Xref and Uref were set with TINY_BROADCAST -- or never -- every instance reads ONE reference
  * record instead of its own copy; 0 switches that off).
  * A solve that converges at its first termination check never stores v|z: the reference returns before v = vnew. */

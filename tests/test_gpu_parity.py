@@ -276,7 +276,7 @@ def test_fused_closed_loop_steps(T):
     # the byte-saving launch forms: no x|u write-back ("store_primal" = 0), per-instance reference records instead of the
     # shared one ("share_ref" = 0) and the v|z store that first-check convergence skips -- everything a later solve or the
     # caller can see (slack, duals, v|z, plant state, statistics) must stay bit-identical, one launch per step
-    for opts in (dict(store_primal=0), dict(share_ref=0), dict(store_primal=0, share_ref=0)):
+    for opts in (dict(store_primal=0), dict(share_ref=0), dict(store_primal=0, share_ref=0), dict(store_primal=2)):
         c = make_batch(suite, batch=B)
         c.set_option("advance_x0", 1)
         for k, v in opts.items():
@@ -286,7 +286,11 @@ def test_fused_closed_loop_steps(T):
         for _ in range(100):
             c.solve_async()
         for k in fa:
-            if k in ("x", "u") and not opts.get("store_primal", 1):
+            if k in ("x", "u") and opts.get("store_primal", 1) == 0:
+                continue
+            if k in ("x", "u") and opts.get("store_primal", 1) == 2:           # first knot only: x_0, x_1, u_0
+                n_first = 2 if k == "x" else 1
+                assert np.array_equal(c.get(k)[:, :, :n_first], fa[k][:, :, :n_first]), (opts, k)
                 continue
             assert np.array_equal(c.get(k), fa[k]), (opts, k)
         sc_ = c.reduce_stats()

@@ -118,7 +118,8 @@ struct SolveArgs {
     int n_lin, n_tlin;
     // One-shot solves (SURVEY.md 8(d) bytes_cold): 1 = the warm-start state is taken as zero (the state after
     // tiny_setup / a reset) without being read.  store_mask: which records the launch writes back -- bit 0 x|u,
-    // bit 1 vnew|znew (= solution->x|u), bit 2 g|y, bit 3 v|z, bit 4 the cone / linear slack and dual records.
+    // bit 1 vnew|znew (= solution->x|u), bit 2 g|y, bit 3 v|z, bit 4 the cone / linear slack and dual records, bit 5 (without bit 0) only the first
+    // knot of x|u.
     int cold, store_mask;
     // Resumed solves (batch_api.hip "repack_after"): an earlier launch capped at iter_base iterations has stored the ADMM
     // state of the instances that did not converge; index[0 .. *count) lists them and this launch carries on from
@@ -1069,7 +1070,8 @@ void admm_solve_kernel(const SolveArgs P) {
                 const size_t off = lbase + s * NZ;
                 if (valid) {
                     // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
-                    if ((P.store_mask & 1) && (acc_iter > 0 || (s == 0 && is_state))) P.prim[off] = X[s];
+                    // bit 0: the whole x|u trajectory; bit 5: only its first knot (x_0, x_1, u_0: what a closed-loop caller applies)
+                    if (((P.store_mask & 1) || ((P.store_mask & 32) && s <= 1)) && (acc_iter > 0 || (s == 0 && is_state))) P.prim[off] = X[s];
                     if (P.store_mask & 2) P.slack[off] = VN[s];
                     if (P.store_mask & 4) P.dual[off] = G[s];
                     if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];   // admm.cpp:431-441 returns before v = vnew

@@ -836,7 +836,7 @@ int launch_solve(TinyBatch* b) {
     a.store_mask = b->one_shot == 2 ? 1 : (b->one_shot == 1 ? 3 : 31);
     // "store_primal" = 0: work->x|u is not written back.  A cone / half-space slack is initialised from it by the next
     // solve (admm.cpp:352-374) and the debug outputs belong to it, so those launches keep the store.
-    if (!b->store_primal && !b->one_shot && !soc && !lin_variant(b) && !b->debug) a.store_mask &= ~1;
+    if (b->store_primal != 1 && !b->one_shot && !soc && !lin_variant(b) && !b->debug) a.store_mask = (a.store_mask & ~1) | (b->store_primal == 2 ? 32 : 0);
     if (steps > 1 && b->step_log) {
         if (int rc = ensure_step_logs(b, steps)) return rc;
         a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
@@ -1613,7 +1613,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
-    else if (!strcmp(name, "store_primal")) b->store_primal = value != 0;
+    else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }

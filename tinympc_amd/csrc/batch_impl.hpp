@@ -98,7 +98,7 @@ struct TinyBatch {
     bool bounds_uniform = false;                   // build_tables: every knot has the same box (admm_kernel.hip.h UB variant)
     bool xref_shared = true, uref_shared = true;   // the Xref / Uref records of all instances are identical (broadcast, or still zero)
     bool share_ref = true;                         // option "share_ref": let launches exploit that
-    bool store_primal = true;            // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)
+    int store_primal = 1;                // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)
     int one_shot = 0;                    // 1: cold state assumed, x|u + vnew|znew written; 2: x|u only (bytes_cold of SURVEY.md 8(d))
     double* d_traj = nullptr;
     // heterogeneous problem families: per-instance problem data, caches and lane tables (device)
