@@ -532,6 +532,10 @@ constexpr int soc_item_passes(int nx, int nu, int n) { return ((nx / 3) * n + (n
 
 // a + d * b with the product rounded before the sum, as the reference's x86-64 build (no FMA contraction) evaluates
 // `Kinf + delta_rho * dKinf_drho` (rho_benchmark.cpp:201-204)
+// C1 and C2 are state the iteration never reads (backward_pass_grad works with Quu_inv / AmBKt, admm.cpp:63-77): their Taylor
+// steps are logged and applied ADAPT_LOG at a time, in the reference's order (same roundings), instead of one read-modify-write
+// of 2 x (nx^2 + nu^2) doubles of HBM per adaptation.
+constexpr int ADAPT_LOG = 32;
 __device__ __forceinline__ double taylor_step(double a, double d, double b) {
 #pragma clang fp contract(off)
     const double t = d * b;
@@ -545,7 +549,11 @@ __device__ __forceinline__ double taylor_step(double a, double d, double b) {
 // stream -- storing both at slot i+1 needs no per-lane select.
 // Register budget: 6 N-long FP64 arrays per lane (+2 with a cone) + the matrix rows.  N <= 12 fits the
 // 256-VGPR budget of two waves per SIMD; longer horizons take the whole 512-entry file (one wave per SIMD).
-constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
+// Half-space variants (LIN) take one wave; the adaptive-rho variant keeps two up to N = 10 (its adaptation block, every 5th
+// iteration, works out of LDS and spills only on the rare flush_c path).
+constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc, bool lin = false, bool adapt = false) {
+    if (lin) return 1;
+    if (adapt) return n <= 10 ? 2 : 1;
     return (n <= 10 || 2 * ((soc ? 8 : 6) * n + 2 * nz + 8) + 40 <= 256) ? 2 : 1;
 }
 
@@ -556,7 +564,7 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc) {
 // registers instead of being read from LDS slot by slot -- 18 LDS reads and as many waits less per iteration at N = 10
 template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu((LIN || ADAPT) ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC), (LIN || ADAPT) ? 1 : solve_kernel_waves_per_simd(NX + NU, N, SOC))))
+__attribute__((amdgpu_waves_per_eu(solve_kernel_waves_per_simd(NX + NU, N, SOC, LIN != 0, ADAPT), solve_kernel_waves_per_simd(NX + NU, N, SOC, LIN != 0, ADAPT))))
 void admm_solve_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
@@ -582,6 +590,16 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sT[SOC ? 4 * N * 16 : 1];               // SOC: x + gc of every slot, transposed through LDS for the cone step
 #endif
     __shared__ double sP[ADAPT ? 4 * NX * NX : 1];            // ADAPT: each row's own Pinf, column-major (lane j keeps column j current)
+    // ADAPT: the lane tables every adaptation reads (ATAB_AT, ATAB_DK, ATAB_DP), lane-major [table][lane][AKC] so that a lane's
+    // coefficients are consecutive (ds_read_b128), and each row's log of rho steps that C1 / C2 still have to take (flush_c)
+    constexpr int AKC = NX > NU ? NX : NU;
+    __shared__ double sTab[ADAPT ? 3 * 16 * AKC : 1];
+    __shared__ double sDl[ADAPT ? 4 * ADAPT_LOG : 1];
+    if constexpr (ADAPT)
+        for (int e = lane; e < 3 * 16 * AKC; e += 64) {
+            const int t = e / (16 * AKC), r = e % (16 * AKC);
+            sTab[e] = P.atab[t * 256 + (r % AKC) * 16 + r / AKC];              // ATAB_AT / ATAB_DK / ATAB_DP = 0 / 256 / 512
+        }
     if constexpr (LS) for (int e = lane; e < 3 * KMAX * 16; e += 64) sLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + e];
     if constexpr (LT) for (int e = lane; e < 3 * N * KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * KMAX * 16 + e];
     for (int e = lane; e < NX * 16; e += 64) sPt[e] = P.tab[TAB_PT + e];
@@ -730,6 +748,37 @@ void admm_solve_kernel(const SolveArgs P) {
                 const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
                 QX[N - 1] = is_state ? -xp : QX[N - 1];
+            };
+            int ndl = 0;                                       // ADAPT: rho steps logged in sDl and not yet taken by C1 / C2
+            auto flush_c = [&](int n) {                        // update_matrices_with_derivatives, rho_benchmark.cpp:196-210 (C1, C2)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (P.aC2 && is_state) {
+                    double* c2 = P.aC2 + (size_t)b * (NX * NX) + NX * j;
+                    double v[NX], d[NX];
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) { v[k] = c2[k]; d[k] = P.atab[ATAB_DC2 + k * 16 + j]; }
+                    for (int i = 0; i < n; ++i) {
+                        const double dl = sDl[grp * ADAPT_LOG + i];
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) v[k] = taylor_step(v[k], dl, d[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) c2[k] = v[k];
+                }
+                if (P.aC1 && j < NU) {
+                    double* c1 = P.aC1 + (size_t)b * (NU * NU) + NU * j;
+                    double v[NU], d[NU];
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) { v[k] = c1[k]; d[k] = P.atab[ATAB_DC1 + k * 16 + j]; }
+                    for (int i = 0; i < n; ++i) {
+                        const double dl = sDl[grp * ADAPT_LOG + i];
+#pragma unroll
+                        for (int k = 0; k < NU; ++k) v[k] = taylor_step(v[k], dl, d[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NU; ++k) c1[k] = v[k];
+                }
             };
             if (!P.traj) terminal_term();
             const int traj_k0 = P.traj ? (P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0)) : 0;
@@ -954,7 +1003,7 @@ void admm_solve_kernel(const SolveArgs P) {
                         if (it > 0 && it % 5 == 0) {
                             double at[NX];
 #pragma unroll
-                            for (int k = 0; k < NX; ++k) at[k] = P.atab[ATAB_AT + k * 16 + j];
+                            for (int k = 0; k < NX; ++k) at[k] = sTab[j * AKC + k];
                             double pri_res = 0.0, ax_max = 0.0, z_max = 0.0, dual_res = 0.0, px_max = 0.0, aty_max = 0.0, q_max = 0.0;
                             double pxq_max = 0.0;              // max |Q x_i|, |R u_i| over the knots before the last: entries of P x AND of q
 #pragma unroll
@@ -1004,29 +1053,19 @@ void admm_solve_kernel(const SolveArgs P) {
                             const double delta = new_rho - rho;
                             if (is_state) {
 #pragma unroll
-                                for (int k = 0; k < NU; ++k) mb[NX + k] = -taylor_step(-mb[NX + k], delta, P.atab[ATAB_DK + k * 16 + j]);
+                                for (int k = 0; k < NU; ++k) mb[NX + k] = -taylor_step(-mb[NX + k], delta, sTab[(16 + j) * AKC + k]);
 #pragma unroll
                                 for (int k = 0; k < NX; ++k) {
                                     const int e = grp * NX * NX + k + NX * j;
-                                    sP[e] = taylor_step(sP[e], delta, P.atab[ATAB_DP + k * 16 + j]);
-                                }
-                                if (P.aC2) {
-#pragma unroll
-                                    for (int k = 0; k < NX; ++k) {
-                                        double* c2 = P.aC2 + (size_t)b * (NX * NX) + k + NX * j;
-                                        *c2 = taylor_step(*c2, delta, P.atab[ATAB_DC2 + k * 16 + j]);
-                                    }
+                                    sP[e] = taylor_step(sP[e], delta, sTab[(32 + j) * AKC + k]);
                                 }
                             } else if (is_input) {
 #pragma unroll
-                                for (int k = 0; k < NX; ++k) mf1[k] = -taylor_step(-mf1[k], delta, P.atab[ATAB_DK + k * 16 + j]);
+                                for (int k = 0; k < NX; ++k) mf1[k] = -taylor_step(-mf1[k], delta, sTab[(16 + j) * AKC + k]);
                             }
-                            if (P.aC1 && j < NU) {
-#pragma unroll
-                                for (int k = 0; k < NU; ++k) {
-                                    double* c1 = P.aC1 + (size_t)b * (NU * NU) + k + NU * j;
-                                    *c1 = taylor_step(*c1, delta, P.atab[ATAB_DC1 + k * 16 + j]);
-                                }
+                            if (P.aC1 || P.aC2) {                                           // C1 / C2: logged, applied by flush_c
+                                if (j == 0) sDl[grp * ADAPT_LOG + ndl] = delta;
+                                if (++ndl == ADAPT_LOG) { flush_c(ndl); ndl = 0; }
                             }
                             rho = new_rho;
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1090,6 +1129,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
             }
             if constexpr (ADAPT) {
+                if (ndl > 0) flush_c(ndl);
                 if (j == 0) P.arho[b] = rho;
                 if (is_state) {
 #pragma unroll
