@@ -46,7 +46,8 @@ for stage in "$@"; do
     sweep)
       timeout 900 python tools/sweep_bench.py --reps 5 --out $O/sweep_config5.json > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md ;;
     adaptive)
-      timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt ;;
+      timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt
+      timeout 300 python tools/adaptive_bench.py > $O/adaptive_bench_run.txt 2>&1; tail -2 $O/adaptive_bench_run.txt ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
