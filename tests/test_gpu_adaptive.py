@@ -74,6 +74,21 @@ def test_per_instance_rho_paths_in_one_batch_match_the_oracle(clip):
             assert rel_err(out[k][b], ref[k][b]) < 1e-9, (k, b)
 
 
+def test_long_solves_take_more_rho_steps_than_the_c1_c2_log_holds():
+    """C1 / C2 take their Taylor steps lazily, 32 logged rho steps at a time (flush_c in admm_kernel.hip.h): tolerances nobody
+    meets keep every instance iterating to max_iter = 300 -> 59 adaptations, one flush inside the loop and one at the end; the
+    cache must come out as the oracle's one-step-at-a-time updates leave it."""
+    suite = sc.tracking_adaptive_suite(B=37, seed=4242, rho_min=0.7, rho_max=30.0, clip=1, max_iter=300)
+    suite["config"] = dict(suite["config"], abs_pri_tol=0.0, abs_dua_tol=0.0)     # (residual < 0 never holds)
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite)
+    assert np.all(ref["iter"].astype(int) == 300) and np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    assert np.allclose(out["rho"], ref["rho"], rtol=1e-9, atol=0.0)
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "Kinf", "Pinf", "C1", "C2"):
+        for b in range(out[k].shape[0]):
+            assert rel_err(out[k][b], ref[k][b]) < 1e-9, (k, b)
+
+
 def test_reset_restores_the_setup_cache_and_off_means_off():
     suite = sc.tracking_adaptive_suite(B=12, seed=31)
     first = run_cases_hip(suite)
