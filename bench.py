@@ -128,11 +128,20 @@ def main():
 
     if not torch.cuda.is_available() or tm.device_count() == 0:
         sys.exit("bench.py needs an MI355X: tinympc_amd has no CPU fallback")
+    # TINYMPC_BENCH_SHARE_GPU=1: smoke test of the N > 1 control flow on a box with fewer GPUs than ranks -- the ranks share
+    # the devices round-robin and talk over gloo (RCCL refuses two ranks on one device); the line it prints is not a measurement
+    share_gpu = bool(os.environ.get("TINYMPC_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("TINYMPC_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        if share_gpu:
+            os.environ["TINYMPC_EXCHANGE"] = "torch"
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
     prob, extra = tm.load_problem("quadrotor_20hz")
     h = extra["hover"]
@@ -317,6 +326,8 @@ def main():
             "kernel_ms": {"first_launch_median": float(np.median(kern_first)), "sum_per_repetition_median": kern_sum_rep,
                           "min": float(kern_ms.min()), "max": float(kern_ms.max()), "count": int(kern_ms.size)},
         }
+        if share_gpu:
+            out["data"] = "synthetic; SMOKE RUN: %d ranks share %d GPU(s) over gloo -- not a measurement" % (world, torch.cuda.device_count())
         if regimes is not None:
             out["regimes"] = regimes
         if cpu is not None:

@@ -48,3 +48,27 @@ def test_sharded_batch_equals_unsharded(world, interleaved):
         table.append(st[list(WIRE_IDX)])
     total = reduce_table(np.array(table), B).numpy()
     assert np.array_equal(total, full_stats), (total, full_stats)
+
+
+def test_bench_control_flow_with_two_ranks_on_this_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank) with both ranks on this
+    box's GPU over gloo (TINYMPC_BENCH_SHARE_GPU: RCCL refuses two ranks on one device): barriers, the max over ranks, the
+    statistics exchange (its torch.distributed form) and rank 0's one JSON line -- whole-job counts, not rank 0's."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, TINYMPC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--no-regimes", "--min-seconds", "0.05", "--batch", "8192"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 speaks for the job
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and "SMOKE RUN" in d["data"]
+    assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9               # 691 iterations over the first 20 steps, on BOTH ranks' instances
+    assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["stats_exchange"] == "torch.distributed"
+    assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]
