@@ -72,3 +72,28 @@ def test_bench_control_flow_with_two_ranks_on_this_gpu():
     assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9               # 691 iterations over the first 20 steps, on BOTH ranks' instances
     assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["stats_exchange"] == "torch.distributed"
     assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_sharded_sweep_driver_counts_what_the_single_process_counts(tmp_path):
+    """tools/sweep_bench.py (BASELINE configs[4]) under torch.distributed.run with two ranks sharing this GPU: the cell's
+    batch is dealt round-robin to the ranks, every rank draws the same seeded inputs and keeps its own instances -- the
+    job-wide iteration count and solved fraction must be the single-process ones."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tool = os.path.join(ROOT, "tools", "sweep_bench.py")
+    common = ["--batch", "4099", "--cells", "12,4,10;20,4,10", "--reps", "0"]
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    p = subprocess.run([sys.executable, tool, *common, "--out", one], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    env = dict(os.environ, TINYMPC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), tool, *common, "--out", two], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    a, b = json.load(open(one)), json.load(open(two))
+    assert [r["kernel"] for r in a] == ["regs", "tile"] and [r["n_gpus"] for r in b] == [2, 2]
+    for ra, rb in zip(a, b):
+        assert ra["iters_per_solve"] == rb["iters_per_solve"] and ra["solved_fraction"] == rb["solved_fraction"], (ra, rb)

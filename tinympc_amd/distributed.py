@@ -134,3 +134,23 @@ class StatsExchange:
             import tinympc_amd as tm
             tm.rccl_comm_destroy(self.comm)
             self.comm = None
+
+
+def init_process_group(local_rank):
+    """One rank per GPU over RCCL ("nccl" is RCCL on ROCm).  Returns (torch.distributed, device index of this rank).
+    TINYMPC_BENCH_SHARE_GPU=1 is the smoke mode of the drivers: the ranks share this box's devices round-robin and talk over
+    gloo (RCCL refuses two ranks on one device), the statistics exchange takes its torch.distributed form."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("TINYMPC_BENCH_SHARE_GPU"):
+        device = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(device)
+        os.environ["TINYMPC_EXCHANGE"] = "torch"
+        dist.init_process_group("gloo")
+    else:
+        device = local_rank
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    return dist, device

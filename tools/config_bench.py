@@ -38,12 +38,9 @@ def dist_init():
     """one process per GPU under torch.distributed.run; a no-op for a plain `python tools/config_bench.py`"""
     global _dist
     if WORLD > 1 or os.environ.get("TINYMPC_FORCE_DIST"):
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(LOCAL_RANK)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", LOCAL_RANK))
-        _dist = dist
+        from tinympc_amd.distributed import init_process_group
+        global LOCAL_RANK
+        _dist, LOCAL_RANK = init_process_group(LOCAL_RANK)        # (LOCAL_RANK becomes the device index: smoke mode shares GPUs)
     return _dist
 
 

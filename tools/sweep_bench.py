@@ -120,14 +120,10 @@ def main():
     ap.add_argument("--cells", default="")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
-    global _dist
+    global _dist, LOCAL_RANK
     if WORLD > 1 or os.environ.get("TINYMPC_FORCE_DIST"):
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(LOCAL_RANK)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", LOCAL_RANK))
-        _dist = dist
+        from tinympc_amd.distributed import init_process_group
+        _dist, LOCAL_RANK = init_process_group(LOCAL_RANK)        # (LOCAL_RANK becomes the device index: smoke mode shares GPUs)
     say = print if RANK == 0 else (lambda *a, **k: None)
     cells = ([tuple(int(v) for v in c.split(",")) for c in args.cells.split(";")] if args.cells else
              [(nx, nu, N) for nx in (4, 8, 12, 20) for nu in (2, 4, 8) for N in (10, 30, 50)])
