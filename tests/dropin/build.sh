@@ -19,6 +19,12 @@ for ex in $EXAMPLES; do
   g++ $CXXFLAGS $INC -o "$OUT/$ex" "$REF/examples/$ex.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
       -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
 done
+# the reference's two code-generation examples (examples/codegen_random.cpp, codegen_cartpole.cpp): tiny_codegen of a
+# TinySolver built with real Eigen types; what they generate is checked by tests/test_gpu_dropin.py
+for ex in codegen_random codegen_cartpole; do
+  g++ $CXXFLAGS $INC -o "$OUT/$ex" "$REF/examples/$ex.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
+      -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
+done
 # our own caller of the exported phase functions (admm.hpp:12-34), real Eigen types across the boundary
 g++ $CXXFLAGS $INC -o "$OUT/phase_driver" "$HERE/phase_driver.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
     -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
