@@ -9,6 +9,7 @@
 #   configs      tools/config_bench.py (configs 3, 4, linear examples)
 #   sweep        tools/sweep_bench.py (config 5)
 #   adaptive     the adaptive-rho parity tests + a timing of the adaptive kernel variant
+#   counters     rocprofv3 SQ / HBM counters of the sweep and cone kernels -> kernel_counters.md
 #   exp          whatever tools/gpu_experiment.sh holds (kernel experiments of the moment)
 set +e
 export TMPDIR=/tmp
@@ -48,6 +49,17 @@ for stage in "$@"; do
     adaptive)
       timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt
       timeout 300 python tools/adaptive_bench.py > $O/adaptive_bench_run.txt 2>&1; tail -2 $O/adaptive_bench_run.txt ;;
+    counters)
+      # SQ / HBM counters of the kernels behind the other BASELINE configs (sweep cells on the one-row and tile kernels, the cone
+      # kernel of config 4): one rocprofv3 pass per counter set, kernel trace only
+      CELLS="12,4,10;4,2,10;12,4,30;4,2,30;12,4,50;4,2,50;20,8,10;20,8,50"
+      cd /tmp
+      for pass in "trace:" "sq:--pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "fetch:--pmc FETCH_SIZE" "write:--pmc WRITE_SIZE"; do
+        name=${pass%%:*}; pmc=${pass#*:}
+        timeout 600 rocprofv3 --kernel-trace $pmc --output-format csv -d $R/$O/$name -o sweep -- python $R/tools/sweep_bench.py --batch 65536 --reps 0 --cells "$CELLS" > $R/$O/${name}_sweep.out 2> $R/$O/${name}_sweep.err
+        timeout 600 rocprofv3 --kernel-trace $pmc --output-format csv -d $R/$O/$name -o cfg4 -- python $R/tools/config_bench.py /dev/null config4 > $R/$O/${name}_cfg4.out 2> $R/$O/${name}_cfg4.err
+      done
+      cd $R; python tools/kernel_counters.py $O > $O/kernel_counters.md; cat $O/kernel_counters.md ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
