@@ -33,7 +33,8 @@ copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", 
           ("bench", "bench_per_step.json", "bench_per_step.json"), ("bench", "bench_torchrun1.json", "bench_torchrun1.json"),
           ("configs", "configs_3_4.json", "configs_3_4.json"), ("sweep", "sweep_config5.json", "sweep_config5.json"),
           ("sweep", "sweep_config5.md", "sweep_config5.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt"),
-          ("adaptive", "adaptive_bench_run.txt", "adaptive_bench_run.txt")]
+          ("adaptive", "adaptive_bench_run.txt", "adaptive_bench_run.txt"),
+          ("counters", "kernel_counters.md", "kernel_counters_table.md")]      # (rNN_kernel_counters.md = this table + its reading)
 for stage, name, dst in copies:
     src = os.path.join(OUT, stage, name)
     if os.path.exists(src):
