@@ -569,11 +569,7 @@ void admm_solve_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
-#ifdef TINYMPC_SOC_PER_KNOT
-    constexpr bool FUSED = MODE == 2 && !SOC && LIN == 0 && fused_shape(NX, NU);
-#else
     constexpr bool FUSED = MODE == 2 && LIN == 0 && fused_shape(NX, NU);              // fused_backward_step(_soc) / fused_forward_step
-#endif
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
     const int grp = lane >> 4;
@@ -586,9 +582,7 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sHi[N * 16];
     __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
     __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
-#ifndef TINYMPC_SOC_PER_KNOT
     __shared__ double sT[SOC ? 4 * N * 16 : 1];               // SOC: x + gc of every slot, transposed through LDS for the cone step
-#endif
     __shared__ double sP[ADAPT ? 4 * NX * NX : 1];            // ADAPT: each row's own Pinf, column-major (lane j keeps column j current)
     // ADAPT: the lane tables every adaptation reads (ATAB_AT, ATAB_DK, ATAB_DP), lane-major [table][lane][AKC] so that a lane's
     // coefficients are consecutive (ds_read_b128), and each row's log of rho steps that C1 / C2 still have to take (flush_c)
@@ -622,17 +616,14 @@ void admm_solve_kernel(const SolveArgs P) {
     const double nim = P.tab[TAB_VEC + VEC_NIM * 16 + j];
     bool soc_lane = false, proj_lane = false;
     int cone_base = -1, cone_c = 0;
-    float cone_mu = 0.0f;
     double socmask = 0.0;
     if constexpr (SOC) {
         socmask = P.tab[TAB_VEC + VEC_SOCFLAG * 16 + j];               // 1.0 on the rows that carry a cone slack
         soc_lane = socmask != 0.0;
         cone_base = (int)P.tab[TAB_VEC + VEC_CONE_BASE * 16 + j];
-        cone_mu = (float)P.tab[TAB_VEC + VEC_CONE_MU * 16 + j];        // admm.cpp:39 takes mu as float
         cone_c = (cone_base >= 0) ? (j - cone_base) : 0;
         proj_lane = soc_lane && cone_base >= 0;
     }
-#ifndef TINYMPC_SOC_PER_KNOT
     // Transposed cone step: the (cone, knot) pairs of a row are dealt out to its lanes, 16 per pass -- lane j of pass p takes
     // item 16 p + j, counted cone by cone (ascending base lane): a state cone has N items (slots 0..N-1), an input cone N-1
     // (slots 1..N-1).  All four rows of a wave share the layout.
@@ -656,7 +647,6 @@ void admm_solve_kernel(const SolveArgs P) {
             }
         }
     }
-#endif
     bool lin_lane = false, tlin_lane = false;
     if constexpr (LS) lin_lane = P.tab[TAB_VEC + VEC_LINFLAG * 16 + j] != 0.0;
     if constexpr (LT) tlin_lane = P.tab[TAB_VEC + VEC_TLINFLAG * 16 + j] != 0.0;
@@ -892,18 +882,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             // vcnew = x + gc on every row of a family whose cone slack is on (:102-109); GC is 0 on the
                             // other rows, so one FMA against the 0/1 mask does the add and the select
                             const double tc = fma(xi, socmask, GC[s]);
-#ifndef TINYMPC_SOC_PER_KNOT
-                            sT[(grp * N + s) * 16 + j] = tc;       // projected after the sweep, one lane per (cone, knot): cone_step()
-#else
-                            const int base = (cone_base >= 0) ? cone_base : j;
-                            const double s0 = __shfl(tc, base, 16);
-                            const double s1 = __shfl(tc, base + 1, 16);
-                            const double s2 = __shfl(tc, base + 2, 16);
-                            double vc = tc;
-                            if (proj_lane && (is_state || s >= 1)) vc = soc_component(s0, s1, s2, tc, cone_c, cone_mu);   // :112-135
-                            GC[s] = tc - vc;                                        // :229 / :234  (gc + x) - vcnew
-                            VC[s] = vc;
-#endif
+                            sT[(grp * N + s) * 16 + j] = tc;       // projected after the sweep, one lane per (cone, knot): the cone step below
                         }
                         // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over
                         // the row with the broadcast-FMA chain (against a vector of ones), separately for the state
@@ -965,7 +944,6 @@ void admm_solve_kernel(const SolveArgs P) {
                         lo_c = lo_n; hi_c = hi_n;
                     }
                     slot_update(N - 1, lo_c, hi_c);
-#ifndef TINYMPC_SOC_PER_KNOT
                     if constexpr (SOC) {
                         // ---- cone step (admm.cpp:112-135, 228-235), transposed: x + gc of every slot went to LDS above; lane j
                         // of pass p gathers the three components of its (cone, knot) item, projects them -- ONE square root /
@@ -992,7 +970,6 @@ void admm_solve_kernel(const SolveArgs P) {
                             VC[s] = vc;
                         }
                     }
-#endif
                     iter += 1;                                                      // :394
                     if constexpr (ADAPT) {
                         // ---- adaptive rho, admm.cpp:397-423: every 5th pass of the loop index (after iterations 6, 11, ...).

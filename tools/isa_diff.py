@@ -22,6 +22,7 @@ def assemble(srcdir, dims, out):
     os.makedirs(gen, exist_ok=True)
     name = "k_%d_%d_%d" % dims
     with open(os.path.join(gen, name + ".hip"), "w") as f:
+        f.write("#define TINYMPC_FUSED_NX %d\n#define TINYMPC_FUSED_NU %d\n" % dims[:2])      # as csrc/Makefile writes the unit
         f.write('#include "../kernel_entry.hpp"\n')
         f.write("namespace tinympc_amd { extern const KernelEntry kentry_%d_%d_%d = KERNELS_FOR(%d, %d, %d); }\n" % (dims + dims))
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", name + ".hip", "-o", out],
