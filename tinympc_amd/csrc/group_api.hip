@@ -38,11 +38,8 @@ struct Rccl {
     std::string why;
 };
 
-Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.so ? &r : nullptr;
-    tried = true;
+Rccl load_rccl() {
+    Rccl r;
     // RCCL must sit on the SAME HIP / HSA runtime this library is bound to.  A process can hold two ROCm stacks -- the
     // system's under /opt/rocm and the one PyTorch-ROCm bundles in torch/lib, whichever got loaded first serves the HIP
     // calls of this library -- and an RCCL from the other stack finds its own, uninitialised HSA runtime ("no ROCm-capable
@@ -65,7 +62,11 @@ Rccl* rccl() {
             r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.so) break;
         }
-    if (!r.so) { r.why = dlerror() ? dlerror() : "librccl.so not found"; return nullptr; }
+    if (!r.so) {
+        const char* e = dlerror();                   // (reading it clears it: once)
+        r.why = e ? e : "librccl.so not found";
+        return r;
+    }
     auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p) r.why = std::string("missing symbol ") + n; return p; };
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
@@ -78,10 +79,16 @@ Rccl* rccl() {
     if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
         dlclose(r.so);
         r.so = nullptr;
-        return nullptr;
     }
-    return &r;
+    return r;
 }
+
+Rccl& rccl_state() {
+    static Rccl r = load_rccl();                     // initialised once, also when several rank threads arrive together
+    return r;
+}
+Rccl* rccl() { return rccl_state().so ? &rccl_state() : nullptr; }
+const char* rccl_why() { return rccl_state().why.c_str(); }     // why rccl() is null
 
 enum : int { WIRE = 8 };       // doubles per shard on the wire: 64 bytes
 
@@ -201,7 +208,7 @@ int tiny_group_setup(TinyGroup** out, const double* Adyn, const double* Bdyn, co
     g->use_rccl = (int)distinct.size() == n_shards && !getenv("TINYMPC_GROUP_HOST_EXCHANGE");
     if (g->use_rccl) {
         Rccl* r = rccl();
-        if (!r) return bail(TINY_ERR_NO_DEVICE, "RCCL unavailable", nullptr);
+        if (!r) return bail(TINY_ERR_NO_DEVICE, "RCCL unavailable", rccl_why());
         g->comm.assign(n_shards, nullptr);
         for (int k = 0; k < n_shards; ++k) { hipSetDevice(g->device[k]); hipDeviceSynchronize(); }
         (void)hipGetLastError();      // RCCL's own HIP checks would trip over an error some earlier, unrelated call left behind
@@ -433,7 +440,7 @@ int tiny_batch_allreduce_stats(TinyBatch* b, void* rccl_comm, int n_ranks, int r
     if (!b || !rccl_comm || !out10) return TINY_ERR_NULL;
     if (n_ranks <= 0 || rank < 0 || rank >= n_ranks) return tinympc_amd::fail(b, TINY_ERR_ARG, "rank %d of %d", rank, n_ranks);
     Rccl* r = rccl();
-    if (!r) return tinympc_amd::fail(b, TINY_ERR_NO_DEVICE, "RCCL unavailable");
+    if (!r) return tinympc_amd::fail(b, TINY_ERR_NO_DEVICE, "RCCL unavailable: %s", rccl_why());
     if (hipSetDevice(b->device) != hipSuccess) return TINY_ERR_HIP;
     if (!b->d_wire || b->wire_ranks < n_ranks) {
         if (b->d_wire) hipFree(b->d_wire);
