@@ -340,6 +340,7 @@ int tiny_group_allreduce_stats(TinyGroup* g, double* out10) {
     for (int k = 0; k < g->n; ++k) {
         TinyBatch* b = g->shard[k];
         if (int rc = tiny_batch_reduce_stats(b, nullptr, g->d_stats[k])) return gfail(g, rc, "shard %d: %s", k, tiny_batch_last_error(b));
+        if (hipSetDevice(g->device[k]) != hipSuccess) return gfail(g, TINY_ERR_HIP, "hipSetDevice(%d)", g->device[k]);   // (a launch goes to the current device's streams only)
         hipLaunchKernelGGL(pack_wire_kernel, dim3(1), dim3(64), 0, b->stream, g->d_stats[k], g->d_wire[k] + (size_t)k * WIRE);
         if (hipGetLastError() != hipSuccess) return gfail(g, TINY_ERR_HIP, "pack_wire_kernel launch failed on shard %d", k);
     }
