@@ -31,8 +31,14 @@ g++ $CXXFLAGS $INC -o "$OUT/phase_driver" "$HERE/phase_driver.cpp" -L"$ROOT/tiny
 # our own caller of the adaptive-rho path (settings->adaptive_rho = 1 + tiny_initialize_sensitivity_matrices)
 g++ $CXXFLAGS $INC -o "$OUT/adaptive_driver" "$HERE/adaptive_driver.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
     -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
+# our own caller of the C++-mangled helpers of rho_benchmark.hpp (rho_api.hip)
+g++ $CXXFLAGS $INC -o "$OUT/rho_driver" "$HERE/rho_driver.cpp" -L"$ROOT/tinympc_amd" -ltinympc_amd \
+    -Wl,-rpath,'$ORIGIN/../../../tinympc_amd' &
 wait
 if [ "$1" = "--golden" ]; then
+  g++ $CXXFLAGS $INC -o "$OUT/ref_rho_driver" "$HERE/rho_driver.cpp" "$REF/src/tinympc/admm.cpp" \
+      "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp"
+  (cd "$OUT" && ./ref_rho_driver > "$ROOT/tests/golden/stdout_rho_driver.txt"); rm -f "$OUT/ref_rho_driver"
   g++ $CXXFLAGS $INC -o "$OUT/ref_phase_driver" "$HERE/phase_driver.cpp" "$REF/src/tinympc/admm.cpp" \
       "$REF/src/tinympc/tiny_api.cpp" "$REF/src/tinympc/rho_benchmark.cpp"
   (cd "$OUT" && ./ref_phase_driver > "$ROOT/tests/golden/stdout_phase_driver.txt"); rm -f "$OUT/ref_phase_driver"

@@ -69,6 +69,25 @@ def test_layout_against_the_real_reference_header(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF + "/src/tinympc"), reason="needs the reference headers")
+def test_rho_adapter_layout_against_the_real_reference_header(tmp_path):
+    """csrc/rho_api.hip mirrors RhoAdapter / RhoBenchmarkResult (rho_benchmark.hpp:5-40) as plain data and static_asserts their
+    sizes (304 / 56): the real header must give those sizes and the offsets the mirror implies."""
+    prog = ('#include <cstdio>\n#include <cstddef>\n#include "tinympc/rho_benchmark.hpp"\nint main(){'
+            'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RhoAdapter), sizeof(RhoBenchmarkResult), offsetof(RhoAdapter, clip),'
+            ' offsetof(RhoAdapter, matrices_initialized), offsetof(RhoAdapter, A_matrix), offsetof(RhoAdapter, q_vector), offsetof(RhoAdapter, ATy_vector),'
+            ' offsetof(RhoAdapter, format_nx), offsetof(RhoBenchmarkResult, initial_rho), offsetof(RhoBenchmarkResult, dual_norm)); return 0;}')
+    src = tmp_path / "rho_layout.cpp"
+    src.write_text(prog)
+    subprocess.check_call(["g++", "-std=c++17", "-w", "-Wno-invalid-offsetof", "-I" + REF + "/src", "-I" + REF + "/include/Eigen", "-I" + REF + "/include",
+                           str(src), "-o", str(tmp_path / "rho_layout")])
+    got = [int(v) for v in subprocess.check_output([str(tmp_path / "rho_layout")]).split()]
+    #        sizes      clip  init  A    q              ATy             nx    initial  dual_norm
+    assert got == [304, 56, 16, 17, 24, 24 + 5 * 24, 24 + 10 * 24, 288, 8, 48], got
+    src_text = open(os.path.join(ROOT, "tinympc_amd", "csrc", "rho_api.hip")).read()
+    assert "sizeof(TinyRhoAdapterPOD) == 304 && sizeof(TinyRhoBenchmarkResultPOD) == 56" in src_text
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/src/tinympc"), reason="needs the reference headers")
 def test_every_function_the_reference_headers_declare_is_exported_or_accounted_for():
     """tiny_api.hpp, admm.hpp, codegen.hpp, rho_benchmark.hpp of the reference against `nm -D libtinympc_amd.so`: the only names
     missing are the C++-mangled internals of rho_benchmark.cpp and the five functions upstream declares but never defines
@@ -80,14 +99,33 @@ def test_every_function_the_reference_headers_declare_is_exported_or_accounted_f
     assert len(declared) >= 35, sorted(declared)
     nm = subprocess.run(["nm", "-D", "--defined-only", tm.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
-    rho_internals = {"initialize_format_matrices", "format_matrices", "compute_residuals", "predict_rho", "update_matrices_with_derivatives",
-                     "benchmark_rho_adaptation"}
+    rho_helpers = {"initialize_format_matrices": "_Z26initialize_format_matricesP10RhoAdapteriii", "predict_rho": "_Z11predict_rhoP10RhoAdapterddddd",
+                   "compute_residuals": "_Z17compute_residualsP10RhoAdapterPdS1_S1_S1_", "update_matrices_with_derivatives": "_Z32update_matrices_with_derivativesP9TinyCached",
+                   "format_matrices": "_Z15format_matricesP10RhoAdapterRKN5Eigen6MatrixIdLin1ELin1ELi0ELin1ELin1EEES5_S5_S5_S5_S5_P9TinyCacheP13TinyWorkspacei",
+                   "benchmark_rho_adaptation": "_Z24benchmark_rho_adaptationP10RhoAdapterRKN5Eigen6MatrixIdLin1ELin1ELi0ELin1ELin1EEES5_S5_S5_S5_S5_P9TinyCacheP13TinyWorkspaceiP18RhoBenchmarkResult"}
+    for name, mangled in rho_helpers.items():                 # C++ linkage upstream: exported under their Itanium names (csrc/rho_api.hip)
+        assert mangled in exported, name
+    assert "_Z6microsv" in exported
+    rho_internals = set(rho_helpers)
     never_defined = {"update_primal", "compute_sensitivity_matrices", "tiny_update_matrices_with_derivatives",
                      "tiny_setup_state_soc_constraints", "tiny_setup_input_soc_constraints"}
     sources = "".join(open(os.path.join(REF, "src", "tinympc", f)).read() for f in ("admm.cpp", "tiny_api.cpp", "codegen.cpp", "rho_benchmark.cpp"))
     for f in never_defined:                                   # (declared, called by nobody, defined nowhere)
         assert not re.search(r"^[\w:<>\*& ]+\b%s\s*\([^;]*\)\s*\{" % f, sources, flags=re.M), f
     assert declared - exported == rho_internals | never_defined, sorted(declared - exported - rho_internals - never_defined)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libtinympc_ref.so")), reason="needs oracle/_ref (built where /root/reference exists)")
+def test_every_symbol_the_reference_library_defines_is_exported():
+    """`nm -D` of the real reference compiled by oracle/Makefile vs libtinympc_amd.so: every function the reference DEFINES
+    (C names and C++-mangled ones; Eigen / libstdc++ instantiations and the shim's own ref_* hooks aside) is a symbol here."""
+    def syms(path, only_text):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and (not only_text or ln.split()[1] == "T")}
+    ref = {s for s in syms(os.path.join(ROOT, "oracle", "_ref", "libtinympc_ref.so"), True)
+           if not s.startswith(("ref_", "_ZN5Eigen", "_ZNK5Eigen", "_ZSt", "_ZNS", "_ZNK", "_ZN9__gnu", "_init", "_fini"))}
+    assert len(ref) >= 25, sorted(ref)
+    assert not (ref - syms(tm.LIB_PATH, False)), sorted(ref - syms(tm.LIB_PATH, False))
 
 
 def test_no_gpu_fails_loudly():

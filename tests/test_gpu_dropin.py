@@ -122,3 +122,24 @@ def test_reference_codegen_examples_generate_a_project_that_solves(tmp_path, ex,
     # zero state, zero references, cold start: the solution is the origin, every instance converges at its first check
     assert m and int(m.group(2)) == B and int(m.group(3)) == B and int(m.group(1)) == B
     assert f"nx {nx} nu {nu} N {N}, batch {B}" in r.stdout and "Hooray" in r.stdout
+
+
+def test_rho_benchmark_helpers_called_through_their_cxx_names():
+    """tests/dropin/rho_driver.cpp (our caller, the reference's rho_benchmark.hpp): the seven C++-mangled helpers of the
+    adaptive-rho module resolve against libtinympc_amd.so (csrc/rho_api.hip) and print what they print when the program is
+    linked against the reference -- dimensions and flags exactly, every number to 1e-9 relative (summation order of the
+    dense products differs, nothing else may)."""
+    import re
+    exe = os.path.join(BUILD, "rho_driver")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    gold = open(os.path.join(ROOT, "tests", "golden", "stdout_rho_driver.txt")).read().splitlines()
+    got = p.stdout.splitlines()
+    assert len(got) == len(gold) == 15
+    num = re.compile(r"-?\d+\.\d+e[+-]\d+")
+    for a, b in zip(got, gold):
+        assert num.sub("#", a) == num.sub("#", b), (a[:120], b[:120])        # words, integers, dimensions, flags
+        for x, y in zip(num.findall(a), num.findall(b)):
+            assert abs(float(x) - float(y)) <= 1e-9 * max(abs(float(y)), 1e-300) + 1e-12, (a[:120], b[:120])
