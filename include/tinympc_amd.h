@@ -469,6 +469,27 @@ bool termination_condition(TinySolver* solver);
  * rax) and the by-value Eigen argument arrives as a pointer; the result buffer is malloc'd (Eigen frees it). */
 TinyVectorPOD* project_soc(TinyVectorPOD* result, const TinyVectorPOD* s, float mu);
 TinyVectorPOD* project_hyperplane(TinyVectorPOD* result, const TinyVectorPOD* z, const TinyVectorPOD* a, double b);
+/* rho_benchmark.hpp:5-94 -- the adaptive-rho module's own helpers.  Upstream they are C++ functions (no extern "C"), so the
+ * library exports them under their Itanium names and a C header cannot declare them; for C++ callers the reference's
+ * rho_benchmark.hpp IS the declaration.  The structs they take, as plain data (layout checked against the real header):
+ *   void     initialize_format_matrices(RhoAdapter*, int nx, int nu, int N)                    rho_benchmark.cpp:14-43
+ *   void     format_matrices(RhoAdapter*, x, u, v, z, g, y (const tinyMatrix&), TinyCache*, TinyWorkspace*, int N)   :45-145
+ *   void     compute_residuals(RhoAdapter*, tinytype* pri_res, dual_res, pri_norm, dual_norm)  :147-178   (on the GPU)
+ *   tinytype predict_rho(RhoAdapter*, pri_res, dual_res, pri_norm, dual_norm, current_rho)     :180-201
+ *   void     update_matrices_with_derivatives(TinyCache*, tinytype new_rho)                    :203-217
+ *   void     benchmark_rho_adaptation(RhoAdapter*, x, u, v, z, g, y, TinyCache*, TinyWorkspace*, int N, RhoBenchmarkResult*)   :219-253
+ *   uint32_t micros()                                                                          :9-11 */
+typedef struct {
+    double rho_min, rho_max;
+    bool clip, matrices_initialized;
+    TinyMatrixPOD A_matrix, z_vector, y_vector, x_decision, P_matrix, q_vector;
+    TinyMatrixPOD Ax_vector, r_prim_vector, r_dual_vector, Px_vector, ATy_vector;
+    int format_nx, format_nu, format_N;
+} TinyRhoAdapterPOD;
+typedef struct {
+    uint32_t time_us;
+    double initial_rho, final_rho, pri_res, dual_res, pri_norm, dual_norm;
+} TinyRhoBenchmarkResultPOD;
 /* NEW: n solvers that share one cache / settings / bounds, solved in ONE launch (gather from and
  * scatter to ordinary TinySolver workspaces).  Returns 0 when all converged, else 1. */
 int tiny_solve_batch(TinySolver** solvers, int n);

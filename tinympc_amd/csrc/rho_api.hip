@@ -88,18 +88,7 @@ DeviceScratch g_scratch;
 
 }  // namespace
 
-// ---- plain-data mirrors of rho_benchmark.hpp:5-40 (layout checked against the real header in tests/test_abi.py) ----
-struct TinyRhoAdapterPOD {
-    double rho_min, rho_max;
-    bool clip, matrices_initialized;
-    TinyMatrixPOD A_matrix, z_vector, y_vector, x_decision, P_matrix, q_vector;
-    TinyMatrixPOD Ax_vector, r_prim_vector, r_dual_vector, Px_vector, ATy_vector;
-    int format_nx, format_nu, format_N;
-};
-struct TinyRhoBenchmarkResultPOD {
-    uint32_t time_us;
-    double initial_rho, final_rho, pri_res, dual_res, pri_norm, dual_norm;
-};
+// ---- the plain-data mirrors of rho_benchmark.hpp:5-40 are TinyRhoAdapterPOD / TinyRhoBenchmarkResultPOD of include/tinympc_amd.h
 static_assert(sizeof(TinyRhoAdapterPOD) == 304 && sizeof(TinyRhoBenchmarkResultPOD) == 56, "rho_benchmark.hpp:5-40 on x86-64");
 
 extern "C" {
