@@ -370,6 +370,12 @@ static void build_tile_tables_w(TinyBatch* b) {
     if (b->set.en_input_bound && b->have_bounds)       // input lanes keep knot i in slot i+1
         for (int i = 0; i < N - 1; ++i)
             for (int a = 0; a < nu; ++a) { lo[(i + 1) * LW + nx + a] = b->u_min[(size_t)i * nu + a]; hi[(i + 1) * LW + nx + a] = b->u_max[(size_t)i * nu + a]; }
+    // knot-invariant box? (as build_tables: the input lanes' slot 0 is the dummy slot) -> the UB form of the tile kernel
+    bool uniform = N >= 2;
+    for (int j = 0; j < nx + nu && uniform; ++j)
+        for (int i = (j < nx ? 0 : 1); i < N && uniform; ++i)
+            uniform = lo[i * LW + j] == lo[LW + j] && hi[i * LW + j] == hi[LW + j];
+    b->tile_bounds_uniform = uniform;
 }
 
 static bool soc_active(const TinyBatch* b);
@@ -468,7 +474,8 @@ static int launch_tile(TinyBatch* b) {
         void* params[] = {&a};
         HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, b->stream, params, nullptr));
     } else {
-        hipLaunchKernelGGL(b->tile->k, dim3(grid), dim3(64), 0, b->stream, a);
+        const bool ub = b->tile->kub && b->tile_bounds_uniform && b->use_ub;      // (jit_fn is null: no cone, no half-spaces)
+        hipLaunchKernelGGL(ub ? b->tile->kub : b->tile->k, dim3(grid), dim3(64), 0, b->stream, a);
         HIP_TRY(b, hipGetLastError());
     }
     if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
@@ -1086,7 +1093,7 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     int tw = 0, tr = 0;
     // (W,R) = (1,1) is the one-row kernel's job where that fits; the tile kernel keeps x|u in LDS and holds longer horizons
     if (!b->tile && jit_tile_shape(nx, nu, N, &tw, &tr) && (tw * tr > 1 || !jit_shape_fits(nx, nu, N, false))) {
-        b->tile_dyn = {nx, nu, N, tw, tr, nullptr};
+        b->tile_dyn = {nx, nu, N, tw, tr, nullptr, nullptr};
         b->tile = &b->tile_dyn;
         b->tile_is_jit = true;
     }

@@ -96,6 +96,7 @@ struct TinyBatch {
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
     bool use_ub = true;                            // option "uniform_bounds": take the UB kernel variant when the box allows it
     bool bounds_uniform = false;                   // build_tables: every knot has the same box (admm_kernel.hip.h UB variant)
+    bool tile_bounds_uniform = false;              // build_tile_tables_w: the same for the tile kernel's UB form
     bool xref_shared = true, uref_shared = true;   // the Xref / Uref records of all instances are identical (broadcast, or still zero)
     bool share_ref = true;                         // option "share_ref": let launches exploit that
     int store_primal = 1;                // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)

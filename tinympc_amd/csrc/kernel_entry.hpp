@@ -15,6 +15,7 @@ struct KernelEntry {
 struct TileEntry {
     int nx, nu, N, W, R;
     SolveKernel k;
+    SolveKernel kub;          // knot-invariant box in registers (nullptr for run-time instantiated tile shapes)
 };
 }  // namespace tinympc_amd
 

@@ -66,12 +66,18 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r) {
 // it is instantiated at run time (jit.hpp) when a wide / long shape has a cone switched on.
 // LIN (bit 0 static, bit 1 time-varying half-spaces, admm.cpp:137-211) / KMAX as in admm_kernel.hip.h: two more L-long
 // arrays per family; a'z is the lane-local product summed over the tile's rows by the same FMA chain against ones.
-template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX>
+// UB: the box is the same at every knot -- a lane's two bounds (and the dummy slot's) live in registers, no LDS read per slot.
+// W = 1 shapes compiled with TINYMPC_FUSED_NX / _NU (csrc/Makefile) run the sweeps on the one-row kernel's fused step blocks
+// (fused_backward_step / fused_forward_step: the lane-local instructions of a step sit in front of its DPP chain, no s_nop)
+// and take that kernel's placement of the forward constant (d <- fma(res, nim, cf)).
+template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
+    constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
+    constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
     static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4), "tile shape");
     using T = TileTab<W>;
     const int lane = threadIdx.x & 63, row = lane >> 4, j16 = lane & 15;
@@ -79,10 +85,10 @@ void admm_tile_kernel(const SolveArgs P) {
     const int jj = wrow * 16 + j16;
     const bool is_state = jj < NX, is_input = jj >= NX && jj < NZ;
 
-    __shared__ double sLo[N * LW];
-    __shared__ double sHi[N * LW];
+    __shared__ double sLo[NB * LW];
+    __shared__ double sHi[NB * LW];
     __shared__ double sX[(N / R) * 64];    // x|u trajectory of this wave: only a rolling value in the sweep, kept for the output
-    for (int e = lane; e < N * LW; e += 64) {
+    for (int e = lane; e < NB * LW; e += 64) {
         sLo[e] = P.tab[T::BOUNDS + e];
         sHi[e] = P.tab[T::BOUNDS + N * LW + e];
     }
@@ -124,6 +130,7 @@ void admm_tile_kernel(const SolveArgs P) {
     const double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const double lo_u = sLo[LW + jj], hi_u = sHi[LW + jj], lo_u0 = sLo[jj], hi_u0 = sHi[jj];     // UB (N >= 2 always)
 
     const unsigned long long inst_mask =
         (RPI == 4) ? ~0ull : ((((1ull << (16 * RPI)) - 1ull)) << (inst * 16 * RPI));
@@ -209,6 +216,12 @@ void admm_tile_kernel(const SolveArgs P) {
                             if constexpr (LT) qlo = fma(-rho, VT[l] - GT[l], qlo);      // :275 | :288 | :301
                             if (ph == R - 1 && l == L - 1) {
                                 pcur = qlo;                                             // p_{N-1}
+                            } else if constexpr (TFUSED) {
+                                double q2, res;                                         // (q2 == qlo: the block forms it again in front of its chain)
+                                fused_backward_step<NX, NU>(q2, res, VN[l], G[l], QX[l], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                                pcur = res;
+                                Dn[l] = fma(res, nim, cf);                              // input lanes: -d_i; state lanes: fdyn
+                                qlo = q2;
                             } else {
                                 const double src = is_input ? qhi : pcur;
                                 const double res = tile_matvec<W, 0, NZ>(fma(qlo, smask, cb), src, mb);
@@ -226,18 +239,39 @@ void admm_tile_kernel(const SolveArgs P) {
                     if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);    // x_g | u_{g-1} of this row's first slot
                     if (hrow == ph) {
                         double xcur = (ph > 0) ? xcarry : x0v;         // x_g | u_{g-1} of the slot being processed
+                        // the box of slot l+1 is read from LDS while slot l is worked on (as admm_kernel.hip.h does): a lone wave
+                        // per SIMD has nothing else to hide the LDS latency behind
+                        double lo_c = UB ? (ph == 0 ? lo_u0 : lo_u) : sLo[(ph * L) * LW + jj], hi_c = UB ? (ph == 0 ? hi_u0 : hi_u) : sHi[(ph * L) * LW + jj];
 #pragma unroll
                         for (int l = 0; l < L; ++l) {
                             const int g = ph * L + l;
+                            double lo_n = lo_u, hi_n = hi_u;
+                            if constexpr (!UB) {
+                                lo_n = (l + 1 < L) ? sLo[(g + 1) * LW + jj] : 0.0; hi_n = (l + 1 < L) ? sHi[(g + 1) * LW + jj] : 0.0;
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                             const double xi = xcur;
                             sX[l * 64 + lane] = xi;
-                            if (g < N - 1) {
-                                const double t = tile_matvec<W, 0, NX>(Dn[l], xi, mf1);         // A x_i | u_i
-                                const double xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);       // + f + B u_i | u_i
-                                if (l + 1 < L) xcur = xn; else xcarry = xn;
+                            double tt, vn;
+                            if constexpr (TFUSED) {
+                                if (g < N - 1) {
+                                    double xn, t = Dn[l];
+                                    fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[l], lo_c, hi_c, mf1, mf2);
+                                    if (l + 1 < L) xcur = xn; else xcarry = xn;
+                                } else {
+                                    tt = xi + G[l];
+                                    vn = vmin64(hi_c, vmax64(lo_c, tt));
+                                }
+                            } else {
+                                if (g < N - 1) {
+                                    const double t = tile_matvec<W, 0, NX>(Dn[l], xi, mf1);         // A x_i | u_i
+                                    const double xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);       // + f + B u_i | u_i
+                                    if (l + 1 < L) xcur = xn; else xcarry = xn;
+                                }
+                                tt = xi + G[l];
+                                vn = vmin64(hi_c, vmax64(lo_c, tt));
                             }
-                            const double tt = xi + G[l];
-                            const double vn = vmin64(sHi[g * LW + jj], vmax64(sLo[g * LW + jj], tt));
+                            lo_c = lo_n; hi_c = hi_n;
                             pmax = fmax(pmax, fabs(xi - vn));
                             dmax = fmax(dmax, fabs(VP[l] - vn));
                             G[l] = tt - vn;
