@@ -102,3 +102,38 @@ def test_fused_one_shot_episode():
     b, _ = closed_loop(lambda: make(True), ("x", "u", "vnew", "znew", "x0"), fused=True, extra_opts=(("one_shot", 1),))
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("dims", [(12, 4, 10), (8, 4, 30), (4, 2, 50), (12, 4, 50), (20, 4, 10), (20, 8, 50)])
+def test_knot_invariant_box_in_registers_equals_the_lds_form(dims):
+    """"uniform_bounds" (default on): when the box is the same at every knot the one-row AND the tile kernel keep a lane's two
+    bounds in registers (UB variants) instead of reading LDS per slot -- same arithmetic, so every field and every iteration
+    count must be bit-identical to the form that reads the table (option off); a box that differs at one knot must fall back to
+    the table form by itself and still match the oracle's iteration counts."""
+    from cpu_solvers import OracleSolver
+    suite = sc.sweep_suite(*dims, B=11, max_iter=120)
+    fields = ("x", "u", "vnew", "znew", "g", "y", "v", "z")
+    outs = []
+    for ub in (1, 0):
+        s = make_batch(suite)
+        s.set_option("uniform_bounds", ub)
+        s.set_x0(suite["cases"]["x0"]); s.set("Xref", suite["cases"]["Xref"]); s.set("Uref", suite["cases"]["Uref"])
+        s.solve()
+        outs.append(({k: s.get(k) for k in fields}, s.status()["iter"].copy(), s.kernel_path()))
+        s.close()
+    (a, ia, pa), (b, ib, pb) = outs
+    assert pa == pb and np.array_equal(ia, ib) and ia.max() > 1
+    for k in fields:
+        assert np.array_equal(a[k], b[k]), k
+    # one knot with a different input bound: not uniform any more
+    cfg = dict(suite["config"])
+    cfg["u_max"] = np.array(cfg["u_max"], dtype=float).copy()
+    cfg["u_max"][:, 1] *= 0.5
+    odd = dict(suite, config=cfg)
+    ref = sc.run_cases(OracleSolver, odd)
+    s = make_batch(odd)
+    s.set_x0(odd["cases"]["x0"]); s.set("Xref", odd["cases"]["Xref"]); s.set("Uref", odd["cases"]["Uref"])
+    s.solve()
+    assert np.array_equal(s.status()["iter"], ref["iter"].astype(int))
+    assert np.max(np.abs(s.get("u") - ref["u"])) <= 1e-9 * max(np.max(np.abs(ref["u"])), 1e-300)
+    s.close()
