@@ -50,11 +50,12 @@ def main():
         tag = tag or f"soc{a[3]} dbg{a[4]} mode{a[5]} lin{a[6]} het{a[7]} adapt{extra[0]} ub{extra[1]}"
         print(f"| ({a[0]},{a[1]},{a[2]}) | {tag} | {r['vgpr']} | {r['agpr']} | {r['scratch']} | {r['occ']} | {r['lds']} |")
     print("\ntile kernel `admm_tile_kernel<NX,NU,N,W,R>`:\n")
-    print("| (nx,nu,N) | W x R | VGPR | AGPR | scratch B/lane | waves/SIMD | LDS B |")
-    print("|---|---|---|---|---|---|---|")
+    print("| (nx,nu,N) | W x R | form | VGPR | AGPR | scratch B/lane | waves/SIMD | LDS B |")
+    print("|---|---|---|---|---|---|---|---|")
     for r in sorted((r for r in rows if r["kind"] == "tile"), key=lambda r: r["args"]):
         a = r["args"]
-        print(f"| ({a[0]},{a[1]},{a[2]}) | {a[3]} x {a[4]} | {r['vgpr']} | {r['agpr']} | {r['scratch']} | {r['occ']} | {r['lds']} |")
+        form = "box in registers (UB)" if len(a) >= 9 and a[8] else "box table in LDS"
+        print(f"| ({a[0]},{a[1]},{a[2]}) | {a[3]} x {a[4]} | {form} | {r['vgpr']} | {r['agpr']} | {r['scratch']} | {r['occ']} | {r['lds']} |")
 
 
 if __name__ == "__main__":
