@@ -134,7 +134,8 @@ Code compile(const std::string& name_s, const bool tile) {
         if (p != std::string::npos) hdr.replace(p, std::string(inc).size(), "");
     }
     std::string src = tile ? "#include \"tile_kernel.hip.h\"\n" : "#include \"admm_kernel.hip.h\"\n";
-    if (!tile) {        // the fused sweep steps of admm_kernel.hip.h are spelled out for ONE (nx, nu) pair per compilation: this one's
+    {   // the fused sweep steps of admm_kernel.hip.h are spelled out for ONE (nx, nu) pair per compilation: this one's (the tile
+        // kernel uses them too when an instance is one row wide, W = 1: nx + nu <= 16)
         int fnx = 0, fnu = 0;
         const size_t lt = name_s.find('<');
         if (lt != std::string::npos && sscanf(name_s.c_str() + lt + 1, "%d , %d", &fnx, &fnu) == 2 && fnx > 0 && fnu > 0 && fnx + fnu <= 16)
