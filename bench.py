@@ -48,17 +48,16 @@ def flops_per_iter(nx, nu, N):
             + (N - 1) * (2 * nx * nx + 4 * nx * nu + 2 * nx + 2 * nu) + 11 * S)
 
 
-def steps_per_launch(steps, warmup, requested=0):
-    """MPC steps fused into one launch: `requested`, or (0 = auto) the largest common divisor of --steps and --warmup that is
-    <= 100 (the reference episode length), so that the timed region is exactly --steps steps in whole launches.  None if a
-    requested value does not divide both."""
+def steps_per_launch(steps, warmup=0, requested=0):
+    """MPC steps fused into one launch of the TIMED region: `requested`, or (0 = auto) the largest divisor of --steps that is
+    <= 100 (the reference episode length), so that the timed region is exactly --steps steps in whole launches.  The warm-up
+    launches are cut the same way from --warmup on their own (it is untimed and ends in a cold start anyway), so `warmup` no
+    longer constrains the choice.  None if a requested value does not divide --steps."""
     T = requested
     if T <= 0:
-        import math
-        g = math.gcd(steps, warmup) if warmup else steps
-        T = max(d for d in range(1, 101) if g % d == 0)
+        T = max(d for d in range(1, 101) if steps % d == 0)
     T = max(1, T)
-    if steps % T or (warmup % T and warmup):
+    if steps % T:
         return None
     return T
 
@@ -158,7 +157,8 @@ def main():
         s.set_option(k, int(v))
     T = steps_per_launch(args.steps, args.warmup, args.steps_per_launch)
     if T is None:
-        sys.exit("--steps and --warmup must be multiples of --steps-per-launch")
+        sys.exit("--steps must be a multiple of --steps-per-launch")
+    Tw = steps_per_launch(args.warmup) if args.warmup > 0 else 1      # the untimed warm-up steps, fused the same way on their own
     s.set_option("steps_per_launch", T)
     launches = args.steps // T
     stream = torch.cuda.Stream(device=local_rank)
@@ -211,9 +211,11 @@ def main():
 
     with torch.cuda.stream(stream):
         cold_start()
-        for _ in range(args.warmup // T):
+        s.set_option("steps_per_launch", Tw)
+        for _ in range(args.warmup // Tw):
             s.solve_async()
         s.synchronize()
+        s.set_option("steps_per_launch", T)
         if dist is not None:                         # first-use costs of the collective stay out of the timed region
             exchange()
             barrier()

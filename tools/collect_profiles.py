@@ -65,7 +65,7 @@ if f:
 traffic = {}
 for mode, key, what in (("step", "per_step_launch", "one launch per MPC step, the 100-step episode from cold"),
                         ("default", "fused_launch", "100 MPC steps fused per launch"),
-                        ("driver", "fused_launch_5_steps", "5 MPC steps fused per launch (--steps 20 --warmup 5)")):
+                        ("driver", "fused_launch_driver_flags", "the launches of --steps 20 --warmup 5: one 5-step warm-up launch, then the 20 timed steps fused per launch")):
     fetch, n1 = pmc_per_launch(f"prof_{mode}_fetch", "FETCH_SIZE")
     write, n2 = pmc_per_launch(f"prof_{mode}_write", "WRITE_SIZE")
     if fetch is None or write is None:
