@@ -394,6 +394,10 @@ int solve_group(TinySolver** solvers, int n) {
     // scatter of group g runs while group g+1 is still crossing PCIe -- the copies (0.4 + 0.6 ms for 4 096 quadrotor solvers)
     // disappear behind the host work that has to happen anyway.
     const int groups = n >= 512 ? 4 : 1;
+    // A handful of solvers (tiny_solve = one): the pack / unpack kernels read and write the pinned host buffer directly over
+    // PCIe (it is device-accessible) -- two copy commands less in a call that is all latency.
+    const bool zero_copy = n <= 8 && !getenv("TINYMPC_AMD_NO_ZERO_COPY");
+    double* const xbuf = zero_copy ? ctx.h_pin : ctx.d_xfer;
     auto split_groups = [&](const std::vector<FieldMap>& fs, size_t tail_doubles) {      // -> field index bounds of each group
         size_t total = tail_doubles;
         for (const FieldMap& fm : fs) total += (size_t)n * fsize(fm);
@@ -424,7 +428,7 @@ int solve_group(TinySolver** solvers, int n) {
                 if (last) for (int k = lo; k < hi; ++k) memcpy(ctx.h_pin + o + (size_t)k * nx, solvers[k]->work->x.data, nx * sizeof(double));   // x[:,0] = x0
             });
             if (last) o1 += (size_t)n * nx;
-            if (hipMemcpyAsync(ctx.d_xfer + o0, ctx.h_pin + o0, (o1 - o0) * sizeof(double), hipMemcpyHostToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
+            if (!zero_copy && hipMemcpyAsync(ctx.d_xfer + o0, ctx.h_pin + o0, (o1 - o0) * sizeof(double), hipMemcpyHostToDevice, b->stream) != hipSuccess) return TINY_ERR_HIP;
             o0 = o1;
         }
     }
@@ -436,7 +440,7 @@ int solve_group(TinySolver** solvers, int n) {
         off = 0;
         for (const FieldMap& fm : in) { fs.push_back(fm.f); offs.push_back(off); off += (size_t)n * fsize(fm); }
         fs.push_back(TINY_F_X0); offs.push_back(off);
-        if (int rc = xfer_fields(b, fs.data(), offs.data(), (int)fs.size(), ctx.d_xfer, true, false, 0, 0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        if (int rc = xfer_fields(b, fs.data(), offs.data(), (int)fs.size(), xbuf, true, false, 0, 0)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
     }
     // adaptive rho: every solver's own cache is state (rho, Kinf, Pinf and the dead copies C1, C2 move during the solve and
     // persist, rho_benchmark.cpp:196-210): up before the launch, back into the caller's TinyCache after it
@@ -481,7 +485,7 @@ int solve_group(TinySolver** solvers, int n) {
         std::vector<size_t> offs;
         size_t o = 0;
         for (const FieldMap& fm : out) { fs.push_back(fm.f); offs.push_back(o); o += (size_t)n * fsize(fm); }
-        if (int rc = xfer_fields(b, fs.data(), offs.data(), (int)fs.size(), ctx.d_xfer, false, true, off_status, off_resid)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
+        if (int rc = xfer_fields(b, fs.data(), offs.data(), (int)fs.size(), xbuf, false, true, off_status, off_resid)) { fprintf(stderr, "tiny_solve: %s\n", b->err); return rc; }
     }
     // download: status + residuals first (every group's scatter looks at the iteration counts), then the field groups, an
     // event behind each; the scatter of a group waits for its own event only
@@ -489,13 +493,13 @@ int solve_group(TinySolver** solvers, int n) {
     const int ogroups = (int)ogb.size() - 1;
     for (int g = 0; g <= ogroups; ++g)
         if (!ctx.ev[g] && hipEventCreateWithFlags(&ctx.ev[g], hipEventDisableTiming) != hipSuccess) return TINY_ERR_HIP;
-    if (hipMemcpyAsync(ctx.h_pin + off_status, ctx.d_xfer + off_status, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
+    if (!zero_copy && hipMemcpyAsync(ctx.h_pin + off_status, ctx.d_xfer + off_status, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return TINY_ERR_HIP;
     std::vector<size_t> gstart(ogroups + 1, 0);
     for (int g = 0; g < ogroups; ++g) {
         size_t o1 = gstart[g];
         for (size_t i = ogb[g]; i < ogb[g + 1]; ++i) o1 += (size_t)n * fsize(out[i]);
         gstart[g + 1] = o1;
-        if (hipMemcpyAsync(ctx.h_pin + gstart[g], ctx.d_xfer + gstart[g], (o1 - gstart[g]) * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+        if ((!zero_copy && hipMemcpyAsync(ctx.h_pin + gstart[g], ctx.d_xfer + gstart[g], (o1 - gstart[g]) * sizeof(double), hipMemcpyDeviceToHost, b->stream) != hipSuccess) ||
             hipEventRecord(ctx.ev[g], b->stream) != hipSuccess) return TINY_ERR_HIP;
     }
     const double t2 = now();
