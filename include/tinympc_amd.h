@@ -112,7 +112,9 @@ int tiny_batch_destroy(TinyBatch* b);
 int tiny_batch_set_bound_constraints(TinyBatch* b, const double* x_min, const double* x_max,
                                      const double* u_min, const double* u_max);
 /* == tiny_set_cone_constraints (tiny_api.cpp:176-208): STATE triple first (the definition's
- * positional order).  Cones have dimension 3 (admm.cpp:53) and must not overlap. */
+ * positional order).  Cones have dimension 3 (admm.cpp:53).  Cones of one family may share rows: the reference projects them
+ * one after the other (admm.cpp:111-135) and so does this library -- on the coverage kernel (single-step launches, shared
+ * problem data); disjoint cones run on the register-resident kernels. */
 int tiny_batch_set_cone_constraints(TinyBatch* b, int n_state_cones, const int* Acx, const int* qcx,
                                     const double* cx, int n_input_cones, const int* Acu,
                                     const int* qcu, const double* cu);
@@ -318,6 +320,8 @@ int tiny_batch_allreduce_stats(TinyBatch* b, void* rccl_comm, int n_ranks, int r
 int tiny_rccl_unique_id(void* id128);
 int tiny_rccl_comm_init_rank(void** comm, int n_ranks, const void* id128, int rank, int device);
 int tiny_rccl_comm_destroy(void* comm);
+int tiny_rccl_comm_count(void* comm);    /* ranks of the communicator (ncclCommCount), or TINY_ERR_NULL / TINY_ERR_HIP (< 0) */
+int tiny_rccl_available(void);          /* 1: librccl could be loaded next to this library's HIP runtime (no communicator is created) */
 /* Only the message: the 8 doubles {sum iter, sum solved, accumulated iterations, accumulated solves, max primal_state,
  * primal_input, dual_state, dual_input} of this batch, written to device memory on the batch's stream behind the solve,
  * for hosts that run the collective themselves (bench.py hands it to torch.distributed = RCCL). */

@@ -58,6 +58,10 @@ def single_solve_suites(only=None):
         "cartpole_episode": sc.cartpole_suite(RefSolver),
         "random_state_quad": sc.random_state_suite("quadrotor_20hz", B=8, seed=7),
         "random_state_rocket_soc": sc.random_state_suite("rocket_landing_20hz", B=8, seed=11, soc=True),
+        # overlapping cones (admm.cpp:111-135 applies them sequentially per column): quadrotor 3 state + 2 input cones sharing rows,
+        # rocket two input cones on the same three rows
+        "random_state_quad_overlap_soc": sc.random_state_suite("quadrotor_20hz", B=6, seed=13, soc="overlap"),
+        "random_state_rocket_overlap_soc": sc.random_state_suite("rocket_landing_20hz", B=5, seed=14, soc="overlap"),
         "sweep_4_2_10": sc.sweep_suite(4, 2, 10),
         "sweep_8_4_30": sc.sweep_suite(8, 4, 30, B=3),
         "sweep_12_2_10": sc.sweep_suite(12, 2, 10, B=3),

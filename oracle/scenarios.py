@@ -395,7 +395,12 @@ def random_state_suite(name="quadrotor_20hz", B=8, seed=7, scale=0.3, soc=False)
     rng = np.random.default_rng(seed)
     kw = dict(max_iter=37, x_min=rng.uniform(-1.0, -0.2, (nx, N)), x_max=rng.uniform(0.2, 1.0, (nx, N)),
               u_min=rng.uniform(-0.5, -0.1, (nu, N - 1)), u_max=rng.uniform(0.1, 0.5, (nu, N - 1)))
-    if soc:
+    if soc == "overlap":
+        # cones that SHARE rows: the reference projects the cones of a column one after the other, overlapping or not
+        # (admm.cpp:111-135), so the order matters -- rows 0..4 of the state are hit by three cones, rows 0..3 of the input by two
+        kw.update(en_state_soc=1, en_input_soc=1, state_cone=([0, 2, 1], [3, 3, 3], [0.7, 0.5, 0.9]),
+                  input_cone=([0, 1], [3, 3], [0.4, 0.6]) if nu >= 4 else ([0, 0], [3, 3], [0.4, 0.6]))
+    elif soc:
         kw.update(en_state_soc=1, en_input_soc=1, state_cone=([1], [3], [0.7]), input_cone=([0], [3], [0.4]))
     cfg = default_config(prob, **kw)
     cases = zero_cases(prob, B)
@@ -472,7 +477,12 @@ def random_linear_suite(name="quadrotor_20hz", B=6, seed=21, tv=True, static=Tru
         kw.update(en_tv_state_linear=1, en_tv_input_linear=1,
                   tv_linear=(rng.normal(0, 1, (2 * N, nx)), rng.normal(0, 0.3, (2, N)),
                              rng.normal(0, 1, (1 * (N - 1), nu)), rng.normal(0, 0.3, (1, N - 1))))
-    if soc:
+    if soc == "overlap":
+        # cones that SHARE rows: the reference projects the cones of a column one after the other, overlapping or not
+        # (admm.cpp:111-135), so the order matters -- rows 0..4 of the state are hit by three cones, rows 0..3 of the input by two
+        kw.update(en_state_soc=1, en_input_soc=1, state_cone=([0, 2, 1], [3, 3, 3], [0.7, 0.5, 0.9]),
+                  input_cone=([0, 1], [3, 3], [0.4, 0.6]) if nu >= 4 else ([0, 0], [3, 3], [0.4, 0.6]))
+    elif soc:
         kw.update(en_state_soc=1, en_input_soc=1, state_cone=([1], [3], [0.7]), input_cone=([0], [3], [0.4]))
     cfg = default_config(prob, **kw)
     cases = zero_cases(prob, B)

@@ -90,8 +90,8 @@ def _worker(rank, world, port, q):
     from cpu_solvers import OracleSolver
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    suite = sc.tracking_random_suite(B=10, seed=77)
-    lo, hi = shard_bounds(10, rank, world)
+    suite = sc.tracking_random_suite(B=11, seed=77)                 # uneven shards (6 + 5): the job size is the sum of the shard sizes
+    lo, hi = shard_bounds(11, rank, world)
     mine = dict(problem=suite["problem"], config=suite["config"], cases={k: v[lo:hi] for k, v in suite["cases"].items()})
     out = sc.run_cases(OracleSolver, mine)
     n = hi - lo
@@ -122,8 +122,23 @@ def test_two_rank_stats_allreduce_matches_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ref = sc.run_cases(OracleSolver, sc.tracking_random_suite(B=10, seed=77))
-    expect = [ref["iter"].sum(), ref["sol_solved"].sum(), 10, ref["primal_residual_state"].max(),
+    ref = sc.run_cases(OracleSolver, sc.tracking_random_suite(B=11, seed=77))
+    expect = [ref["iter"].sum(), ref["sol_solved"].sum(), 11, ref["primal_residual_state"].max(),
               ref["primal_residual_input"].max(), ref["dual_residual_state"].max(), ref["dual_residual_input"].max(),
               ref["iter"].sum(), ref["sol_solved"].sum(), 0.0]
     assert np.allclose(res[0], expect) and res[0] == res[1]
+
+
+def test_reduce_table_takes_the_job_size_from_the_shard_column_and_keeps_a_nan_residual():
+    """ADVICE r02: (1) the default job size must be exact for uneven shards (a 9th column, not shard size x world);
+    (2) a NaN residual of a diverged shard survives the reduction (the native reduce_wire_table does the same)."""
+    import torch
+    from tinympc_amd.distributed import reduce_table
+    rows = [[10, 2, 10, 2, 0.1, 0.2, 0.3, 0.4, 6], [7, 1, 7, 1, 0.5, float("nan"), 0.1, 0.2, 5]]
+    out = reduce_table(torch.tensor(rows, dtype=torch.float64))
+    assert out[0] == 17 and out[1] == 3 and out[2] == 11 and out[7] == 17 and out[8] == 3
+    assert out[3] == 0.5 and torch.isnan(out[4]) and out[5] == 0.3 and out[6] == 0.4
+    out = reduce_table(torch.tensor(rows, dtype=torch.float64)[:, :8], total_batch=11)
+    assert out[2] == 11 and torch.isnan(out[4])
+    with pytest.raises(ValueError):
+        reduce_table(torch.tensor(rows, dtype=torch.float64)[:, :8])

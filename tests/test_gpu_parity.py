@@ -86,6 +86,8 @@ def test_dpp_modes_agree_with_golden(mode):
     lambda: sc.random_state_suite("quadrotor_20hz", B=37, seed=201),
     lambda: sc.random_state_suite("rocket_landing_20hz", B=21, seed=202, soc=True),
     lambda: sc.random_state_suite("cartpole", B=9, seed=203),
+    lambda: sc.random_state_suite("quadrotor_20hz", B=11, seed=204, soc="overlap"),        # cones sharing rows: sequential projections
+    lambda: sc.random_state_suite("rocket_landing_20hz", B=7, seed=205, soc="overlap"),
     lambda: sc.tracking_random_suite(B=130, seed=4242),
     lambda: sc.rocket_random_suite(B=33, seed=77),
     lambda: sc.sweep_suite(8, 2, 10, B=5),
@@ -496,8 +498,17 @@ def test_api_misuse_is_reported_not_ignored():
     s = tm.TinyBatchSolver.from_problem(prob, 4)
     with pytest.raises(tm.TinyMPCError, match="cone dimension"):
         s.set_cone_constraints([0], [4], [0.5], [], [], [])   # the reference's project_soc only handles 3 (admm.cpp:53)
-    with pytest.raises(tm.TinyMPCError, match="overlapping"):
-        s.set_cone_constraints([0, 2], [3, 3], [0.5, 0.5], [], [], [])
+    # overlapping cones are served (sequential projections, admm.cpp:111-135) -- by the coverage kernel, which has no fused steps
+    s.set_cone_constraints([0, 2], [3, 3], [0.5, 0.5], [], [], [])
+    s.update_settings(en_state_soc=1)
+    assert s.kernel_path() == "cover"
+    s.set_option("steps_per_launch", 3)
+    with pytest.raises(tm.TinyMPCError, match="overlapping cones"):
+        s.solve()
+    s.set_option("steps_per_launch", 1)
+    s.update_settings(en_state_soc=0)                          # the family is switched off: the overlap is irrelevant again
+    assert s.kernel_path() == "regs"
+    s.set_cone_constraints([], [], [], [], [], [])
     with pytest.raises(tm.TinyMPCError, match="out of range"):
         s.set_cone_constraints([], [], [], [2], [3], [0.5])   # nu = 4: rows 2..4 do not exist
     with pytest.raises(tm.TinyMPCError):

@@ -42,7 +42,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
-    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy",
+    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy", "tiny_rccl_comm_count", "tiny_rccl_available",
     "tiny_batch_get_option", "tiny_predict_split", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
@@ -133,6 +133,7 @@ def lib():
         L.tiny_rccl_unique_id.argtypes = [C.c_void_p]
         L.tiny_rccl_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.tiny_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.tiny_rccl_comm_count.argtypes = [C.c_void_p]
         L.tiny_batch_allreduce_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, _dp]
         L.tiny_group_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _ip, C.c_int, C.c_int, C.c_int]
@@ -668,6 +669,19 @@ def rccl_comm_init_rank(n_ranks, unique_id: bytes, rank, device) -> int:
 
 def rccl_comm_destroy(comm):
     lib().tiny_rccl_comm_destroy(C.c_void_p(comm))
+
+
+def rccl_comm_count(comm) -> int:
+    """ranks of the communicator, asked of RCCL itself (ncclCommCount)"""
+    n = lib().tiny_rccl_comm_count(C.c_void_p(comm))
+    if n < 0:
+        raise TinyMPCError(f"tiny_rccl_comm_count failed ({n})")
+    return int(n)
+
+
+def rccl_available() -> bool:
+    """librccl loads next to this library's HIP runtime (nothing collective happens)"""
+    return bool(lib().tiny_rccl_available())
 
 
 def load_problem(name):

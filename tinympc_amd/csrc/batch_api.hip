@@ -397,7 +397,9 @@ static int tile_lin_variant(const TinyBatch* b) {
     const long lds = 8L * (2L * b->N * LW + (long)(b->N / b->tile->R) * 64 + ((lv & 1) ? 3L * km * LW : 1) + ((lv & 2) ? 3L * b->N * km * LW : 1));
     return lds <= 60 * 1024 ? lv : 0;
 }
+static bool cones_overlap(const TinyBatch* b);
 static bool use_tile(const TinyBatch* b) {
+    if (cones_overlap(b)) return false;
     if (linear_active(b) && (tile_lin_variant(b) == 0 || b->no_jit || b->tile_soc_failed)) return false;
     // (a cone on a tile shape needs the SOC variant, which only exists through run-time instantiation)
     return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile) && !b->no_tile && !b->hetero && !b->adaptive && !b->force_general && !b->debug &&
@@ -493,7 +495,12 @@ static int lin_variant(const TinyBatch* b) {
     if (lin_kmax(b) > LIN_KMAX && (b->no_jit || b->variant_jit_failed)) return 0;
     return ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
 }
+// cones of an ENABLED family share rows: sequential projections (admm.cpp:111-135), coverage kernel only
+static bool cones_overlap(const TinyBatch* b) {
+    return (b->set.en_state_soc && b->cones_overlap_x) || (b->set.en_input_soc && b->cones_overlap_u);
+}
 static bool use_general(const TinyBatch* b) {
+    if (cones_overlap(b)) return true;
     if (b->adaptive) return false;                    // adaptive rho lives on the one-row kernel only (launch_solve refuses the rest)
     if (linear_active(b)) return lin_variant(b) == 0;
     return !b->hetero && (!has_regs(b) || b->force_general);
@@ -805,6 +812,8 @@ bool soc_active(const TinyBatch* b) {
 }
 
 int launch_solve(TinyBatch* b) {
+    if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
+        return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
     if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
         return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous problem data needs the register-resident kernel (nx+nu <= 16, at most 4 half-spaces per knot and family)");
     if (b->adaptive && !has_regs(b))
@@ -1258,6 +1267,7 @@ int tiny_batch_set_cone_constraints(TinyBatch* b, int nsc, const int* Acx, const
     if (nsc < 0 || nic < 0) return fail(b, TINY_ERR_DIM, "negative cone count");
     if ((nsc > 0 && (!Acx || !qcx || !cx)) || (nic > 0 && (!Acu || !qcu || !cu))) return fail(b, TINY_ERR_NULL, "null cone descriptor with a positive count");
     std::vector<int> used((size_t)(b->nx + b->nu), 0);
+    bool overlap_x = false, overlap_u = false;
     for (int pass = 0; pass < 2; ++pass) {
         const int n = pass ? nic : nsc;
         const int* A = pass ? Acu : Acx;
@@ -1266,10 +1276,14 @@ int tiny_batch_set_cone_constraints(TinyBatch* b, int nsc, const int* Acx, const
         for (int k = 0; k < n; ++k) {
             if (q[k] != 3) return fail(b, TINY_ERR_UNSUPPORTED, "cone dimension %d: the reference's project_soc only handles 3 (admm.cpp:53)", q[k]);
             if (A[k] < 0 || A[k] + 3 > dim) return fail(b, TINY_ERR_DIM, "cone %d out of range", k);
+            // The reference projects the cones of a column one after the other whether they share rows or not
+            // (admm.cpp:111-135).  The register-resident kernels give every row to at most one cone; families with
+            // overlapping cones are served by the coverage kernel, which walks the cones in the reference's order.
             for (int c3 = 0; c3 < 3; ++c3)
-                if (used[off + A[k] + c3]++) return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones");
+                if (used[off + A[k] + c3]++) (pass ? overlap_u : overlap_x) = true;
         }
     }
+    b->cones_overlap_x = overlap_x; b->cones_overlap_u = overlap_u;
     b->Acx.assign(Acx, Acx + nsc); b->qcx.assign(qcx, qcx + nsc); b->cx.assign(cx, cx + nsc);
     b->Acu.assign(Acu, Acu + nic); b->qcu.assign(qcu, qcu + nic); b->cu.assign(cu, cu + nic);
     b->tab_dirty = true;

@@ -44,6 +44,7 @@ struct TinyBatch {
     std::vector<double> x_min, x_max, u_min, u_max;
     std::vector<int> Acx, qcx, Acu, qcu;
     std::vector<double> cx, cu;
+    bool cones_overlap_x = false, cones_overlap_u = false;   // cones of a family share rows (admm.cpp:111-135 projects them one after the other): coverage kernel
     // half-space constraints a_k' z <= b_k (row-major copies: [k][n]); time-varying: [knot][k][n]
     int nsl = 0, nil = 0, ntsl = 0, ntil = 0;
     std::vector<double> Alin_x, blin_x, Alin_u, blin_u, tvA_x, tvb_x, tvA_u, tvb_u;

@@ -23,6 +23,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unistd.h>
 
 using namespace tinympc_amd;
 
@@ -302,7 +303,13 @@ void parallel_solvers(int n, F&& body) {
     static const int cap = getenv("TINYMPC_AMD_HOST_THREADS") ? std::min(32, std::max(1, atoi(getenv("TINYMPC_AMD_HOST_THREADS")))) : 16;
     const int nt = (n < 512) ? 1 : (int)std::min<unsigned>((unsigned)cap, std::max(1u, hw / 2));
     if (nt <= 1) { body(0, n, 0); return; }
-    static WorkerPool pool(cap - 1);                 // (callers hold g_mu: one batch call at a time)
+    // (callers hold g_mu: one batch call at a time.)  The parked threads belong to the process that created them: a fork()ed
+    // child has none of them, and waiting on pending_ there would never end -- so the pool is per pid; the parent's pool object
+    // is abandoned in the child (its threads do not exist there: joining them would hang as well).
+    static WorkerPool* pool_ptr = nullptr;
+    static pid_t pool_pid = 0;
+    if (!pool_ptr || pool_pid != getpid()) { pool_ptr = new WorkerPool(cap - 1); pool_pid = getpid(); }
+    WorkerPool& pool = *pool_ptr;
     const int parts = std::min(nt, pool.workers() + 1);
     const int per = (n + parts - 1) / parts;
     const std::function<void(int)> job = [&](int t) {
@@ -336,13 +343,25 @@ uint64_t family_hash(const TinySolver* s) {
     return h;
 }
 
+int solve_group_locked(TinySolver** solvers, int n, TinyBatch** bout);
+// Every error return of the body below may leave asynchronous copies into the context's pinned / transfer buffers in flight
+// (uploads before the solve, the event-ordered downloads after it); the next call reuses those buffers, so a failed call
+// drains the stream (best effort) before it reports.
 int solve_group(TinySolver** solvers, int n) {
     if (!solvers || n <= 0 || !solvers[0]) return TINY_ERR_NULL;
-    TinySolver* s0 = solvers[0];
-    const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
     std::lock_guard<std::mutex> lk(g_mu);
     TinyBatch* b = nullptr;
+    const int rc = solve_group_locked(solvers, n, &b);
+    if (rc != TINY_OK && b && b->stream)      // (1 = max_iter reached shares its value with TINY_ERR_DIM: the stream is idle then, the call is free)
+        { (void)hipStreamSynchronize(b->stream); (void)hipGetLastError(); }
+    return rc;
+}
+int solve_group_locked(TinySolver** solvers, int n, TinyBatch** bout) {
+    TinySolver* s0 = solvers[0];
+    const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
+    TinyBatch* b = nullptr;
     if (int rc = device_context(s0, n, &b)) return rc;
+    *bout = b;
     Ctx& ctx = g_ctx[s0];
     const uint64_t fam = family_hash(s0);
     if (!ctx.family_valid || ctx.family != fam) {

@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>       // types and prototypes only: the entry points are resolved with dlsym
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +36,7 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     std::string why;
 };
 
@@ -76,6 +78,7 @@ Rccl load_rccl() {
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
         dlclose(r.so);
         r.so = nullptr;
@@ -104,7 +107,9 @@ void reduce_wire_table(const double* table, int n, double total_batch, double* o
     for (int r = 0; r < n; ++r) {
         const double* w = table + (size_t)r * WIRE;
         out10[0] += w[0]; out10[1] += w[1]; out10[7] += w[2]; out10[8] += w[3];
-        for (int k = 0; k < 4; ++k) out10[3 + k] = std::max(out10[3 + k], w[4 + k]);
+        // a NaN residual (a diverged shard) must survive the reduction, as it does in the shard-level atomicMax on bit
+        // patterns and in distributed.reduce_table (torch.max): std::max(out, NaN) would silently drop it
+        for (int k = 0; k < 4; ++k) out10[3 + k] = (std::isnan(w[4 + k]) || std::isnan(out10[3 + k])) ? std::nan("") : std::max(out10[3 + k], w[4 + k]);
     }
     out10[2] = total_batch;
 }
@@ -416,6 +421,18 @@ int tiny_rccl_comm_init_rank(void** comm, int n_ranks, const void* id128, int ra
     if (r->CommInitRank(&c, n_ranks, id, rank) != ncclSuccess) return TINY_ERR_HIP;
     *comm = c;
     return TINY_OK;
+}
+int tiny_rccl_available(void) {
+    Rccl* r = rccl();
+    return (r && r->GetUniqueId && r->CommInitRank) ? 1 : 0;
+}
+// number of ranks of a communicator (ncclCommCount), or a (negative) TINY_ERR_* code: lets a host report the size the
+// exchange REALLY runs at instead of the one it asked for
+int tiny_rccl_comm_count(void* comm) {
+    Rccl* r = rccl();
+    if (!r || !r->CommCount || !comm) return TINY_ERR_NULL;
+    int n = 0;
+    return r->CommCount(static_cast<ncclComm_t>(comm), &n) == ncclSuccess ? n : TINY_ERR_HIP;
 }
 int tiny_rccl_comm_destroy(void* comm) {
     Rccl* r = rccl();

@@ -70,10 +70,18 @@ __global__ __launch_bounds__(256) void rho_residuals_kernel(const double* __rest
     if (t < 5) out5[t] = red[t][0];
 }
 
+// The helper runs on the device the CALLER has current (a process that also drives a TinyBatch / TinyGroup on other GPUs must
+// not find its thread's current device changed by a call into this module), on a private non-blocking stream (never the
+// legacy null stream, which would serialise against every other stream of the process) and with one scratch buffer per device.
 struct DeviceScratch {
     std::mutex mu;
     double* d = nullptr;
     size_t doubles = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t get_stream() {
+        if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); stream = nullptr; }
+        return stream;
+    }
     double* get(size_t need) {
         if (need > doubles) {
             if (d) (void)hipFree(d);
@@ -84,7 +92,8 @@ struct DeviceScratch {
         return d;
     }
 };
-DeviceScratch g_scratch;
+enum { MAX_SCRATCH_DEVICES = 16 };
+DeviceScratch g_scratch[MAX_SCRATCH_DEVICES];
 
 }  // namespace
 
@@ -187,29 +196,34 @@ void tinyamd_compute_residuals(TinyRhoAdapterPOD* a, double* pri_res, double* du
         fprintf(stderr, "tinympc_amd: compute_residuals: %s (this library computes on an MI355X, there is no CPU fallback)\n", what);
         *pri_res = *dual_res = *pri_norm = *dual_norm = nan;
     };
-    std::lock_guard<std::mutex> lk(g_scratch.mu);
-    if (hipSetDevice(0) != hipSuccess) { (void)hipGetLastError(); return loud("no HIP device"); }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_SCRATCH_DEVICES) { (void)hipGetLastError(); return loud("no HIP device"); }
+    DeviceScratch& sc = g_scratch[dev];              // the caller's current device: nothing is changed for the calling thread
+    std::lock_guard<std::mutex> lk(sc.mu);
     const size_t in = (size_t)(m * n + n * n + n + 2 * m + n), out = (size_t)(2 * m + 3 * n + 5);
-    double* d = g_scratch.get(in + out);
+    double* d = sc.get(in + out);
     if (!d) return loud("hipMalloc failed");
+    hipStream_t st = sc.get_stream();
+    if (!st) return loud("hipStreamCreate failed");
     double *dA = d, *dP = dA + m * n, *dx = dP + n * n, *dz = dx + n, *dy = dz + m, *dq = dy + m;
     double *dAx = dq + n, *drp = dAx + m, *dPx = drp + m, *dAT = dPx + n, *drd = dAT + n, *dout = drd + n;
-    bool ok = hipMemcpy(dA, a->A_matrix.data, (size_t)(m * n) * 8, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dP, a->P_matrix.data, (size_t)(n * n) * 8, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dx, a->x_decision.data, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dz, a->z_vector.data, (size_t)m * 8, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dy, a->y_vector.data, (size_t)m * 8, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dq, a->q_vector.data, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) return loud("upload failed");
-    hipLaunchKernelGGL(rho_residuals_kernel, dim3(1), dim3(256), 0, 0, dA, dx, dz, dy, dP, dq, (int)m, (int)n, dAx, drp, dPx, dAT, drd, dout);
+    bool ok = hipMemcpyAsync(dA, a->A_matrix.data, (size_t)(m * n) * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(dP, a->P_matrix.data, (size_t)(n * n) * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(dx, a->x_decision.data, (size_t)n * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(dz, a->z_vector.data, (size_t)m * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(dy, a->y_vector.data, (size_t)m * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpyAsync(dq, a->q_vector.data, (size_t)n * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (!ok) { (void)hipStreamSynchronize(st); return loud("upload failed"); }
+    hipLaunchKernelGGL(rho_residuals_kernel, dim3(1), dim3(256), 0, st, dA, dx, dz, dy, dP, dq, (int)m, (int)n, dAx, drp, dPx, dAT, drd, dout);
     double o5[5];
-    ok = hipGetLastError() == hipSuccess && hipMemcpy(a->Ax_vector.data, dAx, (size_t)m * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(a->r_prim_vector.data, drp, (size_t)m * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(a->Px_vector.data, dPx, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(a->ATy_vector.data, dAT, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(a->r_dual_vector.data, drd, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(o5, dout, sizeof(o5), hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) return loud("kernel or download failed");
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(a->Ax_vector.data, dAx, (size_t)m * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(a->r_prim_vector.data, drp, (size_t)m * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(a->Px_vector.data, dPx, (size_t)n * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(a->ATy_vector.data, dAT, (size_t)n * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(a->r_dual_vector.data, drd, (size_t)n * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(o5, dout, sizeof(o5), hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) { (void)hipStreamSynchronize(st); return loud("kernel or download failed"); }
     *pri_res = o5[0];
     *pri_norm = std::max(o5[1], o5[2]);
     *dual_res = o5[3];

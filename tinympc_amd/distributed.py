@@ -43,14 +43,23 @@ def shard_size(total: int, rank: int, world: int, interleaved: bool = False) -> 
 _wire_index = {}
 
 
-def reduce_table(table, total_batch):
-    """Host-side reduction of the gathered world x 8 table of wire messages -> the 10-entry statistics vector."""
+def reduce_table(table, total_batch=None):
+    """Host-side reduction of the gathered table of wire messages -> the 10-entry statistics vector.  Rows are the 8-double
+    wire message, optionally followed by the shard's own size (a 9th column): total_batch = None takes the job size from
+    that column (exact for uneven and interleaved shards).  A NaN residual propagates (torch.max), as in the native
+    reduce_wire_table."""
     import torch
-    t = torch.as_tensor(table, dtype=torch.float64).reshape(-1, len(WIRE_IDX))
+    t = torch.as_tensor(table, dtype=torch.float64)
+    cols = t.shape[-1] if t.dim() == 2 else len(WIRE_IDX)
+    t = t.reshape(-1, cols)
     out = torch.zeros(10, dtype=torch.float64)
     sums = t[:, :4].sum(dim=0)
     out[0], out[1], out[7], out[8] = sums[0], sums[1], sums[2], sums[3]
-    out[3:7] = t[:, 4:].max(dim=0).values
+    out[3:7] = t[:, 4:8].max(dim=0).values
+    if total_batch is None:
+        if cols <= len(WIRE_IDX):
+            raise ValueError("reduce_table: total_batch is needed when the table carries no shard-size column")
+        total_batch = float(t[:, 8].sum())
     out[2] = float(total_batch)
     return out
 
@@ -61,8 +70,10 @@ def _world_rank(dist, group):
 
 def allreduce_stats(stats, dist=None, group=None, total_batch=None):
     """stats: 1-D float64 torch tensor of 10 entries (device or CPU) as written by
-    TinyBatchSolver.reduce_stats(_async).  Returns the job-wide vector as a CPU tensor (every rank gets
-    the same one).  total_batch: the unsharded batch size; default = this rank's batch x world size.
+    TinyBatchSolver.reduce_stats(_async).  Returns the job-wide vector as a **CPU** tensor whatever device `stats` lives
+    on (every rank gets the same one; the reduction of the gathered table happens on the host).  total_batch: the
+    unsharded batch size; None = the sum of the shards' own sizes (stats[2] of every rank), which travels as a 9th
+    column of the same table -- exact for uneven and interleaved shards, no extra collective, no device read.
 
     The gather of the 64-byte messages is issued as ONE all-reduce(SUM) over a world x 8 table in which a
     rank fills only its own row (adding the other ranks' zeros is exact): on this stack a small all-reduce
@@ -76,11 +87,10 @@ def allreduce_stats(stats, dist=None, group=None, total_batch=None):
     idx = _wire_index.get(stats.device)
     if idx is None:                                                 # built once per device: no host->device copy per call
         idx = _wire_index[stats.device] = torch.tensor(WIRE_IDX, dtype=torch.long, device=stats.device)
-    table = torch.zeros(world, len(WIRE_IDX), dtype=stats.dtype, device=stats.device)
-    table[rank] = stats.index_select(0, idx)                        # 8 doubles = 64 bytes
+    table = torch.zeros(world, len(WIRE_IDX) + 1, dtype=stats.dtype, device=stats.device)
+    table[rank, :len(WIRE_IDX)] = stats.index_select(0, idx)        # 8 doubles = 64 bytes
+    table[rank, len(WIRE_IDX)] = stats[2]                           # + this shard's size (device-side copy, no sync)
     dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)       # the one collective of the path
-    if total_batch is None:
-        total_batch = float(stats[2]) * world
     return reduce_table(table.to("cpu"), total_batch)               # device -> host (synchronises), reduced here
 
 
@@ -94,21 +104,34 @@ class StatsExchange:
         import tinympc_amd as tm
         self.s, self.total = solver, int(total_batch)
         self.world, self.rank = _world_rank(dist, group)
-        self.dist, self.group, self.comm, self.kind = dist, group, None, "native"
-        try:
-            box = [tm.rccl_unique_id() if self.rank == 0 else None]
-        except Exception as e:                       # noqa: BLE001  (rank 0 could not even draw an id: every rank must learn it)
-            box = [repr(e)]
-        dist.broadcast_object_list(box, src=0, group=group)
+        self.dist, self.group, self.comm, self.kind, self.comm_ranks = dist, group, None, "native", 0
         import os
-        ok = isinstance(box[0], (bytes, bytearray)) and os.environ.get("TINYMPC_EXCHANGE", "native") != "torch"     # (=torch: force the fallback)
+        import torch
+        # ncclCommInitRank is itself a collective: a rank that cannot take part (librccl missing on that rank only, a bad
+        # device) must say so BEFORE any rank enters it, or the others would block inside init.  So the ranks first agree,
+        # over the process group they already share, that every one of them can load RCCL and reach its device.
+        can = os.environ.get("TINYMPC_EXCHANGE", "native") != "torch"                    # (=torch: force the fallback)
+        try:
+            can = can and tm.rccl_available() and 0 <= device_index < tm.device_count()
+        except Exception:                            # noqa: BLE001
+            can = False
+        flag = torch.tensor([1.0 if can else 0.0], device=f"cuda:{device_index}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = float(flag.item()) >= 1.0
         if ok:
             try:
-                self.comm = tm.rccl_comm_init_rank(self.world, bytes(box[0]), self.rank, device_index)
-            except Exception:                        # noqa: BLE001
-                ok = False
-        # all ranks or none: a rank that could not join must not leave the others waiting inside the collective
-        import torch
+                box = [tm.rccl_unique_id() if self.rank == 0 else None]
+            except Exception as e:                   # noqa: BLE001  (rank 0 could not draw an id: every rank must learn it)
+                box = [repr(e)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ok = isinstance(box[0], (bytes, bytearray))
+            if ok:
+                try:
+                    self.comm = tm.rccl_comm_init_rank(self.world, bytes(box[0]), self.rank, device_index)
+                    self.comm_ranks = tm.rccl_comm_count(self.comm)
+                except Exception:                    # noqa: BLE001
+                    ok = False
+        # all ranks or none: a rank whose join failed must not leave the others waiting inside the all-gather
         flag = torch.tensor([1.0 if ok else 0.0], device=f"cuda:{device_index}")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if float(flag.item()) < 1.0:
