@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric on its quoted config: QP solves/s (+ ADMM iterations/s) for
-65 536 batched quadrotor-hover instances (nx=12, nu=4, N=10) per MI355X.
+65 536 batched quadrotor-hover instances (nx=12, nu=4, N=10).
 
 A "step" = ONE batched tiny_solve over the whole per-GPU batch (one MPC step of the closed loop of
 examples/quadrotor_hovering.cpp, warm-started from the previous step, plant advanced on device).
@@ -8,37 +8,50 @@ The timed region always starts from the cold state of tiny_setup, so K steps = t
 the reference's 100-step episode (K = 100 -> 882 ADMM iterations per instance).
 State is resident in HBM before timing starts.  The K-step region is repeated (cold start, barrier,
 K steps, statistics exchange, barrier) until at least --min-seconds of timed work has run; `value`
-comes from the MEDIAN repetition, min / max are reported beside it.  Multi-GPU: one process per GPU,
-batch sharded with no data-path collective (weak scaling: 65 536 instances per GPU); ONE RCCL
-all-gather of the 64-byte statistics message (tiny_batch_allreduce_stats, the library's native exchange, on a
-communicator bootstrapped over torch.distributed) closes every timed repetition.
+comes from the MEDIAN repetition, min / max are reported beside it.
+
+How it starts -- all three forms run the same code:
+  python bench.py --gpus 1 ...                             one process, one GPU
+  python bench.py --gpus N ...                             a PLAIN process: it spawns N ranks of itself with
+                                                           torch.distributed.run on 127.0.0.1 (one process per GPU) and
+                                                           passes rank 0's one JSON line through
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N ...                             the ranks are already there (RANK / WORLD_SIZE in the env)
+
+Multi-GPU: one process per GPU, the batch sharded with NO data-path collective; ONE RCCL all-gather of the 64-byte
+statistics message (tiny_batch_allreduce_stats, the library's native exchange, on a communicator bootstrapped over
+torch.distributed) closes every timed repetition.  --scaling weak (default): 65 536 instances PER GPU;
+--scaling strong: 65 536 instances in TOTAL, sharded (at 8 GPUs: 8 192 per GPU = exactly one resident wave set).
+Under weak scaling with N > 1 the strong-scaling form is measured as well, after the headline, and reported as
+`strong_scaling` in the same line.
 
 Rooflines (all in the one JSON line):
   roofline         the bound that BINDS the timed launches: FP64 VALU issue when the launches carry many
                    ADMM iterations (cold / fused steps), HBM when they are single warm steps; `traffic` = HBM
-                   bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json)
+                   bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json, `traffic_source`)
   roofline_hbm / roofline_fp64   both fractions of the timed launches, whichever binds
   regimes          an untimed replay of the reference episode with ONE launch per MPC step after the
-                   timed region: cold steps 0-4 (FP64 fraction) and steady state steps 70-99 (HBM fraction
-                   of real, algorithmic bytes -- every launch loads and stores the records)
-
-  python bench.py --gpus 1 --steps 100 --warmup 10
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-         --master-port 29500 bench.py --gpus 8 --steps 100 --warmup 10
+                   timed region: cold steps 0-4 (FP64 fraction) and steady state steps 70-99 -- `hbm_frac` counts the
+                   bytes the launch form really moves, `hbm_frac_formula` SURVEY.md 8(d)'s bytes_warm
+  configs          (1 GPU) BASELINE configs 3, 4 and six cells of config 5, each with its own roofline (tools/bench_configs.py)
+  cpu_baseline     (1 GPU) the real reference on the host cores, AFTER the GPU legs, in processes of its own
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy rate)
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (spec)
+TOTAL_BATCH = 65536          # BASELINE configs[1]
 
 
 def flops_per_iter(nx, nu, N):
@@ -62,234 +75,396 @@ def steps_per_launch(steps, warmup=0, requested=0):
     return T
 
 
+def shard_size(total, rank, world):
+    """contiguous shards of a `total`-instance batch (identical instances: nothing to balance)"""
+    base, rem = divmod(total, world)
+    return base + (1 if rank < rem else 0)
+
+
+def moved_bytes_per_solve(bytes_warm, S, nx, nu, iters, ref_shared, store_primal):
+    """Bytes one warm solve of the default launch form REALLY moves: SURVEY.md 8(d)'s bytes_warm minus what the form provably
+    skips -- the Xref|Uref read when all instances share one L2-resident record (-8S), the v|z store of a solve that converges
+    at its first check (admm.cpp:431-441 returns before v = vnew: -8S), the x|u store with store_primal = 0 (-8S) or all of it
+    but the first knot with store_primal = 2."""
+    b = bytes_warm
+    if ref_shared:
+        b -= 8 * S
+    if iters == 1:
+        b -= 8 * S
+    if store_primal == 0:
+        b -= 8 * S
+    elif store_primal == 2:
+        b -= 8 * (S - (2 * nx + nu))
+    return b
+
+
 def traffic_per_launch(T, B):
     """PMC-measured HBM bytes per launch of the solve kernel (rocprofv3 FETCH_SIZE / WRITE_SIZE passes,
-    tools/collect_profiles.py).  A launch loads and stores the records once however many MPC steps it fuses."""
+    tools/collect_profiles.py), read from profiles/traffic.json -- a citation of an earlier profiling run, not something this
+    run measures (`traffic_source` says which).  A launch loads and stores the records once however many MPC steps it fuses."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath) or B != 65536:
-        return None
+        return None, None
     try:
         t = json.load(open(tpath))
         for key in (("fused_launch", "fused_100_steps_launch") if T > 1 else ("per_step_launch",)):
             if key in t:
-                return t[key]["hbm_bytes_per_launch"]
+                return t[key]["hbm_bytes_per_launch"], "profiles/traffic.json[%s] (%s)" % (key, t[key].get("round", "r02 PMC run"))
     except Exception:
         pass
-    return None
+    return None, None
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=TOTAL_BATCH, help="instances PER GPU (weak scaling) / in TOTAL (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--grid-waves-per-cu", type=int, default=int(os.environ.get("TINYMPC_GRID_WAVES_PER_CU", "0")))
+    ap.add_argument("--dpp-mode", type=int, default=int(os.environ.get("TINYMPC_DPP_MODE", "2")))
+    ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("TINYMPC_STEPS_PER_LAUNCH", "0")),
+                    help="closed-loop MPC steps fused into one kernel launch (ADMM state stays in registers); "
+                         "0 = auto: the largest divisor of --steps that is <= 100; 1 = one launch per step")
+    ap.add_argument("--opt", action="append", default=[], help="solver option name=value (experiments)")
+    ap.add_argument("--min-seconds", type=float, default=5.0,
+                    help="repeat the timed K-step region until this much timed work has run (median reported)")
+    ap.add_argument("--max-repeats", type=int, default=5000)
+    ap.add_argument("--no-regimes", action="store_true", help="skip the untimed one-launch-per-step replay")
+    ap.add_argument("--regimes", action="store_true", help="(kept for old command lines: the replay is always on)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3 / 4 / 5-slice (1-GPU runs carry them by default)")
+    ap.add_argument("--configs-budget", type=float, default=30.0, help="seconds after which no further config entry is started")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1, weak scaling: skip the additional strong-scaling measurement")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` as a PLAIN process: start N ranks of this very script under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) and hand rank 0's one JSON line through.  Same code path as the launcher form."""
+    import tinympc_amd as tm
+    have = tm.device_count()
+    if have < args.gpus and not os.environ.get("TINYMPC_BENCH_SHARE_GPU"):
+        sys.exit("bench.py --gpus %d: this node shows %d GPU(s) (TINYMPC_BENCH_SHARE_GPU=1 lets the ranks share devices over gloo: "
+                 "a smoke run of the control flow, not a measurement)" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TINYMPC_BENCH_SELF_SPAWNED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+class Job:
+    """One rank's view of the job: device, process group, barrier, max over ranks."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # TINYMPC_BENCH_SHARE_GPU=1: smoke test of the N > 1 control flow on a box with fewer GPUs than ranks -- the ranks share
+        # the devices round-robin and talk over gloo (RCCL refuses two ranks on one device); the line it prints is not a measurement
+        self.share_gpu = bool(os.environ.get("TINYMPC_BENCH_SHARE_GPU"))
+        if self.share_gpu:
+            self.local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(self.local_rank)
+        self.dev = f"cuda:{self.local_rank}"
+        self.dist = None
+        if self.world > 1 or os.environ.get("TINYMPC_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path on one GPU
+            import torch.distributed as dist
+            self.dist = dist
+            if self.share_gpu:
+                os.environ["TINYMPC_EXCHANGE"] = "torch"
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))   # "nccl" is RCCL on ROCm
+        self.one = torch.zeros(1, device=self.dev)
+        self.stream = torch.cuda.Stream(device=self.local_rank)
+
+    def barrier(self):
+        # no rank leaves before every rank has arrived: a one-element all-reduce between two device synchronisations
+        # (dist.barrier() itself costs 0.5 ms on this stack, 25x the all-reduce: tools/dist_exchange_cost.py)
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.all_reduce(self.one)
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+class Hover:
+    """BASELINE configs[1] on this rank's shard: the solver, its cold start, the timed repetition."""
+
+    def __init__(self, job, args, B, total_batch):
+        import numpy as np
+        import tinympc_amd as tm
+        from tinympc_amd.distributed import StatsExchange
+        self.np, self.job, self.args, self.B, self.total = np, job, args, B, total_batch
+        prob, extra = tm.load_problem("quadrotor_20hz")
+        h = extra["hover"]
+        self.nx, self.nu, self.N = prob["nx"], prob["nu"], prob["N"]
+        s = self.s = tm.TinyBatchSolver.from_problem(prob, B, device=job.local_rank)
+        nx, nu, N = self.nx, self.nu, self.N
+        s.set_bound_constraints(np.full((nx, 1), h["x_min"]), np.full((nx, 1), h["x_max"]),
+                                np.full((nu, 1), h["u_min"]), np.full((nu, 1), h["u_max"]))
+        s.update_settings(max_iter=h["max_iter"])
+        s.set_option("advance_x0", 1)
+        s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
+        s.set_option("dpp_mode", args.dpp_mode)
+        for kv in args.opt:                              # experiments: --opt grid_waves_per_cu=8
+            k, v = kv.split("=")
+            s.set_option(k, int(v))
+        self.T = steps_per_launch(args.steps, args.warmup, args.steps_per_launch)
+        if self.T is None:
+            sys.exit("--steps must be a multiple of --steps-per-launch")
+        self.Tw = steps_per_launch(args.warmup) if args.warmup > 0 else 1      # the untimed warm-up steps, fused the same way on their own
+        self.launches = args.steps // self.T
+        s.set_stream(job.stream.cuda_stream)             # kernels, events and the RCCL collective share one stream
+        self.xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
+        self.x0 = np.array(h["x0"], dtype=np.float64)
+        self.stats = job.torch.zeros(10, dtype=job.torch.float64, device=job.dev)
+        self.exchange = StatsExchange(s, job.dist, job.local_rank, total_batch=total_batch) if job.dist is not None else None
+
+    def cold_start(self):
+        self.s.reset()
+        self.s.set_x_ref(self.xref, broadcast=True)
+        self.s.set_x0(self.x0, broadcast=True)
+
+    def timed_repetition(self):
+        """cold start (untimed) -> barrier -> EXACTLY --steps MPC steps + the statistics exchange -> barrier."""
+        s, job = self.s, self.job
+        self.cold_start()
+        s.set_option("timing", self.launches)            # HIP events around every timed solve kernel, on the solver's stream
+        job.barrier()
+        t0 = time.perf_counter()
+        for _ in range(self.launches):
+            s.solve_async()
+        if job.dist is not None:                         # the one exchange of the path: a 64-byte message per rank, RCCL over xGMI
+            st = self.exchange()
+        else:
+            s.reduce_stats_async(self.stats.data_ptr())
+        job.barrier()
+        elapsed = time.perf_counter() - t0
+        if job.dist is None:
+            st = self.stats.to("cpu")
+        return elapsed, st.tolist(), s.timing_ms()
+
+    def measure(self, min_seconds, warmup=True):
+        """-> dict(elapsed median, rep_s, kernel ms arrays, job-wide statistics of one repetition)"""
+        np, s, job, args = self.np, self.s, self.job, self.args
+        with job.torch.cuda.stream(job.stream):
+            if warmup:
+                self.cold_start()
+                s.set_option("steps_per_launch", self.Tw)
+                for _ in range(args.warmup // self.Tw):
+                    s.solve_async()
+                s.synchronize()
+            s.set_option("steps_per_launch", self.T)
+            if job.dist is not None:                     # first-use costs of the collective stay out of the timed region
+                self.exchange()
+                job.barrier()
+            e0, st, km = self.timed_repetition()
+            e0 = job.max_over_ranks([e0])[0]
+            repeats = int(min(max(3, -(-min_seconds // max(e0, 1e-6))), args.max_repeats))
+            rep_s, rep_kernel_ms = [e0], [km]
+            for _ in range(repeats - 1):
+                e, st, km = self.timed_repetition()
+                rep_s.append(e)
+                rep_kernel_ms.append(km)
+        rep_s = np.array(job.max_over_ranks(rep_s))      # every repetition: the slowest rank's clock
+        return dict(elapsed=float(np.median(rep_s)), rep_s=rep_s, repeats=repeats, st=st,
+                    kern_ms=np.concatenate(rep_kernel_ms), kern_first=np.array([k[0] for k in rep_kernel_ms]),
+                    kern_sum_rep=float(np.median([k.sum() for k in rep_kernel_ms])))
+
+    def close(self):
+        if self.exchange is not None:
+            self.exchange.close()
+        self.s.close()
+
+
+def regimes_replay(hv, fl, bytes_warm):
+    """Untimed replay (rank 0): the same episode with ONE launch per MPC step, so that the two regimes SURVEY.md 8(d) asks
+    for are visible in every line -- cold steps (100 ADMM iterations each, FP64 bound) and steady state (1-2 iterations:
+    every launch loads and stores the records, the real HBM roofline of this path).  Median over five replays."""
+    np, s, job, B = hv.np, hv.s, hv.job, hv.B
+    nx, nu, N = hv.nx, hv.nu, hv.N
+    S = nx * N + nu * (N - 1)
+
+    def replay(store_primal, share_ref=1):
+        runs = []
+        s.set_option("store_primal", store_primal)
+        s.set_option("share_ref", share_ref)
+        for _ in range(5):
+            hv.cold_start()
+            s.set_option("timing", 100)
+            for _ in range(100):
+                s.solve_async()
+            s.synchronize()
+            runs.append(s.timing_ms())
+        s.set_option("store_primal", 1)
+        s.set_option("share_ref", 1)
+        return np.median(np.array(runs), axis=0)
+
+    with job.torch.cuda.stream(job.stream):
+        s.set_option("steps_per_launch", 1)
+        ms = replay(1)
+        ms_own = replay(1, share_ref=0)
+        ms_lean = replay(0)
+        ms_u0 = replay(2)
+        # the iteration count of every step of the episode (all instances are identical): which launches skip the v|z store
+        hv.cold_start()
+        iters = []
+        for _ in range(100):
+            s.solve_async()
+            s.synchronize()
+            iters.append(int(s.status()["iter"][0]))
+        s.set_option("steps_per_launch", hv.T)
+    iters = np.array(iters)
+    warm_steps = slice(70, 100)
+
+    def steady(msv, ref_shared, store_primal, note):
+        t = float(msv[warm_steps].mean()) * 1e-3
+        moved = float(np.mean([moved_bytes_per_solve(bytes_warm, S, nx, nu, it, ref_shared, store_primal) for it in iters[warm_steps]]))
+        return {"steps": "70-99", "ms_per_launch": t * 1e3, "ms_per_launch_min": float(msv[warm_steps].min()),
+                "admm_iters_per_solve": float(iters[warm_steps].mean()),
+                "bytes_moved_per_solve": moved, "algorithmic_bytes_per_solve": bytes_warm,
+                "hbm_gbs": moved * B / t / 1e9, "hbm_frac": moved * B / t / 1e9 / HBM_PEAK_GBS,
+                "hbm_frac_formula": bytes_warm * B / t / 1e9 / HBM_PEAK_GBS, "note": note}
+
+    cold = float(ms[:5].mean()) * 1e-3
+    return {
+        "cold": {"steps": "0-4", "admm_iters_per_solve": float(iters[:5].mean()), "ms_per_launch": cold * 1e3,
+                 "fp64_tflops": float(iters[:5].mean()) * B * fl / cold / 1e12,
+                 "fp64_frac": float(iters[:5].mean()) * B * fl / cold / 1e12 / FP64_PEAK_TFLOPS},
+        "steady_state": steady(ms, True, 1,
+                               "one launch per MPC step, the default form.  hbm_frac counts the bytes this form moves: bytes_warm = "
+                               "8(nx+8S)+44 (SURVEY.md 8(d)) minus the Xref|Uref read (config 2's instances share ONE L2-resident "
+                               "reference record) and minus the v|z store of a solve that converges at its first check (admm.cpp:431-441 "
+                               "returns before v = vnew); hbm_frac_formula divides the full bytes_warm by the same time"),
+        "steady_state_per_instance_refs": steady(ms_own, False, 1,
+                                                 "option share_ref = 0: every instance reads its OWN reference record, what any "
+                                                 "non-identical batch needs -- the general warm-step figure of this path"),
+        "steady_state_no_primal_store": steady(ms_lean, True, 0,
+                                               "option store_primal = 0: x|u is not written back either (no consumer between steps when "
+                                               "the plant step runs on the device; solution->x|u = vnew|znew is still stored)"),
+        "steady_state_first_knot_store": steady(ms_u0, True, 2,
+                                                "option store_primal = 2: of x|u only x[:,0], x[:,1], u[:,0] are written (the control a "
+                                                "closed-loop caller applies)"),
+        "iters_per_step": iters.tolist(),
+    }
+
+
+def cpu_baseline_subprocess(seconds, steps):
+    """The real reference on every host core (oracle/cpu_baseline.py), in processes of its own AFTER the GPU legs: the GPU
+    phase then sits at the START of the run (the driver's sparse gpu_busy sampler sees it) and no HIP context is forked."""
+    code = ("import sys, json; sys.path.insert(0, %r); import cpu_baseline; "
+            "print('@@CPU@@' + json.dumps(cpu_baseline.run(seconds=%r, steps=%r)))" % (os.path.join(ROOT, "oracle"), seconds, steps))
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=max(120.0, 20 * seconds))
+        for line in p.stdout.splitlines():
+            if line.startswith("@@CPU@@"):
+                return json.loads(line[7:])
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    except Exception as e:                               # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def main():
+    args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL across ranks)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     # stdout carries exactly ONE line, the result JSON: libraries that chat on fd 1 (RCCL prints a version banner at
     # communicator creation) are pointed at stderr for the whole run
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=65536, help="instances PER GPU")
-    ap.add_argument("--grid-waves-per-cu", type=int, default=int(os.environ.get("TINYMPC_GRID_WAVES_PER_CU", "0")))
-    ap.add_argument("--dpp-mode", type=int, default=int(os.environ.get("TINYMPC_DPP_MODE", "2")))
-    ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("TINYMPC_STEPS_PER_LAUNCH", "0")),
-                    help="closed-loop MPC steps fused into one kernel launch (ADMM state stays in registers); "
-                         "0 = auto: the largest divisor of --steps and --warmup that is <= 100; 1 = one launch per step")
-    ap.add_argument("--opt", action="append", default=[], help="solver option name=value (experiments)")
-    ap.add_argument("--min-seconds", type=float, default=1.0,
-                    help="repeat the timed K-step region until this much timed work has run (median reported)")
-    ap.add_argument("--max-repeats", type=int, default=2000)
-    ap.add_argument("--no-regimes", action="store_true", help="skip the untimed one-launch-per-step replay")
-    ap.add_argument("--regimes", action="store_true", help="(kept for old command lines: the replay is always on)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
-    args = ap.parse_args()
-
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL across ranks)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-
-    # CPU baseline first (rank 0, N=1 only), before any HIP context exists in this process: the real reference on
-    # every host core, the SAME workload as the timed region (the first --steps MPC steps of the episode from cold)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import cpu_baseline
-        cpu = cpu_baseline.run(seconds=args.cpu_seconds, steps=args.steps)
+    t_start = time.perf_counter()
 
     import numpy as np
     import torch
     import tinympc_amd as tm
-    from tinympc_amd.distributed import StatsExchange
 
     if not torch.cuda.is_available() or tm.device_count() == 0:
         sys.exit("bench.py needs an MI355X: tinympc_amd has no CPU fallback")
-    # TINYMPC_BENCH_SHARE_GPU=1: smoke test of the N > 1 control flow on a box with fewer GPUs than ranks -- the ranks share
-    # the devices round-robin and talk over gloo (RCCL refuses two ranks on one device); the line it prints is not a measurement
-    share_gpu = bool(os.environ.get("TINYMPC_BENCH_SHARE_GPU"))
-    if share_gpu:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("TINYMPC_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path on one GPU
-        import torch.distributed as dist
-        if share_gpu:
-            os.environ["TINYMPC_EXCHANGE"] = "torch"
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
-
-    prob, extra = tm.load_problem("quadrotor_20hz")
-    h = extra["hover"]
-    nx, nu, N, B = prob["nx"], prob["nu"], prob["N"], args.batch
-    s = tm.TinyBatchSolver.from_problem(prob, B, device=local_rank)
-    s.set_bound_constraints(np.full((nx, 1), h["x_min"]), np.full((nx, 1), h["x_max"]),
-                            np.full((nu, 1), h["u_min"]), np.full((nu, 1), h["u_max"]))
-    s.update_settings(max_iter=h["max_iter"])
-    s.set_option("advance_x0", 1)
-    s.set_option("grid_waves_per_cu", args.grid_waves_per_cu)
-    s.set_option("dpp_mode", args.dpp_mode)
-    for kv in args.opt:                              # experiments: --opt grid_waves_per_cu=8
-        k, v = kv.split("=")
-        s.set_option(k, int(v))
-    T = steps_per_launch(args.steps, args.warmup, args.steps_per_launch)
-    if T is None:
-        sys.exit("--steps must be a multiple of --steps-per-launch")
-    Tw = steps_per_launch(args.warmup) if args.warmup > 0 else 1      # the untimed warm-up steps, fused the same way on their own
-    s.set_option("steps_per_launch", T)
-    launches = args.steps // T
-    stream = torch.cuda.Stream(device=local_rank)
-    s.set_stream(stream.cuda_stream)                 # kernels, events and the RCCL collective share one stream
-    xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
-    x0 = np.array(h["x0"], dtype=np.float64)
-    dev = f"cuda:{local_rank}"
-    stats = torch.zeros(10, dtype=torch.float64, device=dev)
-
-    def cold_start():
-        s.reset()
-        s.set_x_ref(xref, broadcast=True)
-        s.set_x0(x0, broadcast=True)
-
-    one = torch.zeros(1, device=dev)
-    exchange = StatsExchange(s, dist, local_rank, total_batch=world * B) if dist is not None else None
-
-    def barrier():
-        # no rank leaves before every rank has arrived: a one-element all-reduce between two device synchronisations
-        # (dist.barrier() itself costs 0.5 ms on this stack, 25x the all-reduce: tools/dist_exchange_cost.py)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.all_reduce(one)
-        torch.cuda.synchronize()
-
-    def max_over_ranks(values):
-        if dist is None:
-            return list(values)
-        t = torch.tensor(list(values), dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.tolist()
-
-    def timed_repetition():
-        """cold start (untimed) -> barrier -> EXACTLY --steps MPC steps + the statistics exchange -> barrier."""
-        cold_start()
-        s.set_option("timing", launches)             # HIP events around every timed solve kernel, on `stream`
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(launches):
-            s.solve_async()
-        if dist is not None:                         # the one exchange of the path: a 64-byte message per rank, RCCL over xGMI
-            st = exchange()
-        else:
-            s.reduce_stats_async(stats.data_ptr())
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is None:
-            st = stats.to("cpu")
-        return elapsed, st.tolist(), s.timing_ms()
-
-    with torch.cuda.stream(stream):
-        cold_start()
-        s.set_option("steps_per_launch", Tw)
-        for _ in range(args.warmup // Tw):
-            s.solve_async()
-        s.synchronize()
-        s.set_option("steps_per_launch", T)
-        if dist is not None:                         # first-use costs of the collective stay out of the timed region
-            exchange()
-            barrier()
-        e0, st, km = timed_repetition()
-        e0 = max_over_ranks([e0])[0]
-        repeats = int(min(max(3, -(-args.min_seconds // max(e0, 1e-6))), args.max_repeats))
-        rep_s, rep_kernel_ms = [e0], [km]
-        for _ in range(repeats - 1):
-            e, st, km = timed_repetition()
-            rep_s.append(e)
-            rep_kernel_ms.append(km)
-    rep_s = np.array(max_over_ranks(rep_s))          # every repetition: the slowest rank's clock
-    elapsed = float(np.median(rep_s))
+    job = Job(args)
+    rank, world = job.rank, job.world
+    args.gpus = world
+    strong = args.scaling == "strong"
+    B = shard_size(args.batch, rank, world) if strong else args.batch
+    total = args.batch if strong else world * args.batch
+    hv = Hover(job, args, B, total)
+    nx, nu, N, T, launches = hv.nx, hv.nu, hv.N, hv.T, hv.launches
+    m = hv.measure(args.min_seconds)
+    elapsed, rep_s, st = m["elapsed"], m["rep_s"], m["st"]
     acc_iters, acc_solved, max_resid = st[7], st[8], st[3:7]        # job-wide, one repetition (each starts with a reset)
-    kern_ms = np.concatenate(rep_kernel_ms)          # this rank's solve-kernel durations, all repetitions
-    kern_first = np.array([k[0] for k in rep_kernel_ms])
-    kern_sum_rep = float(np.median([k.sum() for k in rep_kernel_ms]))
-
-    # Untimed replay (rank 0): the same episode with ONE launch per MPC step, so that the two regimes SURVEY.md 8(d) asks
-    # for are visible in every line -- cold steps (100 ADMM iterations each, FP64 bound) and steady state (1-2 iterations:
-    # every launch loads and stores the records, the real HBM roofline of this path).  Median over five replays.
-    regimes = None
+    kern_ms, kern_sum_rep = m["kern_ms"], m["kern_sum_rep"]
     fl = flops_per_iter(nx, nu, N)
-    bytes_warm = s.algorithmic_bytes(cold=False)
+    bytes_warm = hv.s.algorithmic_bytes(cold=False)
+
+    regimes = None
     if rank == 0 and not args.no_regimes:
-        def replay(store_primal):
-            runs = []
-            s.set_option("store_primal", store_primal)
-            for _ in range(5):
-                cold_start()
-                s.set_option("timing", 100)
-                for _ in range(100):
-                    s.solve_async()
-                s.synchronize()
-                runs.append(s.timing_ms())
-            s.set_option("store_primal", 1)
-            return np.median(np.array(runs), axis=0)
-        with torch.cuda.stream(stream):
-            s.set_option("steps_per_launch", 1)
-            ms = replay(1)
-            ms_lean = replay(0)
-            ms_u0 = replay(2)
-            s.set_option("steps_per_launch", T)
-        S = nx * N + nu * (N - 1)
-        cold = float(ms[:5].mean()) * 1e-3
-        warm = float(ms[70:].mean()) * 1e-3
-        lean = float(ms_lean[70:].mean()) * 1e-3
-        first = float(ms_u0[70:].mean()) * 1e-3
-        regimes = {
-            "cold": {"steps": "0-4", "admm_iters_per_solve": 100, "ms_per_launch": cold * 1e3,
-                     "fp64_tflops": 100 * B * fl / cold / 1e12, "fp64_frac": 100 * B * fl / cold / 1e12 / FP64_PEAK_TFLOPS},
-            "steady_state": {"steps": "70-99", "ms_per_launch": warm * 1e3, "ms_per_launch_min": float(ms[70:].min()),
-                             "algorithmic_bytes_per_solve": bytes_warm,
-                             "hbm_gbs": bytes_warm * B / warm / 1e9, "hbm_frac": bytes_warm * B / warm / 1e9 / HBM_PEAK_GBS,
-                             "note": "one launch per MPC step; bytes_warm = 8(nx+8S)+44 per solve (SURVEY.md 8(d)) / launch time; a "
-                                     "solve that converges at its first check does not store v|z again (admm.cpp:431-441 returns "
-                                     "before v = vnew), so the bytes really moved are up to 8S = %d B per solve lower" % (8 * S)},
-            "steady_state_lean": {"steps": "70-99", "ms_per_launch": lean * 1e3, "ms_per_launch_min": float(ms_lean[70:].min()),
-                                  "hbm_gbs": bytes_warm * B / lean / 1e9, "hbm_frac": bytes_warm * B / lean / 1e9 / HBM_PEAK_GBS,
-                                  "bytes_moved_per_solve_max": bytes_warm - 8 * S,
-                                  "first_knot_only": {"ms_per_launch": first * 1e3, "hbm_frac": bytes_warm * B / first / 1e9 / HBM_PEAK_GBS,
-                                                      "note": "store_primal = 2: x[:,0], x[:,1], u[:,0] are still written (the control a caller applies)"},
-                                  "note": "option store_primal = 0: x|u is not written back either (no consumer between steps: the "
-                                          "plant step runs on the device, solution->x|u = vnew|znew is still stored); the figure is "
-                                          "still bytes_warm / launch time, i.e. solves/s in the formula's units"}}
-    solves = float(world) * B * args.steps
+        regimes = regimes_replay(hv, fl, bytes_warm)
+    exchange_kind = hv.exchange.kind if hv.exchange is not None else "none (one rank)"
+    # ranks of the communicator the exchange really ran on: asked of RCCL (ncclCommCount) on the native path, of the process group
+    # when the exchange went through torch.distributed (`stats_exchange` says which)
+    if hv.exchange is None:
+        rccl_ranks = 1
+    elif hv.exchange.kind == "native":
+        rccl_ranks = hv.exchange.comm_ranks
+    else:
+        rccl_ranks = job.dist.get_world_size()
+    hv.close()
+
+    # N > 1 under weak scaling: the strong-scaling form of the metric as well (65 536 instances in TOTAL, sharded)
+    strong_extra = None
+    if world > 1 and not strong and not args.no_strong:
+        hs = Hover(job, args, shard_size(args.batch, rank, world), args.batch)
+        ms_ = hs.measure(min(args.min_seconds, 2.0))
+        sst = ms_["st"]
+        strong_extra = {"total_batch": args.batch, "batch_this_rank": hs.B, "value": args.batch * args.steps / ms_["elapsed"], "unit": "QP solves/s",
+                        "ms_per_step": ms_["elapsed"] / args.steps * 1e3, "admm_iters_per_s": sst[7] / ms_["elapsed"], "repeats": ms_["repeats"],
+                        "kernel_ms_sum_per_repetition": ms_["kern_sum_rep"],
+                        "note": "the same timed region with 65 536 instances in TOTAL, sharded over the ranks (BASELINE: '64k-batch ... 1/2/4/8 GPU')"}
+        hs.close()
+
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        import bench_configs
+        configs = bench_configs.run_all(device=job.local_rank, budget_s=args.configs_budget,
+                                        log=lambda msg: print(msg, file=sys.stderr, flush=True))
+    gpu_phase_s = time.perf_counter() - t_start
+
+    # CPU baseline LAST (rank 0, N = 1 only): the real reference on every host core, the SAME workload as the timed region
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_subprocess(args.cpu_seconds, args.steps)
+
+    solves = float(total) * args.steps
     value = solves / elapsed
     avg_kernel_s = float(kern_ms.mean()) * 1e-3
     # real HBM bytes of one launch: the records are loaded and stored once however many MPC steps it fuses
     hbm_gbs = bytes_warm * B / avg_kernel_s / 1e9
-    iters_local = acc_iters / world                  # one repetition, this GPU
+    iters_local = acc_iters * (B / float(total))     # one repetition, this GPU (identical instances)
     fp64_tflops = iters_local * fl / (kern_sum_rep * 1e-3) / 1e12
-    traffic = traffic_per_launch(T, B)
-    common = {"traffic": traffic, "kernel": "admm_solve_kernel<12,4,10>", "avg_launch_ms": avg_kernel_s * 1e3,
+    traffic, traffic_source = traffic_per_launch(T, B)
+    common = {"traffic": traffic, "traffic_source": traffic_source, "kernel": "admm_solve_kernel<12,4,10>", "avg_launch_ms": avg_kernel_s * 1e3,
               "launches_per_repetition": launches, "mpc_steps_per_launch": T}
     roofline_hbm = dict({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": bytes_warm * B,
@@ -302,18 +477,21 @@ def main():
                          **common)
     binding = roofline_fp64 if roofline_fp64["frac"] >= roofline_hbm["frac"] else roofline_hbm
     if rank == 0:
+        per = "%d identical instances %s" % (args.batch, "in total, sharded" if strong else "per GPU")
         out = {
             "metric": "QP solves/sec (+ ADMM iters/sec), 64k-batch quadrotor hover",
             "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "quadrotor_hovering (nx=12, nu=4, N=10), 65536 identical instances per GPU, "
-                                   "closed-loop MPC steps from a cold start (BASELINE configs[1])",
-                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}",
+            "config": {"workload": "quadrotor_hovering (nx=12, nu=4, N=10), %s, closed-loop MPC steps from a cold start "
+                                   "(BASELINE configs[1])" % per,
+                       "batch_per_gpu": B, "total_batch": total, "parallelism": f"batch-sharded x{world}",
                        "grid_waves_per_cu": args.grid_waves_per_cu, "dpp_mode": args.dpp_mode,
-                       "mpc_steps_per_launch": T,
-                       "stats_exchange": (exchange.kind if exchange is not None else "none (one rank)")},
-            "timed_region": {"repeats": int(repeats), "seconds_total": float(rep_s.sum()),
+                       "mpc_steps_per_launch": T, "stats_exchange": exchange_kind,
+                       "launcher": ("self-spawned torch.distributed.run" if os.environ.get("TINYMPC_BENCH_SELF_SPAWNED") else
+                                    ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "plain process"))},
+            "rccl_ranks": rccl_ranks,
+            "timed_region": {"repeats": int(m["repeats"]), "seconds_total": float(rep_s.sum()),
                              "ms": {"median": elapsed * 1e3, "min": float(rep_s.min()) * 1e3, "max": float(rep_s.max()) * 1e3},
                              "value_min": solves / float(rep_s.max()), "value_max": solves / float(rep_s.min()),
                              "note": "each repetition = cold start (untimed), barrier, exactly --steps MPC steps + the statistics "
@@ -325,22 +503,23 @@ def main():
             "roofline": binding,
             "roofline_hbm": roofline_hbm,
             "roofline_fp64": roofline_fp64,
-            "kernel_ms": {"first_launch_median": float(np.median(kern_first)), "sum_per_repetition_median": kern_sum_rep,
+            "kernel_ms": {"first_launch_median": float(np.median(m["kern_first"])), "sum_per_repetition_median": kern_sum_rep,
                           "min": float(kern_ms.min()), "max": float(kern_ms.max()), "count": int(kern_ms.size)},
+            "gpu_phase_seconds": gpu_phase_s,
         }
-        if share_gpu:
+        if job.share_gpu:
             out["data"] = "synthetic; SMOKE RUN: %d ranks share %d GPU(s) over gloo -- not a measurement" % (world, torch.cuda.device_count())
+        if strong_extra is not None:
+            out["strong_scaling"] = strong_extra
         if regimes is not None:
             out["regimes"] = regimes
+        if configs is not None:
+            out["configs"] = configs
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if exchange is not None:
-        exchange.close()
-    s.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

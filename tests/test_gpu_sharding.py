@@ -74,6 +74,70 @@ def test_bench_control_flow_with_two_ranks_on_this_gpu():
     assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_plain_process_spawns_its_own_ranks_weak_and_strong():
+    """`python3 bench.py --gpus 2 ...` as a PLAIN process (no launcher in front of it) starts its own two
+    ranks, emits exactly one JSON line, and carries the strong-scaling form of the metric (65 536-style total batch sharded
+    over the ranks) beside the weak one; --scaling strong makes that form the headline."""
+    import json
+    import subprocess
+    env = dict(os.environ, TINYMPC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-regimes",
+            "--min-seconds", "0.05", "--batch", "8192"]
+    p = subprocess.run(base, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["launcher"] == "self-spawned torch.distributed.run"
+    assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["total_batch"] == 16384 and d["rccl_ranks"] == 2
+    assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9
+    ss = d["strong_scaling"]
+    assert ss["total_batch"] == 8192 and ss["batch_this_rank"] == 4096
+    assert abs(ss["value"] - 8192 * 20 / (ss["ms_per_step"] * 20 * 1e-3)) < 1e-6 * ss["value"]
+    p = subprocess.run(base + ["--scaling", "strong"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 4096 and d["config"]["total_batch"] == 8192 and "strong_scaling" not in d
+    assert abs(d["value"] - 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9
+
+
+def test_bench_line_carries_the_other_configs_and_honest_hbm_fields():
+    """the 1-GPU line holds `configs` (BASELINE configs 3, 4 and six sweep cells, each with a
+    roofline that recomputes from its own fields), `regimes` with hbm_frac from the bytes really moved next to the formula
+    figure and the per-instance-reference regime, `traffic_source`, and the CPU baseline measured AFTER the GPU legs."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.3", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["launcher"] == "plain process"
+    assert d["roofline"]["traffic_source"] is None or "traffic.json" in d["roofline"]["traffic_source"]
+    cf = d["configs"]
+    assert set(cf) == {"config3", "config4", "sweep_4_2_10", "sweep_12_4_30", "sweep_4_2_50", "sweep_12_8_30", "sweep_20_8_10", "sweep_20_8_50"}
+    for name, e in cf.items():
+        assert "error" not in e and "skipped" not in e, (name, e)
+        r = e["roofline"]
+        assert abs(r["frac"] - e["iters"] * r["flops_per_iter"] / (e["ms"] * 1e-3) / (r["peak"] * 1e12)) < 1e-12 + 1e-9 * r["frac"], name
+        assert abs(e["solves_per_s"] - e["solves"] / (e["ms"] * 1e-3)) < 1e-6 * e["solves_per_s"]
+    assert cf["config3"]["solves"] == 262144 and cf["config4"]["solves"] == 65536 * 90 and cf["sweep_20_8_50"]["kernel"] == "tile"
+    rg = d["regimes"]
+    for k in ("steady_state", "steady_state_per_instance_refs", "steady_state_no_primal_store", "steady_state_first_knot_store"):
+        assert rg[k]["bytes_moved_per_solve"] <= rg[k]["algorithmic_bytes_per_solve"] and rg[k]["hbm_frac"] <= rg[k]["hbm_frac_formula"] + 1e-12
+    assert rg["steady_state_per_instance_refs"]["bytes_moved_per_solve"] > rg["steady_state"]["bytes_moved_per_solve"]
+    assert sum(rg["iters_per_step"]) == 882                            # the reference's 100-step hover episode, SURVEY.md 8(c)
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
+    assert d["gpu_phase_seconds"] > 0
+
+
 def test_sharded_sweep_driver_counts_what_the_single_process_counts(tmp_path):
     """tools/sweep_bench.py (BASELINE configs[4]) under torch.distributed.run with two ranks sharing this GPU: the cell's
     batch is dealt round-robin to the ranks, every rank draws the same seeded inputs and keeps its own instances -- the

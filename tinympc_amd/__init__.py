@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -68,11 +69,32 @@ class TinyMPCError(RuntimeError):
     pass
 
 
-def build(force: bool = False) -> str:
-    """Compile libtinympc_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if force and os.path.exists(LIB_PATH):
-        os.remove(LIB_PATH)
+def build(force: bool = False, report=None) -> str:
+    """Compile libtinympc_amd.so for gfx950 with hipcc (cross-compiles without a GPU).  make decides by mtime which
+    translation units are stale; what it did is reported -- every object either REBUILT by this call or REUSED (up to date) --
+    on `report` (a callable taking one line; default: stderr) and kept in csrc/_gen/build_report.json, so that a build check can
+    tell a fresh compile from a shipped library.  force (or TINYMPC_AMD_BUILD_FORCE=1): `make clean` first."""
+    import glob
+    import json
+    import time
+    say = report or (lambda line: print(line, file=sys.stderr, flush=True))
+    force = force or bool(os.environ.get("TINYMPC_AMD_BUILD_FORCE"))
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    watched = lambda: {p: os.path.getmtime(p) for p in glob.glob(os.path.join(CSRC, "_gen", "*.o")) + ([LIB_PATH] if os.path.exists(LIB_PATH) else [])}
+    before, t0 = watched(), time.time()
     subprocess.check_call(["make", "-C", CSRC, "-j", str(min(16, os.cpu_count() or 1))], stdout=subprocess.DEVNULL)
+    after = watched()
+    rebuilt = sorted(os.path.basename(p) for p, m in after.items() if before.get(p) != m)
+    reused = sorted(os.path.basename(p) for p, m in after.items() if before.get(p) == m)
+    mode = "forced full rebuild" if force else ("rebuilt" if len(reused) == 0 else ("incremental" if rebuilt else "reused (every object up to date)"))
+    say("tinympc_amd.build: %s -- %d object(s) compiled now%s, %d reused, %.1f s" %
+        (mode, len(rebuilt), (" (" + ", ".join(rebuilt[:8]) + (", ..." if len(rebuilt) > 8 else "") + ")") if rebuilt else "", len(reused), time.time() - t0))
+    try:
+        with open(os.path.join(CSRC, "_gen", "build_report.json"), "w") as f:
+            json.dump({"build_mode": mode, "rebuilt": rebuilt, "reused": reused, "seconds": time.time() - t0, "when": time.time()}, f, indent=1)
+    except OSError:
+        pass
     return LIB_PATH
 
 

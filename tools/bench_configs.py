@@ -1,0 +1,175 @@
+"""The other BASELINE configs as entries of bench.py's one JSON line: after the timed region of
+config 2, rank 0 of a 1-GPU run times -- untimed by the headline, HIP events on the solver's stream --
+
+  config3   quadrotor_tracking (12,4,10) x 262 144, per-instance random references (SURVEY.md 8(d) recipe), ONE cold solve
+            (reference workload: examples/quadrotor_tracking.cpp:77-106)
+  config4   rocket_landing (6,3,10) x 65 536, input second-order cone on, the 90-step closed loop fused into one launch
+            (examples/rocket_landing_mpc.cpp:94-135)
+  sweep_*   six cells of the config-5 sweep x 131 072, one cold solve each (tools/sweep_bench.py runs all 36)
+
+Every entry carries what its roofline fraction is made of: frac == iters * flops_per_iter / (ms * 1e-3) / (peak * 1e12).
+The inputs are the recipes of tools/config_bench.py / tools/sweep_bench.py (same seeds); the reference / initial-state
+arrays are expanded along the horizon ON the device (torch) instead of being built as GB-sized host arrays.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tinympc_amd as tm  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
+SWEEP_CELLS = ((4, 2, 10), (12, 4, 30), (4, 2, 50), (12, 8, 30), (20, 8, 10), (20, 8, 50))
+
+
+def _entry(workload, ms, solves, iters, nx, nu, N, bytes_per_solve, kernel, **extra):
+    fl = tm.flops_per_iter(nx, nu, N)
+    t = ms * 1e-3
+    tf = iters * fl / t / 1e12
+    e = dict(workload=workload, kernel=kernel, ms=ms, solves=int(solves), iters=int(iters), solves_per_s=solves / t, iters_per_s=iters / t,
+             iters_per_solve=iters / solves,
+             roofline=dict(bound="fp64-valu", frac=tf / FP64_PEAK_TFLOPS, achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                           flops_per_iter=fl, flops=iters * fl,
+                           note="frac = iters x flops_per_iter / (ms x 1e-3) / (peak x 1e12); flops_per_iter = SURVEY.md 8 footnote 1 (box iteration)"),
+             hbm=dict(algorithmic_bytes_per_solve=int(bytes_per_solve), gbs=bytes_per_solve * solves / t / 1e9,
+                      frac_formula=bytes_per_solve * solves / t / 1e9 / HBM_PEAK_GBS))
+    e.update(extra)
+    return e
+
+
+def _cold_solves(s, n, stream_sync=True):
+    """n cold solves of the batch as it stands (reset -> solve), kernel time of each from HIP events on the solver's stream"""
+    ms = []
+    for _ in range(n):
+        s.reset()
+        s.set_option("timing", 1)
+        s.solve_async()
+        ms.append(float(np.sum(s.timing_ms())))
+    return ms
+
+
+def config3(B=262144, device=0):
+    import torch
+    prob, extra = tm.load_problem("quadrotor_20hz")
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    traj = np.array(extra["y_axis_line"])
+    rng = np.random.default_rng(20260923)
+    k = rng.integers(0, 291, B)
+    Xref = traj[k[:, None] + np.arange(N)[None, :]].transpose(0, 2, 1) + rng.normal(0, 0.05, (B, nx, N))
+    Uref = rng.normal(0, 0.05, (B, nu, N - 1))
+    x0 = Xref[:, :, 0].copy()
+    x0[:, :3] += rng.normal(0, 0.1, (B, 3))
+    s = tm.TinyBatchSolver.from_problem(prob, B, device=device)
+    s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+    s.update_settings(max_iter=100)
+    s.set_x_ref(Xref)
+    s.set_u_ref(Uref)
+    s.set_x0(x0)
+    s.set_option("repack_after", 0)                   # the plain launch
+    plain = min(_cold_solves(s, 3))
+    st = s.reduce_stats()
+    s.set_option("repack_after", -1)                  # the default: automatic split (histogram -> K, kept if the clock confirms it)
+    auto = _cold_solves(s, 8)
+    st2 = s.reduce_stats()
+    assert st2[0] == st[0] and st2[1] == st[1], "the split solve must reproduce the plain one"
+    best = min(min(auto[4:]), plain)
+    e = _entry("quadrotor_tracking (12,4,10) x %d, per-instance random Xref/Uref, one cold solve (BASELINE configs[2])" % B,
+               best, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(),
+               plain_launch_ms=plain, automatic_split_ms=min(auto[4:]), automatic_split_k=s.get_option("auto_split_k"),
+               automatic_split_verdict=s.get_option("auto_split_verdict"), solved_fraction=st[1] / B)
+    s.close()
+    del torch
+    return e
+
+
+def config4(B=65536, device=0):
+    prob, extra = tm.load_problem("rocket_landing_20hz")
+    m = extra["mpc"]
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    rng = np.random.default_rng(20260923)
+    x0 = 1.1 * np.array(m["xinit"]) * (1 + 0.05 * rng.uniform(-1, 1, (B, nx)))
+    xinit, xg = np.array(m["xinit"], dtype=float), np.array(m["xg"], dtype=float)
+    traj = np.stack([xinit + (xg - xinit) * float(i) / (m["NTOTAL"] - 1) for i in range(m["NTOTAL"])])
+    s = tm.TinyBatchSolver.from_problem(prob, B, device=device)
+    s.set_bound_constraints(np.array(m["x_min"]), np.array(m["x_max"]), np.full((nu, 1), m["u_min"]), np.full((nu, 1), m["u_max"]))
+    s.set_cone_constraints(m["state_cone"]["A"], m["state_cone"]["q"], m["state_cone"]["c"],
+                           m["input_cone"]["A"], m["input_cone"]["q"], m["input_cone"]["c"])
+    s.update_settings(abs_pri_tol=m["abs_pri_tol"], max_iter=m["max_iter"], en_input_soc=1)
+    uref = np.zeros((nu, N - 1)); uref[2, :] = m["uref_z"]
+    steps = m["NTOTAL"] - N
+    s.set_option("advance_x0", 1)
+    s.set_option("steps_per_launch", steps)
+    ms, st = [], None
+    for _ in range(3):
+        s.reset()
+        s.set_u_ref(uref, broadcast=True)
+        s.set_reference_trajectory(traj)              # examples/rocket_landing_mpc.cpp:111-113 (window k .. k+N-1)
+        s.set_x0(x0)
+        s.set_option("timing", 1)
+        s.solve_async()
+        ms.append(float(np.sum(s.timing_ms())))
+        st = s.reduce_stats()
+    S = nx * N + nu * (N - 1)
+    e = _entry("rocket_landing (6,3,10) x %d, input second-order cone on, %d-step closed loop fused into one launch (BASELINE configs[3])" % (B, steps),
+               min(ms), B * steps, st[7], nx, nu, N, s.algorithmic_bytes() + 8 * 3 * nu * (N - 1), s.kernel_path(),
+               solved_fraction=st[8] / (B * steps), mpc_steps_per_launch=steps,
+               note="flops_per_iter counts the box iteration only (the cone projection's sqrt / divisions are extra work, not extra credit); "
+                    "bytes: bytes_warm + the cone slack records, once per LAUNCH (S = %d)" % S)
+    e["hbm"]["gbs"] /= steps                           # the records move once per launch, not once per fused step
+    e["hbm"]["frac_formula"] /= steps
+    s.close()
+    return e
+
+
+def sweep_cell(nx, nu, N, B=131072, device=0):
+    import torch
+    prob, rng = tm.random_problem(nx, nu, N)
+    s = tm.TinyBatchSolver.from_problem(prob, B, device=device)
+    s.set_bound_constraints(np.full((nx, 1), -1e17), np.full((nx, 1), 1e17), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+    s.update_settings(max_iter=500)
+    x0 = rng.uniform(-1, 1, (B, nx))                  # the same draws as tools/sweep_bench.py
+    xr = rng.uniform(-0.2, 0.2, (B, nx, 1))
+    s.set_x0(x0)
+    # Xref = the instance's vector replicated along the horizon: expanded on the device into the [batch][cols][rows] layout
+    dev = torch.device("cuda", device)
+    xr_d = torch.from_numpy(np.ascontiguousarray(xr[:, :, 0])).to(dev)[:, None, :].expand(B, N, nx).contiguous()
+    torch.cuda.synchronize(dev)
+    s.set_device("Xref", xr_d.data_ptr())
+    s.synchronize()
+    del xr_d
+    ms = _cold_solves(s, 3)
+    st = s.reduce_stats()
+    e = _entry("random sweep cell (nx=%d, nu=%d, N=%d) x %d, one cold solve, max_iter 500 (BASELINE configs[4])" % (nx, nu, N, B),
+               min(ms), B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B,
+               automatic_split_k=s.get_option("auto_split_k"))
+    s.close()
+    return e
+
+
+def run_all(device=0, budget_s=30.0, log=None):
+    """-> {"config3": ..., "config4": ..., "sweep_4_2_10": ...}; an entry that fails is reported as {"error": ...}, entries that
+    would start after the budget is spent as {"skipped": ...} (the bench line must appear whatever happens here)"""
+    out, t0 = {}, time.perf_counter()
+    jobs = [("config3", lambda: config3(device=device)), ("config4", lambda: config4(device=device))]
+    jobs += [("sweep_%d_%d_%d" % c, (lambda c=c: sweep_cell(*c, device=device))) for c in SWEEP_CELLS]
+    for name, fn in jobs:
+        if time.perf_counter() - t0 > budget_s:
+            out[name] = {"skipped": "time budget of %.0f s spent" % budget_s}
+            continue
+        t1 = time.perf_counter()
+        try:
+            out[name] = fn()
+            out[name]["wall_s_incl_setup"] = time.perf_counter() - t1
+        except Exception as e:                         # noqa: BLE001
+            out[name] = {"error": repr(e)}
+        if log:
+            log("configs: %s done in %.1f s" % (name, time.perf_counter() - t1))
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run_all(log=lambda m: print(m, file=sys.stderr)), indent=1))

@@ -60,6 +60,9 @@ for stage in "$@"; do
         timeout 600 rocprofv3 --kernel-trace $pmc --output-format csv -d $R/$O/$name -o cfg4 -- python $R/tools/config_bench.py /dev/null config4 > $R/$O/${name}_cfg4.out 2> $R/$O/${name}_cfg4.err
       done
       cd $R; python tools/kernel_counters.py $O > $O/kernel_counters.md; cat $O/kernel_counters.md ;;
+    bench3)
+      # round 3: the driver's command (plain process, defaults of the new line: regimes, configs, CPU baseline last)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; echo "rc=$?"; tail -c 600 $O/bench_driver_flags.json; echo; tail -5 $O/bench_driver_flags.err ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
