@@ -57,9 +57,26 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
     return acc;
 }
 
-// two waves per SIMD when the five L-long arrays + the matrix rows fit 256 VGPRs
-constexpr int tile_waves_per_simd(int nx, int nu, int n, int r) {
-    return (2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 276) ? 2 : 1;   // measured: (12,8,30) at 274 gains, (20,2,30) at 282 loses to spills
+// LM (round 3): which per-lane arrays leave the register file.  bit 0: QX (the linear-cost constants, written once per solve, read
+// once per backward step); bit 1: Dn (-d | fdyn, written by a backward step, read by the forward step of the same slot); bit 2: the
+// x|u trajectory is not kept at all -- the sweep only needs its rolling value, and ONE extra forward pass after the last
+// iteration reproduces it bit for bit from the d of that iteration (only where nothing reads x|u between solves: no cone,
+// no half-spaces).  What stays in registers: g|y, vnew|znew, v|z -- 3 L-long arrays instead of 5 + the LDS trajectory.  That is
+// what lets a lane hold a 50-knot horizon (R = 1: every row sweeps its own instance, no lanes idle in the sweeps) where round 2
+// had to split the horizon over two rows.  The LDS arrays are COMPACT: [slot][row group][NZ] + one dummy entry per slot that all
+// the lanes beyond nx+nu share (they only ever hold zeros).
+enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_ALL = 7 };
+constexpr int tile_reg_arrays(int lm) { return 5 - ((lm & TILE_LM_QX) ? 1 : 0) - ((lm & TILE_LM_DN) ? 1 : 0); }
+constexpr int tile_lds_slot(int nx, int nu, int w) { return (4 / w) * (nx + nu) + 1; }
+// bytes of wave-private LDS: bound tables (unless UB), the trajectory (unless REGEN), the offloaded arrays
+constexpr long tile_lds_bytes(int nx, int nu, int n, int w, int r, int lm, bool ub) {
+    return 8L * (2L * (ub ? 2 : n) * 16 * w + ((lm & TILE_LM_REGEN) ? 1 : (n / r) * 64) +
+                 (((lm & TILE_LM_QX) ? 1 : 0) + ((lm & TILE_LM_DN) ? 1 : 0)) * (long)(n / r) * tile_lds_slot(nx, nu, w));
+}
+// two waves per SIMD when the L-long register arrays + the matrix rows fit 256 VGPRs AND eight waves' LDS fits the CU
+constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int w = 1) {
+    return (2 * (tile_reg_arrays(lm) * (n / r) + 2 * (nx + nu)) + 44 <= 276 &&      // measured (round 2): (12,8,30) at 274 gains, (20,2,30) at 282 loses to spills
+            (lm == 0 || 8 * tile_lds_bytes(nx, nu, n, w, r, lm, true) <= 150 * 1024)) ? 2 : 1;
 }
 
 // SOC: second-order-cone slacks (admm.cpp:102-135, 228-235) -- two more L-long arrays; this variant is never compiled in,
@@ -70,24 +87,30 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r) {
 // W = 1 shapes compiled with TINYMPC_FUSED_NX / _NU (csrc/Makefile) run the sweeps on the one-row kernel's fused step blocks
 // (fused_backward_step / fused_forward_step: the lane-local instructions of a step sit in front of its DPP chain, no s_nop)
 // and take that kernel's placement of the forward constant (d <- fma(res, nim, cf)).
-template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false>
+template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R))))
+__attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
     constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
     constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
-    static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4), "tile shape");
+    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0;
+    constexpr bool KEEPX = !(LM & TILE_LM_REGEN) || SOC || LIN != 0;    // the cone / half-space slacks of the next solve start from x|u
+    constexpr int SLOT = tile_lds_slot(NX, NU, W);
+    static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4) && L >= 2, "tile shape");
     using T = TileTab<W>;
     const int lane = threadIdx.x & 63, row = lane >> 4, j16 = lane & 15;
     const int inst = row / RPI, sub = row % RPI, wrow = sub % W, hrow = sub / W;
     const int jj = wrow * 16 + j16;
     const bool is_state = jj < NX, is_input = jj >= NX && jj < NZ;
+    const int li = jj < NZ ? (row / W) * NZ + jj : (4 / W) * NZ;       // this lane's entry of a compact LDS slot (the dummy beyond nx+nu)
 
     __shared__ double sLo[NB * LW];
     __shared__ double sHi[NB * LW];
-    __shared__ double sX[(N / R) * 64];    // x|u trajectory of this wave: only a rolling value in the sweep, kept for the output
+    __shared__ double sX[KEEPX ? (N / R) * 64 : 1];    // x|u trajectory of this wave: only a rolling value in the sweep, kept for the output
+    __shared__ double sQ[QL ? L * SLOT : 1];           // LM bit 0: QX
+    __shared__ double sD[DL ? L * SLOT : 1];           // LM bit 1: Dn
     for (int e = lane; e < NB * LW; e += 64) {
         sLo[e] = P.tab[T::BOUNDS + e];
         sHi[e] = P.tab[T::BOUNDS + N * LW + e];
