@@ -122,6 +122,28 @@ static const TileEntry* find_tile(int nx, int nu, int N) {
         if (g_tiles[i]->nx == nx && g_tiles[i]->nu == nu && g_tiles[i]->N == N) return g_tiles[i];
     return nullptr;
 }
+// tile_dims.txt may list a shape with several R (rows along the horizon), the preferred one first; every entry of a shape has
+// the same W (table layout).  The plain launch takes the first entry that HAS the needed form (an R = 1 entry of a long horizon has
+// no box-table-in-LDS form: one wave's LDS would not hold it) -- or the entry with R == want_r (option "tile_r", experiments).
+// R of the cone / half-space variants of a compiled-in shape (all arrays in registers, trajectory in LDS): the LAST entry of the
+// shape in tile_dims.txt, i.e. the one with the most rows along the horizon
+static int variant_tile_r(const TinyBatch* b) {
+    int r = b->tile ? b->tile->R : 1;
+    for (int i = 0; i < g_ntiles; ++i)
+        if (g_tiles[i]->nx == b->nx && g_tiles[i]->nu == b->nu && g_tiles[i]->N == b->N) r = g_tiles[i]->R;
+    return r;
+}
+static const TileEntry* pick_tile_entry(const TinyBatch* b, bool ub) {
+    const TileEntry* first_ok = nullptr;
+    for (int i = 0; i < g_ntiles; ++i) {
+        const TileEntry* t = g_tiles[i];
+        if (t->nx != b->nx || t->nu != b->nu || t->N != b->N) continue;
+        if (!(ub ? (t->kub != nullptr || t->k != nullptr) : (t->k != nullptr))) continue;
+        if (b->tile_r > 0 && t->R == b->tile_r) return t;
+        if (!first_ok) first_ok = t;
+    }
+    return first_ok;
+}
 static const KernelEntry* find_kernel(int nx, int nu, int N) {
     for (int i = 0; i < g_nkernels; ++i)
         if (g_kernels[i]->nx == nx && g_kernels[i]->nu == nu && g_kernels[i]->N == N) return g_kernels[i];
@@ -394,7 +416,8 @@ static int tile_lin_variant(const TinyBatch* b) {
     if (km == 0) return 0;
     const int lv = ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
     const long LW = 16L * b->tile->W;
-    const long lds = 8L * (2L * b->N * LW + (long)(b->N / b->tile->R) * 64 + ((lv & 1) ? 3L * km * LW : 1) + ((lv & 2) ? 3L * b->N * km * LW : 1));
+    const int r2 = b->tile_is_jit ? b->tile->R : variant_tile_r(b);
+    const long lds = 8L * (2L * b->N * LW + (long)(b->N / r2) * 64 + ((lv & 1) ? 3L * km * LW : 1) + ((lv & 2) ? 3L * b->N * km * LW : 1));
     return lds <= 60 * 1024 ? lv : 0;
 }
 static bool cones_overlap(const TinyBatch* b);
@@ -422,9 +445,13 @@ static int launch_tile(TinyBatch* b) {
     hipFunction_t jit_fn = nullptr;
     const bool soc = soc_active(b);
     const int lv = tile_lin_variant(b);
+    int vR = b->tile->R;                             // rows along the horizon of the form this launch takes
     if (b->tile_is_jit || soc || lv) {               // a tile shape outside tile_dims.txt, or a cone / half-space variant: instantiate it now (jit.hpp)
         std::string why;
-        jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, b->tile->W, b->tile->R, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
+        // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
+        // register / LDS budget of THAT form, not from the compiled-in plain form's entry)
+        if (!b->tile_is_jit) vR = variant_tile_r(b);
+        jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, b->tile->W, vR, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
         if (!jit_fn) {                               // the coverage kernel takes over
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }
@@ -463,7 +490,11 @@ static int launch_tile(TinyBatch* b) {
         if (int rc = ensure_step_logs(b, steps)) return rc;
         a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
     }
-    const int ipw = 4 / (b->tile->W * b->tile->R);
+    const bool ub = b->tile_bounds_uniform && b->use_ub;
+    const TileEntry* te = jit_fn ? nullptr : pick_tile_entry(b, ub);
+    if (!jit_fn && !te) return fail(b, TINY_ERR_UNSUPPORTED, "no compiled-in tile kernel form for (%d,%d,%d)", b->nx, b->nu, b->N);
+    if (te) vR = te->R;
+    const int ipw = 4 / (b->tile->W * vR);
     int grid = (b->batch + ipw - 1) / ipw;
     if (b->grid_waves_per_cu > 0) {
         const long cap = (long)b->num_cus * b->grid_waves_per_cu;
@@ -476,8 +507,7 @@ static int launch_tile(TinyBatch* b) {
         void* params[] = {&a};
         HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, b->stream, params, nullptr));
     } else {
-        const bool ub = b->tile->kub && b->tile_bounds_uniform && b->use_ub;      // (jit_fn is null: no cone, no half-spaces)
-        hipLaunchKernelGGL(ub ? b->tile->kub : b->tile->k, dim3(grid), dim3(64), 0, b->stream, a);
+        hipLaunchKernelGGL((ub && te->kub) ? te->kub : te->k, dim3(grid), dim3(64), 0, b->stream, a);      // (jit_fn is null: no cone, no half-spaces)
         HIP_TRY(b, hipGetLastError());
     }
     if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
@@ -1632,6 +1662,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "no_jit")) { b->no_jit = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "no_tile")) { b->no_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
+    else if (!strcmp(name, "tile_r")) b->tile_r = (int)value;      // experiments: the tile_dims.txt entry with this R (0: the first that fits)
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
     else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }

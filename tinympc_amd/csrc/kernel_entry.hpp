@@ -14,7 +14,7 @@ struct KernelEntry {
 };
 struct TileEntry {
     int nx, nu, N, W, R;
-    SolveKernel k;
+    SolveKernel k;            // box table in LDS (nullptr when the wave's LDS would not hold it next to the offloaded arrays)
     SolveKernel kub;          // knot-invariant box in registers (nullptr for run-time instantiated tile shapes)
 };
 }  // namespace tinympc_amd

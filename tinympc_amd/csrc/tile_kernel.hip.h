@@ -65,18 +65,29 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
 // what lets a lane hold a 50-knot horizon (R = 1: every row sweeps its own instance, no lanes idle in the sweeps) where round 2
 // had to split the horizon over two rows.  The LDS arrays are COMPACT: [slot][row group][NZ] + one dummy entry per slot that all
 // the lanes beyond nx+nu share (they only ever hold zeros).
-enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_ALL = 7 };
-constexpr int tile_reg_arrays(int lm) { return 5 - ((lm & TILE_LM_QX) ? 1 : 0) - ((lm & TILE_LM_DN) ? 1 : 0); }
+enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_VP = 8, TILE_LM_ALL = 15 };
+constexpr int tile_lds_arrays(int lm) { return ((lm & TILE_LM_QX) ? 1 : 0) + ((lm & TILE_LM_DN) ? 1 : 0) + ((lm & TILE_LM_VP) ? 1 : 0); }
+constexpr int tile_reg_arrays(int lm) { return 5 - tile_lds_arrays(lm); }
 constexpr int tile_lds_slot(int nx, int nu, int w) { return (4 / w) * (nx + nu) + 1; }
 // bytes of wave-private LDS: bound tables (unless UB), the trajectory (unless REGEN), the offloaded arrays
 constexpr long tile_lds_bytes(int nx, int nu, int n, int w, int r, int lm, bool ub) {
     return 8L * (2L * (ub ? 2 : n) * 16 * w + ((lm & TILE_LM_REGEN) ? 1 : (n / r) * 64) +
-                 (((lm & TILE_LM_QX) ? 1 : 0) + ((lm & TILE_LM_DN) ? 1 : 0)) * (long)(n / r) * tile_lds_slot(nx, nu, w));
+                 tile_lds_arrays(lm) * (long)(n / r) * tile_lds_slot(nx, nu, w));
 }
+// max(a, |b|) as ONE opaque instruction: spelled with fmax / fabs the L residual updates of a sweep form a reduction that the
+// compiler re-associates into a tree BEHIND the sweep -- every slot's x, vnew and x + g then stay live to the end of the sweep (at
+// L = 50 that is 300 registers of pressure, i.e. accumulation-register traffic on every access) -- the asm keeps each update next to
+// the step that feeds it.  v_max_f64 returns the other operand when one is a NaN, as fmax does.
+__device__ __forceinline__ double vmax_abs64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // two waves per SIMD when the L-long register arrays + the matrix rows fit 256 VGPRs AND eight waves' LDS fits the CU
 constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int w = 1) {
     return (2 * (tile_reg_arrays(lm) * (n / r) + 2 * (nx + nu)) + 44 <= 276 &&      // measured (round 2): (12,8,30) at 274 gains, (20,2,30) at 282 loses to spills
-            (lm == 0 || 8 * tile_lds_bytes(nx, nu, n, w, r, lm, true) <= 150 * 1024)) ? 2 : 1;
+            (lm == 0 || 8 * tile_lds_bytes(nx, nu, n, w, r, lm, true) <= 158 * 1024)) ? 2 : 1;
 }
 
 // SOC: second-order-cone slacks (admm.cpp:102-135, 228-235) -- two more L-long arrays; this variant is never compiled in,
@@ -95,7 +106,7 @@ void admm_tile_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
     constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
     constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
-    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0;
+    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0;
     constexpr bool KEEPX = !(LM & TILE_LM_REGEN) || SOC || LIN != 0;    // the cone / half-space slacks of the next solve start from x|u
     constexpr int SLOT = tile_lds_slot(NX, NU, W);
     static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4) && L >= 2, "tile shape");
@@ -111,6 +122,7 @@ void admm_tile_kernel(const SolveArgs P) {
     __shared__ double sX[KEEPX ? (N / R) * 64 : 1];    // x|u trajectory of this wave: only a rolling value in the sweep, kept for the output
     __shared__ double sQ[QL ? L * SLOT : 1];           // LM bit 0: QX
     __shared__ double sD[DL ? L * SLOT : 1];           // LM bit 1: Dn
+    __shared__ double sV[VL_ ? L * SLOT : 1];          // LM bit 3: v|z (see the forward sweep)
     for (int e = lane; e < NB * LW; e += 64) {
         sLo[e] = P.tab[T::BOUNDS + e];
         sHi[e] = P.tab[T::BOUNDS + N * LW + e];
@@ -162,7 +174,7 @@ void admm_tile_kernel(const SolveArgs P) {
         const int b = tile * IPW + inst;
         if (b < P.batch) {
             const int g0 = hrow * L;                                   // first global slot of this row
-            double G[L], VN[L], VP[L], QX[L], Dn[L];
+            double G[L], VN[L], VP[VL_ ? 1 : L], QX[QL ? 1 : L], Dn[DL ? 1 : L];
             double VC[SOC ? L : 1], GC[SOC ? L : 1];
             double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
             double ref_last = 0.0;
@@ -174,9 +186,9 @@ void admm_tile_kernel(const SolveArgs P) {
                 const double r = valid ? P.ref[off] : 0.0;
                 VN[l] = valid ? P.slack[off] : 0.0;
                 G[l] = valid ? P.dual[off] : 0.0;
-                VP[l] = valid ? P.slack_prev[off] : 0.0;
-                QX[l] = -(r * qr);
-                Dn[l] = 0.0;
+                if constexpr (VL_) sV[l * SLOT + li] = valid ? P.slack_prev[off] : 0.0; else VP[l] = valid ? P.slack_prev[off] : 0.0;
+                if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else QX[l] = -(r * qr);
+                if constexpr (DL) sD[l * SLOT + li] = 0.0; else Dn[l] = 0.0;
                 if constexpr (SOC) {
                     VC[l] = (valid && soc_lane) ? P.prim[off] : 0.0;                    // vcnew = x, zcnew = u (admm.cpp:352-357)
                     GC[l] = (valid && soc_lane) ? P.cdual[off] : 0.0;
@@ -191,15 +203,20 @@ void admm_tile_kernel(const SolveArgs P) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) pt[k] = P.tab[T::PT + k * LW + jj];
                 const double xp = tile_matvec<W, 0, NX>(0.0, ref_last, pt);
-                if (hrow == R - 1 && is_state) QX[L - 1] = -xp;
+                if (hrow == R - 1 && is_state) { if constexpr (QL) sQ[(L - 1) * SLOT + li] = -xp; else QX[L - 1] = -xp; }
+            }
+            if constexpr (QL || DL || VL_) {                           // (each lane only ever reads its own entries back: no barrier needed,
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the fence keeps the compiler from moving LDS reads above these writes)
             }
 
             int iter = 0, solved = 0, checked = 0, countdown = 0;
             unsigned acc_iter = 0, acc_solved = 0;
             double rp = 0.0, rd = 0.0;
+            double x1v = 0.0, x0_last = x0v;                   // slot 1 (x_1 | u_0) of the last sweep; the x0 the last solve started from
             const int nsteps = P.steps > 1 ? P.steps : 1;
             for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch (as admm_kernel.hip.h)
             iter = 0; solved = 0; countdown = P.check_termination;
+            x0_last = x0v;
             if constexpr (SOC) {
                 if (step > 0) {                                        // vcnew = x, zcnew = u of the previous solve
 #pragma unroll
@@ -231,9 +248,19 @@ void admm_tile_kernel(const SolveArgs P) {
                         qhi = __shfl(qhi, (lane + LW) & 63);
                     }
                     if (hrow == ph) {
+                        // QX in LDS: read two steps ahead of its use (a lone wave per SIMD has nothing else to hide the LDS latency
+                        // behind), and no further: the scheduling barrier at every step keeps the compiler from hoisting all L reads
+                        // to the top of the sweep, which is what turns 3 register arrays into 1 KB of scratch per lane
+                        double qa = 0.0, qb = 0.0;
+                        if constexpr (QL) { qa = sQ[(L - 1) * SLOT + li]; qb = sQ[(L - 2) * SLOT + li]; }
 #pragma unroll
                         for (int l = L - 1; l >= 0; --l) {
-                            double qlo = fma(-rho, VN[l] - G[l], QX[l]);                // admm.cpp:267 | :280 | :293
+                            double qxl;
+                            if constexpr (QL) {
+                                qxl = qa; qa = qb;
+                                if (l >= 2) qb = sQ[(l - 2) * SLOT + li];
+                            } else qxl = QX[l];
+                            double qlo = fma(-rho, VN[l] - G[l], qxl);                  // admm.cpp:267 | :280 | :293
                             if constexpr (SOC) qlo = fma(-rho, VC[l] - GC[l], qlo);     // :269 | :282 | :295
                             if constexpr (LS) qlo = fma(-rho, VL[l] - GL[l], qlo);      // :272 | :285 | :298
                             if constexpr (LT) qlo = fma(-rho, VT[l] - GT[l], qlo);      // :275 | :288 | :301
@@ -241,15 +268,17 @@ void admm_tile_kernel(const SolveArgs P) {
                                 pcur = qlo;                                             // p_{N-1}
                             } else if constexpr (TFUSED) {
                                 double q2, res;                                         // (q2 == qlo: the block forms it again in front of its chain)
-                                fused_backward_step<NX, NU>(q2, res, VN[l], G[l], QX[l], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                                fused_backward_step<NX, NU>(q2, res, VN[l], G[l], qxl, rho, smask, cb, pcur, qhi, mb, mb + NX);
                                 pcur = res;
-                                Dn[l] = fma(res, nim, cf);                              // input lanes: -d_i; state lanes: fdyn
+                                const double dn = fma(res, nim, cf);                    // input lanes: -d_i; state lanes: fdyn
+                                if constexpr (DL) sD[l * SLOT + li] = dn; else Dn[l] = dn;
                                 qlo = q2;
                             } else {
                                 const double src = is_input ? qhi : pcur;
                                 const double res = tile_matvec<W, 0, NZ>(fma(qlo, smask, cb), src, mb);
                                 pcur = res;                                             // p_i | d_i
-                                Dn[l] = res * nim;
+                                const double dn = res * nim;
+                                if constexpr (DL) sD[l * SLOT + li] = dn; else Dn[l] = dn;
                             }
                             qhi = qlo;
                         }
@@ -265,38 +294,56 @@ void admm_tile_kernel(const SolveArgs P) {
                         // the box of slot l+1 is read from LDS while slot l is worked on (as admm_kernel.hip.h does): a lone wave
                         // per SIMD has nothing else to hide the LDS latency behind
                         double lo_c = UB ? (ph == 0 ? lo_u0 : lo_u) : sLo[(ph * L) * LW + jj], hi_c = UB ? (ph == 0 ? hi_u0 : hi_u) : sHi[(ph * L) * LW + jj];
+                        double da = 0.0, db = 0.0, va = 0.0, vb = 0.0;   // Dn / v|z in LDS: read two steps ahead (see the backward sweep)
+                        if constexpr (DL) { da = sD[li]; db = sD[SLOT + li]; }
+                        if constexpr (VL_) { va = sV[li]; vb = sV[SLOT + li]; }
 #pragma unroll
                         for (int l = 0; l < L; ++l) {
                             const int g = ph * L + l;
                             double lo_n = lo_u, hi_n = hi_u;
+                            double dcur = 0.0;
+                            if constexpr (DL) {
+                                dcur = da; da = db;
+                                if (l + 2 < L) db = sD[(l + 2) * SLOT + li];
+                            }
+                            double vcur = 0.0;
+                            if constexpr (VL_) {
+                                vcur = va; va = vb;
+                                if (l + 2 < L) vb = sV[(l + 2) * SLOT + li];
+                            }
                             if constexpr (!UB) {
                                 lo_n = (l + 1 < L) ? sLo[(g + 1) * LW + jj] : 0.0; hi_n = (l + 1 < L) ? sHi[(g + 1) * LW + jj] : 0.0;
-                                __builtin_amdgcn_sched_barrier(0);
                             }
+                            if constexpr (!UB) __builtin_amdgcn_sched_barrier(0);
                             const double xi = xcur;
-                            sX[l * 64 + lane] = xi;
+                            if constexpr (KEEPX) sX[l * 64 + lane] = xi;
                             double tt, vn;
                             if constexpr (TFUSED) {
                                 if (g < N - 1) {
-                                    double xn, t = Dn[l];
+                                    double xn, t;
+                                    if constexpr (DL) t = dcur; else t = Dn[l];
                                     fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[l], lo_c, hi_c, mf1, mf2);
                                     if (l + 1 < L) xcur = xn; else xcarry = xn;
+                                    if (g == 0) x1v = xn;
                                 } else {
                                     tt = xi + G[l];
                                     vn = vmin64(hi_c, vmax64(lo_c, tt));
                                 }
                             } else {
                                 if (g < N - 1) {
-                                    const double t = tile_matvec<W, 0, NX>(Dn[l], xi, mf1);         // A x_i | u_i
+                                    double dnl;
+                                    if constexpr (DL) dnl = dcur; else dnl = Dn[l];
+                                    const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);           // A x_i | u_i
                                     const double xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);       // + f + B u_i | u_i
                                     if (l + 1 < L) xcur = xn; else xcarry = xn;
+                                    if (g == 0) x1v = xn;
                                 }
                                 tt = xi + G[l];
                                 vn = vmin64(hi_c, vmax64(lo_c, tt));
                             }
                             lo_c = lo_n; hi_c = hi_n;
-                            pmax = fmax(pmax, fabs(xi - vn));
-                            dmax = fmax(dmax, fabs(VP[l] - vn));
+                            pmax = vmax_abs64(pmax, xi - vn);
+                            if constexpr (VL_) dmax = vmax_abs64(dmax, vcur - vn); else dmax = vmax_abs64(dmax, VP[l] - vn);
                             G[l] = tt - vn;
                             VN[l] = vn;
                             if constexpr (SOC) {
@@ -355,18 +402,54 @@ void admm_tile_kernel(const SolveArgs P) {
                 }
                 if (conv) { solved = 1; break; }
 #pragma unroll
-                for (int l = 0; l < L; ++l) VP[l] = VN[l];
+                for (int l = 0; l < L; ++l) { if constexpr (VL_) sV[l * SLOT + li] = VN[l]; else VP[l] = VN[l]; }      // :445-446 (L LDS stores, no VALU work)
             }
             acc_iter += (unsigned)iter;
             acc_solved += (unsigned)solved;
             if (nsteps > 1) {
                 if (P.iter_log && sub == 0 && j16 == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
-                if (P.u0_log && hrow == 0 && is_input && iter > 0) P.u0_log[((size_t)step * P.batch + b) * NU + (jj - NX)] = sX[64 + lane];
+                if (P.u0_log && hrow == 0 && is_input && iter > 0) P.u0_log[((size_t)step * P.batch + b) * NU + (jj - NX)] = x1v;
                 // plant step x0 <- A x0 + B u_0 + f = the forward pass' x_1 (slot 1 of the first horizon row; L >= 2)
-                if (iter > 0) x0v = (hrow == 0 && is_state) ? sX[64 + lane] : 0.0;
+                if (iter > 0) x0v = (hrow == 0 && is_state) ? x1v : 0.0;
             }
             }
 
+            if constexpr (!KEEPX) {
+                // ---- the x|u trajectory, regenerated: forward_pass (admm.cpp:25-32) once more with the d of the last iteration and
+                // the x0 that solve started from -- the same instructions on the same inputs as the last sweep, bit for bit
+                if (iter > 0) {
+                    double xcarry = 0.0;
+#pragma unroll
+                    for (int ph = 0; ph < R; ++ph) {
+                        if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);
+                        if (hrow == ph) {
+                            double xcur = (ph > 0) ? xcarry : x0_last;
+#pragma unroll
+                            for (int l = 0; l < L; ++l) {
+                                const int g = ph * L + l;
+                                const bool valid = is_state || (is_input && g >= 1);
+                                const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
+                                const double xi = xcur;
+                                if (valid) P.prim[off] = xi;
+                                if (g < N - 1) {
+                                    double xn, dnl;
+                                    if constexpr (DL) dnl = sD[l * SLOT + li]; else dnl = Dn[l];
+                                    if constexpr (TFUSED) {
+                                        double tt, vn, t = dnl;
+                                        fused_forward_step<NX, NU>(tt, vn, t, xn, xi, 0.0, 0.0, 0.0, mf1, mf2);
+                                    } else {
+                                        const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
+                                        xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);
+                                    }
+                                    if (l + 1 < L) xcur = xn; else xcarry = xn;
+                                }
+                            }
+                        }
+                    }
+                } else if (hrow == 0 && is_state) {
+                    P.prim[((size_t)b * N) * NZ + jj] = x0v;           // max_iter = 0: only x[:,0] = x0 is set
+                }
+            }
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const int g = g0 + l;
@@ -374,17 +457,19 @@ void admm_tile_kernel(const SolveArgs P) {
                 const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
                 if (valid) {
                     // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
+                    if constexpr (KEEPX) {
                     if (iter > 0) P.prim[off] = sX[l * 64 + lane];
                     else if (g == 0 && is_state) P.prim[off] = x0v;
+                    }
                     P.slack[off] = VN[l];
                     P.dual[off] = G[l];
-                    P.slack_prev[off] = VP[l];
+                    if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else P.slack_prev[off] = VP[l];
                     if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
                     if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
                     if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
                 }
             }
-            if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = sX[64 + lane];
+            if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = x1v;
             // residual maxima over the instance's lanes (state rows / input rows separately)
             double ps = is_state ? rp : 0.0, pi = is_input ? rp : 0.0, ds = is_state ? rd : 0.0, di = is_input ? rd : 0.0;
 #pragma unroll
@@ -404,6 +489,30 @@ void admm_tile_kernel(const SolveArgs P) {
             }
         }
     }
+}
+
+// The compiled-in form of a tile shape (csrc/Makefile): as many arrays leave the register file as one wave's LDS share allows.
+// Preference by accesses per slot and iteration saved: v|z (read + write + the copy), Dn (write + read), QX (read).  One wave per
+// SIMD must keep four waves per CU resident (160 KB / 4, a little less for the allocation granule); two waves per SIMD eight.
+// No kernel at all (nullptr) when not even the trajectory-free form fits the static limit of 64 KB -- a (W, R) entry further down
+// tile_dims.txt then serves.
+constexpr long TILE_LDS_STATIC_LIMIT = 64 * 1024 - 512;
+constexpr int tile_best_lm(int nx, int nu, int n, int w, int r, bool ub) {
+    const int cand[4] = {TILE_LM_REGEN | TILE_LM_VP | TILE_LM_DN | TILE_LM_QX, TILE_LM_REGEN | TILE_LM_VP | TILE_LM_DN, TILE_LM_REGEN | TILE_LM_VP,
+                         TILE_LM_REGEN};
+    for (int i = 0; i < 4; ++i) {
+        const long bytes = tile_lds_bytes(nx, nu, n, w, r, cand[i], ub);
+        const int waves = tile_waves_per_simd(nx, nu, n, r, cand[i], w);
+        if (bytes <= TILE_LDS_STATIC_LIMIT && bytes * 4 * waves <= 158 * 1024) return cand[i];
+    }
+    return -1;
+}
+typedef void (*TileKernelFn)(const SolveArgs);
+template <int NX, int NU, int N, int W, int R, bool UB>
+constexpr TileKernelFn tile_kernel_or_null() {
+    constexpr int lm = tile_best_lm(NX, NU, N, W, R, UB);
+    if constexpr (lm >= 0) return admm_tile_kernel<NX, NU, N, W, R, false, 0, LIN_KMAX, UB, (lm >= 0 ? lm : 0)>;
+    else return nullptr;
 }
 
 }  // namespace tinympc_amd
