@@ -142,6 +142,9 @@ struct SolveArgs {
     // 1: every instance has the same Xref | Uref record (set with TINY_BROADCAST, or never set): all rows read instance 0's
     // record -- one L2-resident line set instead of 8S bytes of HBM per instance
     int ref_shared;
+    // tile kernel, dynamic form (tile_kernel.hip.h DYN): ONE device-wide counter of the instances handed out so far, zeroed by
+    // the host before the launch; a slot of a persistent wave takes the next instance off it the moment it is free
+    int* work_counter;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------

@@ -507,8 +507,28 @@ static int launch_tile(TinyBatch* b) {
         void* params[] = {&a};
         HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, b->stream, params, nullptr));
     } else {
-        hipLaunchKernelGGL((ub && te->kub) ? te->kub : te->k, dim3(grid), dim3(64), 0, b->stream, a);      // (jit_fn is null: no cone, no half-spaces)
+        // (jit_fn is null: no cone, no half-spaces.)  Dynamic form: a persistent grid -- as many waves as the chip holds at once --
+        // whose slots draw instances from a device-wide counter; taken when more than one instance shares a wave (lock step makes
+        // a wave as slow as its slowest instance) and the batch is several times what is resident.  Option "tile_dyn": 0 never, 1 always.
+        SolveKernel ks = (ub && te->kub) ? te->kub : te->k, kd = (ub && te->kubdyn) ? te->kubdyn : te->kdyn;
+        int resident = 0;
+        bool dyn = kd != nullptr && b->tile_dyn_opt != 0;
+        if (dyn) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kd), 64, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
+            resident = per_cu * b->num_cus;
+            if (b->tile_dyn_opt < 0 && (ipw < 2 || (long)grid < 4L * resident || b->grid_waves_per_cu > 0)) dyn = false;
+        }
+        if (dyn) {
+            if (!b->d_work_counter) HIP_TRY(b, hipMalloc(reinterpret_cast<void**>(&b->d_work_counter), sizeof(int)));
+            HIP_TRY(b, hipMemsetAsync(b->d_work_counter, 0, sizeof(int), b->stream));
+            a.work_counter = b->d_work_counter;
+            hipLaunchKernelGGL(kd, dim3(std::min(grid, resident)), dim3(64), 0, b->stream, a);
+        } else {
+            hipLaunchKernelGGL(ks, dim3(grid), dim3(64), 0, b->stream, a);
+        }
         HIP_TRY(b, hipGetLastError());
+        b->last_tile_dyn = dyn;
     }
     if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
     return TINY_OK;
@@ -865,7 +885,7 @@ int launch_solve(TinyBatch* b) {
     if (int rc = upload_tables(b)) return rc;
     const bool soc = soc_active(b);
     SolveArgs a;
-    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0;
+    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0; a.work_counter = nullptr;
     a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
@@ -1132,7 +1152,7 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     int tw = 0, tr = 0;
     // (W,R) = (1,1) is the one-row kernel's job where that fits; the tile kernel keeps x|u in LDS and holds longer horizons
     if (!b->tile && jit_tile_shape(nx, nu, N, &tw, &tr) && (tw * tr > 1 || !jit_shape_fits(nx, nu, N, false))) {
-        b->tile_dyn = {nx, nu, N, tw, tr, nullptr, nullptr};
+        b->tile_dyn = {nx, nu, N, tw, tr, nullptr, nullptr, nullptr, nullptr};
         b->tile = &b->tile_dyn;
         b->tile_is_jit = true;
     }
@@ -1261,7 +1281,7 @@ int tiny_batch_destroy(TinyBatch* b) {
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
                     b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count,
-                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab};
+                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter};
     for (void* p : bufs)
         if (p) hipFree(p);
     if (b->h_wire) hipHostFree(b->h_wire);
@@ -1662,6 +1682,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "no_jit")) { b->no_jit = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "no_tile")) { b->no_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
+    else if (!strcmp(name, "tile_dyn")) b->tile_dyn_opt = (int)value;   // -1 (default): by batch size; 0: static tiles; 1: the dynamic form whenever it exists
     else if (!strcmp(name, "tile_r")) b->tile_r = (int)value;      // experiments: the tile_dims.txt entry with this R (0: the first that fits)
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;

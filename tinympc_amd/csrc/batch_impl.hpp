@@ -34,6 +34,9 @@ struct TinyBatch {
     tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
     bool tile_is_jit = false, tile_soc_failed = false;
     bool no_jit = false, jit_failed = false, variant_jit_failed = false;     // run-time instantiation of the one-row kernel for shapes outside kernel_dims.txt (jit.hpp)
+    int tile_dyn_opt = -1;                       // option "tile_dyn"
+    bool last_tile_dyn = false;
+    int* d_work_counter = nullptr;               // the dynamic tile form's device-wide instance counter
     int tile_r = 0;                              // option "tile_r": pick the tile_dims.txt entry with this many rows along the horizon
     bool no_tile = false, prefer_tile = false;   // prefer_tile: take the tile kernel even where a one-row instantiation exists
     // host copies of the problem family

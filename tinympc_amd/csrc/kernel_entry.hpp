@@ -16,6 +16,7 @@ struct TileEntry {
     int nx, nu, N, W, R;
     SolveKernel k;            // box table in LDS (nullptr when the wave's LDS would not hold it next to the offloaded arrays)
     SolveKernel kub;          // knot-invariant box in registers (nullptr for run-time instantiated tile shapes)
+    SolveKernel kdyn, kubdyn; // the same two forms on a persistent grid whose slots draw instances from a device-wide counter
 };
 }  // namespace tinympc_amd
 

@@ -98,7 +98,7 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int 
 // W = 1 shapes compiled with TINYMPC_FUSED_NX / _NU (csrc/Makefile) run the sweeps on the one-row kernel's fused step blocks
 // (fused_backward_step / fused_forward_step: the lane-local instructions of a step sit in front of its DPP chain, no s_nop)
 // and take that kernel's placement of the forward constant (d <- fma(res, nim, cf)).
-template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0>
+template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W))))
 void admm_tile_kernel(const SolveArgs P) {
@@ -169,15 +169,49 @@ void admm_tile_kernel(const SolveArgs P) {
 
     const unsigned long long inst_mask =
         (RPI == 4) ? ~0ull : ((((1ull << (16 * RPI)) - 1ull)) << (inst * 16 * RPI));
+    const int nsteps = P.steps > 1 ? P.steps : 1;
+    const int g0 = hrow * L;                                           // first global slot of this row
     const int ntiles = (P.batch + IPW - 1) / IPW;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile * IPW + inst;
-        if (b < P.batch) {
-            const int g0 = hrow * L;                                   // first global slot of this row
-            double G[L], VN[L], VP[VL_ ? 1 : L], QX[QL ? 1 : L], Dn[DL ? 1 : L];
-            double VC[SOC ? L : 1], GC[SOC ? L : 1];
-            double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
-            double ref_last = 0.0;
+    // ---- the state of this lane's instance (one instance per SLOT of RPI rows; IPW slots per wave)
+    double G[L], VN[L], VP[VL_ ? 1 : L], QX[QL ? 1 : L], Dn[DL ? 1 : L];
+    double VC[SOC ? L : 1], GC[SOC ? L : 1];
+    double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
+    double ref_last = 0.0, x0v = 0.0, x1v = 0.0, x0_last = 0.0, rp = 0.0, rd = 0.0;   // x1v: slot 1 (x_1 | u_0) of the last sweep; x0_last: the x0 the last solve started from
+    int b = 0, iter = 0, solved = 0, checked = 0, countdown = 0, step = 0;
+    unsigned acc_iter = 0, acc_solved = 0;
+    bool have = false;                                                  // this slot holds an instance that is not finished yet
+    int next_tile = blockIdx.x;                                         // static assignment: tiles of IPW instances, grid stride
+    bool exhausted = false;                                             // DYN: the work counter has run past the batch (wave-uniform)
+    // One loop pass = one ADMM iteration of every slot that holds an instance.  A slot that has none takes the next instance
+    // first (load) and hands its finished one back last (store); both are executed under the EXEC mask of that slot only.
+    //   static (DYN = false): the wave moves on to its next tile when ALL its slots are done -- a wave runs as long as its
+    //     slowest instance, the others idle (E[max of 4] / mean = 1.5 ... 2.5 on the config-5 cells);
+    //   dynamic (DYN = true, persistent grid): a slot takes the next instance off ONE device-wide counter the moment it is free
+    //     (one atomic per wave and pass that needs any) -- rows only idle in the tail of the launch.  Instances are independent, so
+    //     who solves which changes nothing in the results.
+    for (;;) {
+        bool fresh = false;
+        if constexpr (DYN) {
+            const bool need = !have && !exhausted;
+            const unsigned long long m = __ballot(need && sub == 0 && j16 == 0);          // one leader lane per slot that needs work
+            if (m != 0ull) {
+                const int first = __ffsll((long long)m) - 1, n = __popcll(m);
+                int base = 0;
+                if (lane == first) base = atomicAdd(P.work_counter, n);
+                base = __shfl(base, first);
+                const int leader = (lane / (16 * RPI)) * (16 * RPI);                     // leader lane of this lane's slot
+                if (need) { b = base + __popcll(m & ((1ull << leader) - 1ull)); fresh = b < P.batch; }
+                if (base + n >= P.batch) exhausted = true;
+            }
+        } else {
+            if (__ballot(have) == 0ull && next_tile < ntiles) {                          // lock step: the whole wave moves on together
+                b = next_tile * IPW + inst;
+                fresh = b < P.batch;
+                next_tile += gridDim.x;
+            }
+        }
+        if (fresh) {
+            // ---- load the instance record
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const int g = g0 + l;
@@ -197,7 +231,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 if constexpr (LT) { VT[l] = (valid && tlin_lane) ? P.prim[off] : 0.0; GT[l] = (valid && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
-            double x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
+            x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
             {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
                 double pt[NX];
 #pragma unroll
@@ -209,36 +243,38 @@ void admm_tile_kernel(const SolveArgs P) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the fence keeps the compiler from moving LDS reads above these writes)
             }
 
-            int iter = 0, solved = 0, checked = 0, countdown = 0;
-            unsigned acc_iter = 0, acc_solved = 0;
-            double rp = 0.0, rd = 0.0;
-            double x1v = 0.0, x0_last = x0v;                   // slot 1 (x_1 | u_0) of the last sweep; the x0 the last solve started from
-            const int nsteps = P.steps > 1 ? P.steps : 1;
-            for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch (as admm_kernel.hip.h)
-            iter = 0; solved = 0; countdown = P.check_termination;
-            x0_last = x0v;
-            if constexpr (SOC) {
-                if (step > 0) {                                        // vcnew = x, zcnew = u of the previous solve
+            have = true; step = 0; acc_iter = 0; acc_solved = 0; checked = 0; rp = 0.0; rd = 0.0; x1v = 0.0;
+        }
+        if (__ballot(have) == 0ull) break;
+        bool start = fresh;                                             // a solve begins: this instance's first, or its next fused MPC step
+        if (have) {
+            if (start) {
+                iter = 0; solved = 0; countdown = P.check_termination;
+                x0_last = x0v;
+                if constexpr (SOC) {
+                    if (step > 0) {                                        // vcnew = x, zcnew = u of the previous solve
 #pragma unroll
-                    for (int l = 0; l < L; ++l) VC[l] = soc_lane ? sX[l * 64 + lane] : 0.0;
+                        for (int l = 0; l < L; ++l) VC[l] = soc_lane ? sX[l * 64 + lane] : 0.0;
+                    }
+                    if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
                 }
-                if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
-            }
-            if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
-                if (step > 0) {
+                if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
+                    if (step > 0) {
 #pragma unroll
-                    for (int l = 0; l < L; ++l) VL[l] = lin_lane ? sX[l * 64 + lane] : 0.0;
+                        for (int l = 0; l < L; ++l) VL[l] = lin_lane ? sX[l * 64 + lane] : 0.0;
+                    }
+                    if (hrow == 0 && is_state && lin_lane) VL[0] = x0v;
                 }
-                if (hrow == 0 && is_state && lin_lane) VL[0] = x0v;
-            }
-            if constexpr (LT) {                                        // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
-                if (step > 0) {
+                if constexpr (LT) {                                        // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
+                    if (step > 0) {
 #pragma unroll
-                    for (int l = 0; l < L; ++l) VT[l] = tlin_lane ? sX[l * 64 + lane] : 0.0;
+                        for (int l = 0; l < L; ++l) VT[l] = tlin_lane ? sX[l * 64 + lane] : 0.0;
+                    }
+                    if (hrow == 0 && is_state && tlin_lane) VT[0] = x0v;
                 }
-                if (hrow == 0 && is_state && tlin_lane) VT[0] = x0v;
             }
-            for (int it = 0; it < P.max_iter; ++it) {
+            bool conv = false;
+            if (iter < P.max_iter) {
                 // ---- backward_pass_grad (admm.cpp:13-20): the horizon rows take turns, last row first
                 double pcur = 0.0, qhi = 0.0;
 #pragma unroll
@@ -390,7 +426,6 @@ void admm_tile_kernel(const SolveArgs P) {
                     }
                 }
                 iter += 1;
-                bool conv = false;
                 if (countdown > 0 && --countdown == 0) {
                     countdown = P.check_termination;
                     checked = 1;
@@ -400,91 +435,122 @@ void admm_tile_kernel(const SolveArgs P) {
                     const unsigned long long bal = __ballot(ok);
                     conv = (bal & inst_mask) == inst_mask;
                 }
-                if (conv) { solved = 1; break; }
+                if (!conv) {
 #pragma unroll
-                for (int l = 0; l < L; ++l) { if constexpr (VL_) sV[l * SLOT + li] = VN[l]; else VP[l] = VN[l]; }      // :445-446 (L LDS stores, no VALU work)
+                    for (int l = 0; l < L; ++l) { if constexpr (VL_) sV[l * SLOT + li] = VN[l]; else VP[l] = VN[l]; }      // :445-446 (L LDS stores, no VALU work)
+                }
             }
-            acc_iter += (unsigned)iter;
-            acc_solved += (unsigned)solved;
-            if (nsteps > 1) {
-                if (P.iter_log && sub == 0 && j16 == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
-                if (P.u0_log && hrow == 0 && is_input && iter > 0) P.u0_log[((size_t)step * P.batch + b) * NU + (jj - NX)] = x1v;
-                // plant step x0 <- A x0 + B u_0 + f = the forward pass' x_1 (slot 1 of the first horizon row; L >= 2)
-                if (iter > 0) x0v = (hrow == 0 && is_state) ? x1v : 0.0;
-            }
-            }
-
-            if constexpr (!KEEPX) {
-                // ---- the x|u trajectory, regenerated: forward_pass (admm.cpp:25-32) once more with the d of the last iteration and
-                // the x0 that solve started from -- the same instructions on the same inputs as the last sweep, bit for bit
-                if (iter > 0) {
-                    double xcarry = 0.0;
+            if (conv || iter >= P.max_iter) {                            // this solve is over (admm.cpp:431-441 | :448-454)
+                solved = conv ? 1 : 0;
+                acc_iter += (unsigned)iter;
+                acc_solved += (unsigned)solved;
+                if (nsteps > 1) {
+                    if (P.iter_log && sub == 0 && j16 == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
+                    if (P.u0_log && hrow == 0 && is_input && iter > 0) P.u0_log[((size_t)step * P.batch + b) * NU + (jj - NX)] = x1v;
+                    // plant step x0 <- A x0 + B u_0 + f = the forward pass' x_1 (slot 1 of the first horizon row; L >= 2)
+                    if (iter > 0 && step + 1 < nsteps) x0v = (hrow == 0 && is_state) ? x1v : 0.0;
+                }
+                step += 1;
+                if (step < nsteps) {
+                    // the next fused MPC step of the same instance starts in the next pass
+                    iter = 0; solved = 0; countdown = P.check_termination;
+                    x0_last = x0v;
+                    if constexpr (SOC) {
+                        if (true) {                                        // vcnew = x, zcnew = u of the previous solve
 #pragma unroll
-                    for (int ph = 0; ph < R; ++ph) {
-                        if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);
-                        if (hrow == ph) {
-                            double xcur = (ph > 0) ? xcarry : x0_last;
+                            for (int l = 0; l < L; ++l) VC[l] = soc_lane ? sX[l * 64 + lane] : 0.0;
+                        }
+                        if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
+                    }
+                    if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
+                        if (true) {
 #pragma unroll
-                            for (int l = 0; l < L; ++l) {
-                                const int g = ph * L + l;
-                                const bool valid = is_state || (is_input && g >= 1);
-                                const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
-                                const double xi = xcur;
-                                if (valid) P.prim[off] = xi;
-                                if (g < N - 1) {
-                                    double xn, dnl;
-                                    if constexpr (DL) dnl = sD[l * SLOT + li]; else dnl = Dn[l];
-                                    if constexpr (TFUSED) {
-                                        double tt, vn, t = dnl;
-                                        fused_forward_step<NX, NU>(tt, vn, t, xn, xi, 0.0, 0.0, 0.0, mf1, mf2);
-                                    } else {
-                                        const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
-                                        xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);
+                            for (int l = 0; l < L; ++l) VL[l] = lin_lane ? sX[l * 64 + lane] : 0.0;
+                        }
+                        if (hrow == 0 && is_state && lin_lane) VL[0] = x0v;
+                    }
+                    if constexpr (LT) {                                        // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
+                        if (true) {
+#pragma unroll
+                            for (int l = 0; l < L; ++l) VT[l] = tlin_lane ? sX[l * 64 + lane] : 0.0;
+                        }
+                        if (hrow == 0 && is_state && tlin_lane) VT[0] = x0v;
+                    }
+                } else {
+                if constexpr (!KEEPX) {
+                    // ---- the x|u trajectory, regenerated: forward_pass (admm.cpp:25-32) once more with the d of the last iteration and
+                    // the x0 that solve started from -- the same instructions on the same inputs as the last sweep, bit for bit
+                    if (iter > 0) {
+                        double xcarry = 0.0;
+#pragma unroll
+                        for (int ph = 0; ph < R; ++ph) {
+                            if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);
+                            if (hrow == ph) {
+                                double xcur = (ph > 0) ? xcarry : x0_last;
+#pragma unroll
+                                for (int l = 0; l < L; ++l) {
+                                    const int g = ph * L + l;
+                                    const bool valid = is_state || (is_input && g >= 1);
+                                    const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
+                                    const double xi = xcur;
+                                    if (valid) P.prim[off] = xi;
+                                    if (g < N - 1) {
+                                        double xn, dnl;
+                                        if constexpr (DL) dnl = sD[l * SLOT + li]; else dnl = Dn[l];
+                                        if constexpr (TFUSED) {
+                                            double tt, vn, t = dnl;
+                                            fused_forward_step<NX, NU>(tt, vn, t, xn, xi, 0.0, 0.0, 0.0, mf1, mf2);
+                                        } else {
+                                            const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
+                                            xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);
+                                        }
+                                        if (l + 1 < L) xcur = xn; else xcarry = xn;
                                     }
-                                    if (l + 1 < L) xcur = xn; else xcarry = xn;
                                 }
                             }
                         }
+                    } else if (hrow == 0 && is_state) {
+                        P.prim[((size_t)b * N) * NZ + jj] = x0v;           // max_iter = 0: only x[:,0] = x0 is set
                     }
-                } else if (hrow == 0 && is_state) {
-                    P.prim[((size_t)b * N) * NZ + jj] = x0v;           // max_iter = 0: only x[:,0] = x0 is set
                 }
-            }
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int g = g0 + l;
-                const bool valid = is_state || (is_input && g >= 1);
-                const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
-                if (valid) {
-                    // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
-                    if constexpr (KEEPX) {
-                    if (iter > 0) P.prim[off] = sX[l * 64 + lane];
-                    else if (g == 0 && is_state) P.prim[off] = x0v;
+                for (int l = 0; l < L; ++l) {
+                    const int g = g0 + l;
+                    const bool valid = is_state || (is_input && g >= 1);
+                    const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
+                    if (valid) {
+                        // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
+                        if constexpr (KEEPX) {
+                        if (iter > 0) P.prim[off] = sX[l * 64 + lane];
+                        else if (g == 0 && is_state) P.prim[off] = x0v;
+                        }
+                        P.slack[off] = VN[l];
+                        P.dual[off] = G[l];
+                        if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else P.slack_prev[off] = VP[l];
+                        if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
+                        if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
+                        if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
                     }
-                    P.slack[off] = VN[l];
-                    P.dual[off] = G[l];
-                    if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else P.slack_prev[off] = VP[l];
-                    if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
-                    if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
-                    if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
                 }
-            }
-            if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = x1v;
-            // residual maxima over the instance's lanes (state rows / input rows separately)
-            double ps = is_state ? rp : 0.0, pi = is_input ? rp : 0.0, ds = is_state ? rd : 0.0, di = is_input ? rd : 0.0;
+                if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = x1v;
+                // residual maxima over the instance's lanes (state rows / input rows separately)
+                double ps = is_state ? rp : 0.0, pi = is_input ? rp : 0.0, ds = is_state ? rd : 0.0, di = is_input ? rd : 0.0;
 #pragma unroll
-            for (int off = 8 * RPI; off >= 1; off >>= 1) {
-                ps = fmax(ps, __shfl_xor(ps, off)); pi = fmax(pi, __shfl_xor(pi, off));
-                ds = fmax(ds, __shfl_xor(ds, off)); di = fmax(di, __shfl_xor(di, off));
-            }
-            if (sub == 0 && j16 == 0) {
-                P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
-                *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(ps, pi, ds, di);
-                if (P.accum) {
-                    uint2 ac = P.accum[b];
-                    ac.x += acc_iter;
-                    ac.y += acc_solved;
-                    P.accum[b] = ac;
+                for (int off = 8 * RPI; off >= 1; off >>= 1) {
+                    ps = fmax(ps, __shfl_xor(ps, off)); pi = fmax(pi, __shfl_xor(pi, off));
+                    ds = fmax(ds, __shfl_xor(ds, off)); di = fmax(di, __shfl_xor(di, off));
+                }
+                if (sub == 0 && j16 == 0) {
+                    P.status[b] = make_int4(iter, solved, solved ? 1 : 11, checked);
+                    *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = make_double4(ps, pi, ds, di);
+                    if (P.accum) {
+                        uint2 ac = P.accum[b];
+                        ac.x += acc_iter;
+                        ac.y += acc_solved;
+                        P.accum[b] = ac;
+                    }
+                }
+                    have = false;
                 }
             }
         }
@@ -508,10 +574,10 @@ constexpr int tile_best_lm(int nx, int nu, int n, int w, int r, bool ub) {
     return -1;
 }
 typedef void (*TileKernelFn)(const SolveArgs);
-template <int NX, int NU, int N, int W, int R, bool UB>
+template <int NX, int NU, int N, int W, int R, bool UB, bool DYN = false>
 constexpr TileKernelFn tile_kernel_or_null() {
     constexpr int lm = tile_best_lm(NX, NU, N, W, R, UB);
-    if constexpr (lm >= 0) return admm_tile_kernel<NX, NU, N, W, R, false, 0, LIN_KMAX, UB, (lm >= 0 ? lm : 0)>;
+    if constexpr (lm >= 0) return admm_tile_kernel<NX, NU, N, W, R, false, 0, LIN_KMAX, UB, (lm >= 0 ? lm : 0), DYN>;
     else return nullptr;
 }
 
