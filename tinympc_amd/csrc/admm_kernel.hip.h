@@ -471,6 +471,21 @@ __device__ __forceinline__ double vmin64(double a, double b) {
     return r;
 }
 
+// max(a, |b|) as ONE opaque instruction (long horizons only, N > 12): spelled with fmax / fabs the N residual updates of a sweep
+// form a reduction that the compiler re-associates into a tree BEHIND the sweep, so every slot's x, vnew and x + g stay live to the
+// end of the sweep -- at N = 30 that is accumulation-register traffic on every access.  v_max_f64 returns the other operand when
+// one is a NaN, as fmax does.
+__device__ __forceinline__ double vmax_abs64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool OPAQUE>
+__device__ __forceinline__ double resid_max(double a, double b) {
+    if constexpr (OPAQUE) return vmax_abs64(a, b);
+    else return fmax(a, fabs(b));
+}
+
 __device__ __forceinline__ double grp_max16(double v) {
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 16));
@@ -877,8 +892,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         const double xi = X[s];
                         const double t = xi + G[s];                                 // :85 / :88
                         const double vn = vmin64(hi, vmax64(lo, t));                // :91-98
-                        pmax = fmax(pmax, fabs(xi - vn));
-                        dmax = fmax(dmax, fabs(VP[s] - vn));
+                        pmax = resid_max<(N > 12)>(pmax, xi - vn);
+                        dmax = resid_max<(N > 12)>(dmax, VP[s] - vn);
                         G[s] = t - vn;                      // :222 / :225  g + x - vnew; (g + x) == t bit-for-bit
                         VN[s] = vn;
                         if constexpr (SOC) {
@@ -933,8 +948,8 @@ void admm_solve_kernel(const SolveArgs P) {
                             const double xi = X[i];
                             fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
                             X[i + 1] = xn;
-                            pmax = fmax(pmax, fabs(xi - vn));
-                            dmax = fmax(dmax, fabs(VP[i] - vn));
+                            pmax = resid_max<(N > 12)>(pmax, xi - vn);
+                            dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
                             G[i] = tt - vn;
                             VN[i] = vn;
                             if constexpr (SOC) sT[(grp * N + i) * 16 + j] = fma(xi, socmask, GC[i]);     // x + gc -> cone step (below)

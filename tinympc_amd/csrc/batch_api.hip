@@ -139,7 +139,8 @@ static const TileEntry* pick_tile_entry(const TinyBatch* b, bool ub) {
         const TileEntry* t = g_tiles[i];
         if (t->nx != b->nx || t->nu != b->nu || t->N != b->N) continue;
         if (!(ub ? (t->kub != nullptr || t->k != nullptr) : (t->k != nullptr))) continue;
-        if (b->tile_r > 0 && t->R == b->tile_r) return t;
+        if (b->tile_r > 0 && t->R == b->tile_r && (b->tile_lm < 0 || t->lm == b->tile_lm)) return t;
+        if (b->tile_r == 0 && b->tile_lm >= 0 && t->lm == b->tile_lm) return t;
         if (!first_ok) first_ok = t;
     }
     return first_ok;
@@ -1152,7 +1153,7 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     int tw = 0, tr = 0;
     // (W,R) = (1,1) is the one-row kernel's job where that fits; the tile kernel keeps x|u in LDS and holds longer horizons
     if (!b->tile && jit_tile_shape(nx, nu, N, &tw, &tr) && (tw * tr > 1 || !jit_shape_fits(nx, nu, N, false))) {
-        b->tile_dyn = {nx, nu, N, tw, tr, nullptr, nullptr, nullptr, nullptr};
+        b->tile_dyn = {nx, nu, N, tw, tr, 0, nullptr, nullptr, nullptr, nullptr};
         b->tile = &b->tile_dyn;
         b->tile_is_jit = true;
     }
@@ -1683,6 +1684,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "no_tile")) { b->no_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "tile_dyn")) b->tile_dyn_opt = (int)value;   // -1 (default): by batch size; 0: static tiles; 1: the dynamic form whenever it exists
+    else if (!strcmp(name, "tile_lm")) b->tile_lm = (int)value;    // experiments: the tile_dims.txt entry with this LM column
     else if (!strcmp(name, "tile_r")) b->tile_r = (int)value;      // experiments: the tile_dims.txt entry with this R (0: the first that fits)
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;

@@ -31,9 +31,10 @@ struct TinyBatch {
     double* d_ttab = nullptr;
     size_t ttab_doubles = 0;
     std::vector<double> h_ttab;
-    tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
+    tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
     bool tile_is_jit = false, tile_soc_failed = false;
     bool no_jit = false, jit_failed = false, variant_jit_failed = false;     // run-time instantiation of the one-row kernel for shapes outside kernel_dims.txt (jit.hpp)
+    int tile_lm = -1;                            // option "tile_lm"
     int tile_dyn_opt = -1;                       // option "tile_dyn"
     bool last_tile_dyn = false;
     int* d_work_counter = nullptr;               // the dynamic tile form's device-wide instance counter

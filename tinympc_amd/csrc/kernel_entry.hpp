@@ -14,6 +14,7 @@ struct KernelEntry {
 };
 struct TileEntry {
     int nx, nu, N, W, R;
+    int lm;                   // which arrays leave the register file (tile_kernel.hip.h TILE_LM_*); 99: the largest set that fits the wave's LDS share
     SolveKernel k;            // box table in LDS (nullptr when the wave's LDS would not hold it next to the offloaded arrays)
     SolveKernel kub;          // knot-invariant box in registers (nullptr for run-time instantiated tile shapes)
     SolveKernel kdyn, kubdyn; // the same two forms on a persistent grid whose slots draw instances from a device-wide counter

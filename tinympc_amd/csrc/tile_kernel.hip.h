@@ -74,16 +74,6 @@ constexpr long tile_lds_bytes(int nx, int nu, int n, int w, int r, int lm, bool 
     return 8L * (2L * (ub ? 2 : n) * 16 * w + ((lm & TILE_LM_REGEN) ? 1 : (n / r) * 64) +
                  tile_lds_arrays(lm) * (long)(n / r) * tile_lds_slot(nx, nu, w));
 }
-// max(a, |b|) as ONE opaque instruction: spelled with fmax / fabs the L residual updates of a sweep form a reduction that the
-// compiler re-associates into a tree BEHIND the sweep -- every slot's x, vnew and x + g then stay live to the end of the sweep (at
-// L = 50 that is 300 registers of pressure, i.e. accumulation-register traffic on every access) -- the asm keeps each update next to
-// the step that feeds it.  v_max_f64 returns the other operand when one is a NaN, as fmax does.
-__device__ __forceinline__ double vmax_abs64(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // two waves per SIMD when the L-long register arrays + the matrix rows fit 256 VGPRs AND eight waves' LDS fits the CU
 constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int w = 1) {
     return (2 * (tile_reg_arrays(lm) * (n / r) + 2 * (nx + nu)) + 44 <= 276 &&      // measured (round 2): (12,8,30) at 274 gains, (20,2,30) at 282 loses to spills
@@ -574,9 +564,10 @@ constexpr int tile_best_lm(int nx, int nu, int n, int w, int r, bool ub) {
     return -1;
 }
 typedef void (*TileKernelFn)(const SolveArgs);
-template <int NX, int NU, int N, int W, int R, bool UB, bool DYN = false>
+template <int NX, int NU, int N, int W, int R, int LMREQ, bool UB, bool DYN = false>
 constexpr TileKernelFn tile_kernel_or_null() {
-    constexpr int lm = tile_best_lm(NX, NU, N, W, R, UB);
+    // LMREQ (6th column of tile_dims.txt): 99 = the rule above; else that very set, if one wave's static LDS holds it
+    constexpr int lm = LMREQ == 99 ? tile_best_lm(NX, NU, N, W, R, UB) : (tile_lds_bytes(NX, NU, N, W, R, LMREQ, UB) <= TILE_LDS_STATIC_LIMIT ? LMREQ : -1);
     if constexpr (lm >= 0) return admm_tile_kernel<NX, NU, N, W, R, false, 0, LIN_KMAX, UB, (lm >= 0 ? lm : 0), DYN>;
     else return nullptr;
 }
