@@ -357,6 +357,43 @@ def test_tracking_full_batch_properties():
     assert np.all(np.abs(out["znew"]) <= 0.5 + 1e-15) and np.all(np.abs(out["vnew"]) <= 5 + 1e-15)
 
 
+@pytest.mark.parametrize("dims,B", [((4, 2, 50), 131072), ((12, 8, 10), 32768), ((20, 8, 30), 32768)])
+def test_sweep_cells_full_batch_on_the_dynamic_tile_form(dims, B):
+    """BASELINE config 5 cells at benchmark batch sizes (the sweep cells were only parity-tested at B = 2-9): 512 unique
+    instances of the cell's recipe (per-instance random x0 / Xref, max_iter 500, iteration counts from a handful to 500) are
+    checked against the oracle field by field, their replicas must agree bit for bit -- on the DYNAMIC form of the tile kernel
+    (persistent grid, slots draw instances from a device-wide counter: which wave solves which instance differs from launch to
+    launch, the results must not) -- and the static-tile form of the same kernel must give the very same bits."""
+    import tinympc_amd as tm
+    U = 512
+    base = sc.sweep_suite(*dims, B=U, max_iter=500)
+    suite = dict(problem=base["problem"], config=base["config"],
+                 cases={k: np.concatenate([v] * (B // U), axis=0) for k, v in base["cases"].items()})
+    probe = make_batch(suite)
+    assert probe.kernel_path() == "tile"
+    probe.close()
+    ref = sc.run_cases(OracleSolver, base)
+    assert len(np.unique(ref["iter"])) > 5                                     # the cell does diverge
+    outs = {}
+    for dyn in (1, 0):
+        out = run_cases_hip(suite, options={"tile_dyn": dyn})
+        outs[dyn] = out
+        assert np.array_equal(out["iter"][:U].astype(int), ref["iter"].astype(int))
+        assert np.array_equal(out["sol_solved"][:U].astype(int), ref["sol_solved"].astype(int))
+        for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+            for b in range(U):
+                assert rel_err(out[k][b], ref[k][b]) < RTOL, (k, b, dyn)
+            v = out[k].reshape(B // U, U, -1)
+            assert np.array_equal(v, np.broadcast_to(v[:1], v.shape)), (k, dyn)   # replicas agree bit for bit
+    for k in ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z", "primal_residual_state", "dual_residual_input"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k                        # dynamic form == static form, bit for bit
+    s = make_batch(suite)                                                       # and the default really takes the dynamic form at this size
+    s.set_x0(suite["cases"]["x0"]); s.set("Xref", suite["cases"]["Xref"])
+    s.solve()
+    assert s.get_option("last_tile_dyn") == 1
+    s.close()
+
+
 def test_rocket_soc_full_batch_properties():
     """BASELINE config 4 at full per-job size: 65 536 rocket-landing instances with the second-order-cone
     thrust constraint on, perturbed initial states.  ALL 2048 unique instances are checked against the oracle,

@@ -1794,6 +1794,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     }
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
+    if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form
     if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;
     if (!strcmp(name, "repack_after")) return b->repack_after;
     return fail(b, TINY_ERR_ARG, "unknown option %s", name);
