@@ -326,6 +326,9 @@ int tiny_rccl_available(void);          /* 1: librccl could be loaded next to th
  * primal_input, dual_state, dual_input} of this batch, written to device memory on the batch's stream behind the solve,
  * for hosts that run the collective themselves (bench.py hands it to torch.distributed = RCCL). */
 int tiny_batch_stats_message(TinyBatch* b, void* device_out);
+/* ... and the host reduction of the gathered n_shards x 8 table -> the 10-entry statistics vector (SUM over the counts, MAX over
+ * the residuals; a NaN residual survives), as the two allreduce entry points run it.  Host code only: works without a GPU. */
+int tiny_reduce_stats_messages(const double* table, int n_shards, long total_batch, double* out10);
 
 /* ------------------------------------------------------------------------------------------ */
 /* (B) Reference entry points over plain-data mirrors of the reference structs.

@@ -142,3 +142,21 @@ def test_reduce_table_takes_the_job_size_from_the_shard_column_and_keeps_a_nan_r
     assert out[2] == 11 and torch.isnan(out[4])
     with pytest.raises(ValueError):
         reduce_table(torch.tensor(rows, dtype=torch.float64)[:, :8])
+
+
+def test_native_reduction_of_the_gathered_messages_agrees_with_reduce_table_nan_included():
+    """the native group / RCCL exchange reduces the gathered messages on the host with the same result as
+    distributed.reduce_table -- including a NaN residual of a diverged shard, which std::max(out, NaN) used to drop."""
+    import torch
+    import tinympc_amd as tm
+    from tinympc_amd.distributed import reduce_table
+    rng = np.random.default_rng(3)
+    table = np.concatenate([rng.integers(0, 1000, (5, 4)).astype(float), rng.uniform(0, 1, (5, 4))], axis=1)
+    for nan_at in (None, (3, 5), (0, 7), (4, 4)):
+        t = table.copy()
+        if nan_at:
+            t[nan_at] = np.nan
+        a = tm.reduce_stats_messages(t, 4242)
+        b = reduce_table(torch.tensor(t), 4242).numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), (nan_at, a, b)
+        assert a[2] == 4242 and (nan_at is None) == (not np.isnan(a).any())

@@ -157,31 +157,3 @@ def test_random_problems_sharded_equal_unsharded():
             break
     assert done >= 15
 
-
-def test_a_nan_residual_of_one_shard_survives_the_group_reduction():
-    """a diverged shard's NaN residual must not be dropped by the host reduction of the gathered 64-byte messages
-    (std::max(out, NaN) keeps `out`): the native group exchange and distributed.reduce_table (torch.max) agree -- NaN."""
-    from tinympc_amd.distributed import WIRE_IDX, reduce_table
-    prob, extra = tm.load_problem("quadrotor_20hz")
-    nx, nu, N, B = prob["nx"], prob["nu"], prob["N"], 12
-    g = tm.TinyGroupSolver.from_problem(prob, B, devices=[0, 0])
-    g.update_settings(max_iter=5)
-    x0 = np.zeros((B, nx)); x0[:, 0] = 0.1
-    x0[B - 1, 2] = np.nan                                        # one instance of the SECOND shard diverges from the start
-    g.set_x0(x0)
-    g.solve()
-    st = g.allreduce_stats()
-    assert np.isnan(st[3]) and st[2] == B and st[0] == 5 * B     # primal state residual maximum: NaN, not dropped
-    # the same table reduced by the torch.distributed form of the exchange
-    rows = []
-    for k in range(g.shards):
-        idx = g.shard_indices(k)
-        s = tm.TinyBatchSolver.from_problem(prob, len(idx))
-        s.update_settings(max_iter=5)
-        s.set_x0(x0[idx])
-        s.solve()
-        rows.append(s.reduce_stats()[list(WIRE_IDX)])
-        s.close()
-    ref = reduce_table(np.array(rows), B).numpy()
-    assert np.array_equal(np.isnan(st), np.isnan(ref)) and np.array_equal(st[~np.isnan(st)], ref[~np.isnan(ref)])
-    g.close()

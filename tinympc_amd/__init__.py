@@ -43,7 +43,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
-    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy", "tiny_rccl_comm_count", "tiny_rccl_available",
+    "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy", "tiny_rccl_comm_count", "tiny_rccl_available", "tiny_reduce_stats_messages",
     "tiny_batch_get_option", "tiny_predict_split", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
@@ -156,6 +156,7 @@ def lib():
         L.tiny_rccl_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.tiny_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.tiny_rccl_comm_count.argtypes = [C.c_void_p]
+        L.tiny_reduce_stats_messages.argtypes = [_dp, C.c_int, C.c_long, _dp]
         L.tiny_batch_allreduce_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, _dp]
         L.tiny_group_setup.argtypes = [C.POINTER(C.c_void_p), _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _ip, C.c_int, C.c_int, C.c_int]
@@ -699,6 +700,16 @@ def rccl_comm_count(comm) -> int:
     if n < 0:
         raise TinyMPCError(f"tiny_rccl_comm_count failed ({n})")
     return int(n)
+
+
+def reduce_stats_messages(table, total_batch):
+    """native host reduction of gathered 64-byte messages ([n_shards, 8]) -> the 10-entry statistics vector (no GPU needed)"""
+    t = np.ascontiguousarray(np.asarray(table, dtype=np.float64).reshape(-1, 8))
+    out = np.zeros(10)
+    rc = lib().tiny_reduce_stats_messages(t.ctypes.data_as(_dp), t.shape[0], int(total_batch), out.ctypes.data_as(_dp))
+    if rc != OK:
+        raise TinyMPCError(f"tiny_reduce_stats_messages failed ({rc})")
+    return out
 
 
 def rccl_available() -> bool:

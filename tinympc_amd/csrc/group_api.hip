@@ -422,6 +422,14 @@ int tiny_rccl_comm_init_rank(void** comm, int n_ranks, const void* id128, int ra
     *comm = c;
     return TINY_OK;
 }
+// The host reduction of the gathered 64-byte messages ({sum iter, sum solved, accumulated iterations, accumulated solves, four
+// residual maxima} per shard) -> the 10-entry statistics vector: what tiny_group_allreduce_stats / tiny_batch_allreduce_stats run
+// after their all-gather, for hosts that move the messages themselves (MPI, torch.distributed).  No GPU involved.
+int tiny_reduce_stats_messages(const double* table, int n_shards, long total_batch, double* out10) {
+    if (!table || !out10 || n_shards <= 0) return TINY_ERR_NULL;
+    reduce_wire_table(table, n_shards, (double)total_batch, out10);
+    return TINY_OK;
+}
 int tiny_rccl_available(void) {
     Rccl* r = rccl();
     return (r && r->GetUniqueId && r->CommInitRank) ? 1 : 0;
