@@ -594,32 +594,6 @@ void admm_solve_kernel(const SolveArgs P) {
     const bool is_state = j < NX;
     const bool is_input = (j >= NX) && (j < NZ);
 
-    // EARLY: the HBM loads of this wave's first tile are issued BEFORE the table prologue (~2 us of L2 / LDS traffic per wave): in
-    // the warm regime -- one or two iterations per launch, every launch loads and stores the records -- a wave then spends its
-    // prologue with its record loads already in flight instead of starting them afterwards.  (Plain variants only: the others
-    // need table data to know what to load.)
-    constexpr bool EARLY = !SOC && LIN == 0 && !HET && !ADAPT && !DBG;
-    double G[N], VN[N], VP[N], QX[N];
-    double x0v = 0.0;
-    bool early_loaded = false;
-    if constexpr (EARLY) {
-        const int slot0 = (int)blockIdx.x * 4 + grp;
-        if (P.index == nullptr && slot0 < P.batch) {
-            const size_t lb = (size_t)slot0 * (N * NZ) + j - (is_input ? NZ : 0);
-#pragma unroll
-            for (int s = 0; s < N; ++s) {
-                const bool valid = is_state || (is_input && s >= 1);
-                const size_t off = lb + s * NZ;
-                const bool warm = valid && !P.cold;
-                QX[s] = valid ? P.ref[P.ref_shared ? (off - (size_t)slot0 * (N * NZ)) : off] : 0.0;     // the raw reference: scaled after the prologue
-                VN[s] = warm ? P.slack[off] : 0.0;
-                G[s] = warm ? P.dual[off] : 0.0;
-                VP[s] = warm ? P.slack_prev[off] : 0.0;
-            }
-            x0v = is_state ? P.x0[(size_t)slot0 * NX + j] : 0.0;
-            early_loaded = true;
-        }
-    }
     // per-wave LDS copies of the tables that are read with a dynamic index or only once per solve
     __shared__ double sPt[NX * 16];
     __shared__ double sLo[N * 16];
@@ -741,27 +715,21 @@ void admm_solve_kernel(const SolveArgs P) {
             }
             // record base of this lane: input lanes read knot s-1 at slot s
             const size_t lbase = (size_t)b * (N * NZ) + j - (is_input ? NZ : 0);
-            double X[N], Dn[N - 1];
+            double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
             double VC[SOC ? N : 1], GC[SOC ? N : 1];
             double VL[LS ? N : 1], GL[LS ? N : 1], VT[LT ? N : 1], GT[LT ? N : 1];
             double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
             double ref_last = 0.0, qx_last_plain = 0.0;
             // ---- load the instance record (coalesced: contiguous NZ*8-byte knot segments)
-            const bool have_early = EARLY && early_loaded && tile == (int)blockIdx.x;      // this tile's records are already on their way
 #pragma unroll
             for (int s = 0; s < N; ++s) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
                 const bool warm = valid && !P.cold;
-                double r;
-                if (have_early) {
-                    r = QX[s];
-                } else {
-                    r = valid ? P.ref[P.ref_shared ? (off - (size_t)b * (N * NZ)) : off] : 0.0;
-                    VN[s] = warm ? P.slack[off] : 0.0;
-                    G[s] = warm ? P.dual[off] : 0.0;
-                    VP[s] = warm ? P.slack_prev[off] : 0.0;
-                }
+                const double r = valid ? P.ref[P.ref_shared ? (off - (size_t)b * (N * NZ)) : off] : 0.0;
+                VN[s] = warm ? P.slack[off] : 0.0;
+                G[s] = warm ? P.dual[off] : 0.0;
+                VP[s] = warm ? P.slack_prev[off] : 0.0;
                 QX[s] = -(r * qr);                           // admm.cpp:266 / :279
                 X[s] = 0.0;
                 if (s == N - 1) ref_last = r;
@@ -779,7 +747,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
-            if (!have_early) x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;    // tiny_set_x0
+            double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;           // tiny_set_x0
             auto terminal_term = [&]() {   // -(Xref[:,N-1]^T Pinf) (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
