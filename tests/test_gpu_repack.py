@@ -173,3 +173,36 @@ def test_automatic_split_picks_a_cap_for_divergent_batches_only():
         u.solve()
     assert u.get_option("auto_split_k") == 0 and u.get_option("auto_split_verdict") == 0
     u.close()
+
+
+@pytest.mark.parametrize("dims,B", [((8, 2, 10), 32768), ((4, 2, 30), 16384)])
+def test_the_clock_may_move_a_one_row_shape_to_the_dynamic_tile_form_and_nothing_changes(dims, B):
+    """Round 3: once the one-row kernel's own question (plain launch or split solve) is settled, ONE eligible solve of a large
+    batch runs on the tile kernel's dynamic slot form (its one-row layout), timed, and is kept if the clock says so.  Whatever
+    the sequence of launch forms over repeated cold solves -- plain, split, dynamic tile form, kept or rejected -- every solve
+    must leave bit-identical results, equal to the oracle's on the unique instances."""
+    U = 256
+    base = sc.sweep_suite(*dims, B=U, max_iter=500)
+    suite = dict(problem=base["problem"], config=base["config"],
+                 cases={k: np.concatenate([v] * (B // U), axis=0) for k, v in base["cases"].items()})
+    ref = sc.run_cases(OracleSolver, base)
+    s = make_batch(suite)
+    assert s.kernel_path() == "regs"
+    s.set_x0(suite["cases"]["x0"])
+    s.set("Xref", suite["cases"]["Xref"])
+    first, verdicts, dyn_seen = None, [], False
+    for n in range(10):
+        s.reset()
+        s.solve()
+        out = {f: s.get(f) for f in ("x", "u", "vnew", "znew", "g", "y", "v", "z")}
+        st = s.status()
+        out.update(iter=st["iter"], solved=st["solved"], pr=st["primal_residual_state"], dr=st["dual_residual_input"])
+        if first is None:
+            first = out
+            assert np.array_equal(out["iter"][:U], ref["iter"].astype(int)) and np.array_equal(out["solved"][:U], ref["sol_solved"].astype(int))
+        else:
+            same(first, out, ("solve", n))
+        verdicts.append(s.get_option("tile_alt_verdict"))
+        dyn_seen = dyn_seen or s.get_option("last_tile_dyn") == 1
+    assert dyn_seen and verdicts[-1] != 0, verdicts               # the dynamic form was tried and the clock gave its verdict
+    s.close()

@@ -862,6 +862,22 @@ bool soc_active(const TinyBatch* b) {
     return (b->set.en_state_soc && !b->Acx.empty()) || (b->set.en_input_soc && !b->Acu.empty());
 }
 
+// histogram of the iteration counts the solve just enqueued leaves in d_status -> pinned host memory, asynchronously (hist_ev)
+static int enqueue_iteration_histogram(TinyBatch* b) {
+    if (!b->d_hist) {
+        HIP_TRY(b, hipMalloc(&b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned)));
+        HIP_TRY(b, hipHostMalloc(reinterpret_cast<void**>(&b->h_hist), TinyBatch::HIST_BINS * sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(b, hipEventCreateWithFlags(&b->hist_ev, hipEventDisableTiming));
+    }
+    HIP_TRY(b, hipMemsetAsync(b->d_hist, 0, TinyBatch::HIST_BINS * sizeof(unsigned), b->stream));
+    hipLaunchKernelGGL(iter_hist_kernel, dim3(64), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_hist);
+    HIP_TRY(b, hipGetLastError());
+    HIP_TRY(b, hipMemcpyAsync(b->h_hist, b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipEventRecord(b->hist_ev, b->stream));
+    b->hist_pending = true;
+    return TINY_OK;
+}
+
 int launch_solve(TinyBatch* b) {
     if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
         return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
@@ -989,19 +1005,59 @@ int launch_solve(TinyBatch* b) {
         for (int i = 0; i < TinyBatch::HIST_BINS; ++i) iters += (double)i * b->h_hist[i];
         if (++b->auto_probes > 1 && iters > 0.0 && hipEventElapsedTime(&ms, b->auto_ev0, b->auto_ev1) == hipSuccess && ms > 0.0f) {
             const double rate = (double)ms / iters;
-            if (b->auto_last_cap > 0) b->auto_split_rate = rate; else b->auto_plain_rate = rate;
-            if (b->auto_last_cap > 0 && b->auto_plain_rate > 0.0 && b->auto_verdict == 0)
-                b->auto_verdict = b->auto_split_rate < 0.97 * b->auto_plain_rate ? 1 : -1;
+            if (b->probe_was_tile) {
+                // the dynamic slot form of the tile kernel (one-row layout) against the best the one-row kernel did on this batch
+                b->tile_rate = rate;
+                const double best = (b->auto_verdict == 1 && b->auto_split_rate > 0.0) ? b->auto_split_rate : b->auto_plain_rate;
+                if (best > 0.0) b->tile_verdict = rate < 0.97 * best ? 1 : -1;
+            } else {
+                if (b->auto_last_cap > 0) b->auto_split_rate = rate; else b->auto_plain_rate = rate;
+                if (b->auto_last_cap > 0 && b->auto_plain_rate > 0.0 && b->auto_verdict == 0)
+                    b->auto_verdict = b->auto_split_rate < 0.97 * b->auto_plain_rate ? 1 : -1;
+            }
         }
+        b->probe_was_tile = false;
         if (b->auto_verdict == 0) {                   // (a kept split keeps its K; a rejected one stays rejected until the options change)
             b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
             b->auto_cap_max_iter = a.max_iter;
         }
     }
+    // The same batch on the tile kernel's dynamic slot form (its one-row layout, tile_dims.txt): persistent waves whose rows take
+    // the next instance off a device-wide counter the moment they are free.  It wins where solves are long and their iteration
+    // counts spread (3-32 % on 14 of the 16 N = 10 / 30 config-5 cells) and loses where they are short (config 3: 2.4x), so the
+    // clock decides here as well: once the one-row kernel's own question (plain or split) is settled, ONE eligible solve runs on
+    // the dynamic form, timed; it is kept if it beats the one-row kernel's best time per instance-iteration by 3 %.
+    const bool tile_alt_ok = auto_split && b->tile && !b->tile_is_jit && b->tile->W == 1 && b->tile_dyn_opt < 0 && !b->prefer_tile && !soc && !jk.lin &&
+                             !jk.het && !jk.adapt && !jk.dbg && !b->d_traj && !b->reset_duals && b->store_primal == 1 && !b->no_tile && b->repack_after < 0;
+    if (tile_alt_ok) {
+        const bool one_row_settled = b->auto_plain_rate > 0.0 && (b->auto_verdict != 0 || b->auto_cap == 0);
+        const bool probe_tile = b->tile_verdict == 0 && one_row_settled && !b->hist_pending;
+        if (b->tile_verdict == 1 || probe_tile) {
+            if (b->tile_verdict == 1 && ++b->tile_since >= 32) {             // distributions drift: re-open both questions
+                b->tile_since = 0; b->tile_verdict = 0; b->auto_verdict = 0; b->auto_plain_rate = 0.0; b->auto_since = 0;
+            } else {
+                if (probe_tile) {
+                    if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
+                    HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
+                }
+                const int save_dyn = b->tile_dyn_opt, save_lm = b->tile_lm, save_r = b->tile_r;
+                b->tile_dyn_opt = 1; b->tile_lm = -1; b->tile_r = 0;         // the first entry of the shape, dynamic slots
+                const int rc = launch_tile(b);
+                b->tile_dyn_opt = save_dyn; b->tile_lm = save_lm; b->tile_r = save_r;
+                if (rc != TINY_OK) return rc;
+                if (probe_tile) {
+                    HIP_TRY(b, hipEventRecord(b->auto_ev1, b->stream));
+                    if (int rc2 = enqueue_iteration_histogram(b)) return rc2;
+                    b->probe_was_tile = true;
+                }
+                return TINY_OK;
+            }
+        }
+    }
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
     if (auto_split && b->auto_verdict != 0 && ++b->auto_since >= 32) {      // distributions drift: ask the clock again now and then
-        b->auto_since = 0; b->auto_verdict = 0; b->auto_plain_rate = 0.0;
+        b->auto_since = 0; b->auto_verdict = 0; b->auto_plain_rate = 0.0; b->tile_verdict = 0;
     }
     // this solve is timed and leaves its iteration histogram behind -- while the question is open; a decided batch launches
     // without the two event records (each costs the next launch a dispatch bubble) and without the histogram pass
@@ -1060,17 +1116,7 @@ int launch_solve(TinyBatch* b) {
     }
     if (auto_probe) { HIP_TRY(b, hipEventRecord(b->auto_ev1, b->stream)); b->auto_last_cap = (cap > 0 && cap < b->set.max_iter && split_ok) ? cap : 0; }
     if (auto_probe) {                                 // feed the next solve's decision: histogram of THIS solve's iteration counts
-        if (!b->d_hist) {
-            HIP_TRY(b, hipMalloc(&b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned)));
-            HIP_TRY(b, hipHostMalloc(reinterpret_cast<void**>(&b->h_hist), TinyBatch::HIST_BINS * sizeof(unsigned), hipHostMallocDefault));
-            HIP_TRY(b, hipEventCreateWithFlags(&b->hist_ev, hipEventDisableTiming));
-        }
-        HIP_TRY(b, hipMemsetAsync(b->d_hist, 0, TinyBatch::HIST_BINS * sizeof(unsigned), b->stream));
-        hipLaunchKernelGGL(iter_hist_kernel, dim3(64), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_hist);
-        HIP_TRY(b, hipGetLastError());
-        HIP_TRY(b, hipMemcpyAsync(b->h_hist, b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(b, hipEventRecord(b->hist_ev, b->stream));
-        b->hist_pending = true;
+        if (int rc = enqueue_iteration_histogram(b)) return rc;
     }
     if (b->d_traj) b->traj_step += steps;            // the window moves one knot per MPC step
     return TINY_OK;
@@ -1794,6 +1840,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     }
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
+    if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
     if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form
     if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;
     if (!strcmp(name, "repack_after")) return b->repack_after;

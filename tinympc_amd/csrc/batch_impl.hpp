@@ -34,6 +34,9 @@ struct TinyBatch {
     tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
     bool tile_is_jit = false, tile_soc_failed = false;
     bool no_jit = false, jit_failed = false, variant_jit_failed = false;     // run-time instantiation of the one-row kernel for shapes outside kernel_dims.txt (jit.hpp)
+    int tile_verdict = 0, tile_since = 0;        // the dynamic tile form tried on a one-row shape: 1 kept, -1 rejected, 0 open (batch_api.hip launch_solve)
+    double tile_rate = 0.0;
+    bool probe_was_tile = false;
     int tile_lm = -1;                            // option "tile_lm"
     int tile_dyn_opt = -1;                       // option "tile_dyn"
     bool last_tile_dyn = false;

@@ -140,11 +140,12 @@ def sweep_cell(nx, nu, N, B=131072, device=0):
     s.set_device("Xref", xr_d.data_ptr())
     s.synchronize()
     del xr_d
-    ms = _cold_solves(s, 3)
+    # (a shape the one-row kernel holds settles its launch form over the first solves: plain, split, the tile kernel's dynamic form)
+    ms = _cold_solves(s, 3 if s.kernel_path() == "tile" else 8)
     st = s.reduce_stats()
     e = _entry("random sweep cell (nx=%d, nu=%d, N=%d) x %d, one cold solve, max_iter 500 (BASELINE configs[4])" % (nx, nu, N, B),
                min(ms), B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B,
-               automatic_split_k=s.get_option("auto_split_k"))
+               automatic_split_k=s.get_option("auto_split_k"), tile_alt_verdict=s.get_option("tile_alt_verdict"))
     s.close()
     return e
 
