@@ -1054,6 +1054,7 @@ int launch_solve(TinyBatch* b) {
             }
         }
     }
+    b->last_tile_dyn = false;                        // (this launch runs on the one-row kernel)
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
     if (auto_split && b->auto_verdict != 0 && ++b->auto_since >= 32) {      // distributions drift: ask the clock again now and then

@@ -27,20 +27,20 @@ for stage in "$@"; do
       echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -6 $O/pytest_gpu.txt ;;
     bench)
       timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; tail -c 1500 $O/bench_driver_flags.json; echo
-      timeout 600 python bench.py --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
-      timeout 300 python bench.py --steps-per-launch 1 --no-cpu-baseline --no-regimes > $O/bench_per_step.json 2> $O/bench_per_step.err
-      TINYMPC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+      timeout 600 python bench.py --no-cpu-baseline --no-configs --min-seconds 2 > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
+      timeout 300 python bench.py --steps-per-launch 1 --no-cpu-baseline --no-regimes --no-configs --min-seconds 2 > $O/bench_per_step.json 2> $O/bench_per_step.err
+      TINYMPC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-regimes --min-seconds 2 > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
       tail -c 300 $O/bench_torchrun1.json; echo ;;
     prof)
       cd /tmp
       for mode in driver default step; do
         case $mode in driver) extra="--steps 20 --warmup 5" ;; default) extra="" ;; step) extra="--steps-per-launch 1 --warmup 0" ;; esac
-        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${mode}_trace -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.3 $extra > $R/$O/rocprof_${mode}_bench.json 2> $R/$O/rocprof_${mode}_trace.err
-        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_${mode}_fetch -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_fetch.err
-        timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_${mode}_write -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_write.err
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_${mode}_trace -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --no-configs --min-seconds 0.3 $extra > $R/$O/rocprof_${mode}_bench.json 2> $R/$O/rocprof_${mode}_trace.err
+        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_${mode}_fetch -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --no-configs --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_fetch.err
+        timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_${mode}_write -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --no-configs --min-seconds 0.05 $extra > /dev/null 2> $R/$O/rocprof_${mode}_write.err
       done
       # SQ counters of the fused launches (issue utilisation of the headline kernel): their own pass, kernel-trace only
-      timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $R/$O/prof_default_sq -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --min-seconds 0.05 > /dev/null 2> $R/$O/rocprof_default_sq.err
+      timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $R/$O/prof_default_sq -o hover -- python $R/bench.py --no-cpu-baseline --no-regimes --no-configs --min-seconds 0.05 > /dev/null 2> $R/$O/rocprof_default_sq.err
       cd $R; find $O -name "*kernel_stats.csv" | head ;;
     configs)
       timeout 900 python tools/config_bench.py $O/configs_3_4.json > $O/configs.out 2> $O/configs.err; tail -c 800 $O/configs.out ;;
