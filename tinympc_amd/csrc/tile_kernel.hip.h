@@ -99,6 +99,13 @@ void admm_tile_kernel(const SolveArgs P) {
     constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0;
     constexpr bool KEEPX = !(LM & TILE_LM_REGEN) || SOC || LIN != 0;    // the cone / half-space slacks of the next solve start from x|u
     constexpr int SLOT = tile_lds_slot(NX, NU, W);
+    // DEFER (horizon split over R > 1 rows, trajectory kept in LDS): a sweep phase runs on ONE of the R horizon rows while the others
+    // idle, so everything in it costs R times its instructions.  The slot update (slack, dual, residual maxima: 9-10 lane-local
+    // instructions per slot) needs nothing from the sweep but x_i, which the sweep leaves in sX anyway -- it moves behind the
+    // sweep, where ALL rows run it on their own slots at once.  Same operations on the same values: bit-identical.
+    // Measured (profiles/r03_tile_forms_defer.md): +7-13 % on the wide R = 2 forms and on (8,8,50); neutral to -5 % on narrow shapes, whose
+    // fused step blocks had the slot update's instructions fill DPP wait states for free -- so only from 16 rows on.
+    constexpr bool DEFER = R > 1 && KEEPX && !SOC && LIN == 0 && NZ >= 16;
     static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4) && L >= 2, "tile shape");
     using T = TileTab<W>;
     const int lane = threadIdx.x & 63, row = lane >> 4, j16 = lane & 15;
@@ -343,6 +350,24 @@ void admm_tile_kernel(const SolveArgs P) {
                             if constexpr (!UB) __builtin_amdgcn_sched_barrier(0);
                             const double xi = xcur;
                             if constexpr (KEEPX) sX[l * 64 + lane] = xi;
+                            if constexpr (DEFER) {                                       // the chains only; the slot update follows the sweep
+                                if (g < N - 1) {
+                                    double dnl;
+                                    if constexpr (DL) dnl = dcur; else dnl = Dn[l];
+                                    double xn;
+                                    if constexpr (TFUSED) {                              // (the one-row kernel's placement of the forward constant)
+                                        const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
+                                        xn = tile_matvec<W, NX, NZ>(t, t, mf2);
+                                    } else {
+                                        const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
+                                        xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);
+                                    }
+                                    if (l + 1 < L) xcur = xn; else xcarry = xn;
+                                    if (g == 0) x1v = xn;
+                                }
+                                lo_c = lo_n; hi_c = hi_n;
+                                continue;
+                            }
                             double tt, vn;
                             if constexpr (TFUSED) {
                                 if (g < N - 1) {
@@ -413,6 +438,22 @@ void admm_tile_kernel(const SolveArgs P) {
                                 }
                             }
                         }
+                    }
+                }
+                if constexpr (DEFER) {
+                    // ---- update_slack + update_dual + residual maxima (admm.cpp:81-98, 219-225, 314-317) of every row's own slots
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (sX: each lane reads back what it wrote itself)
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        const int g = g0 + l;
+                        const double xi = sX[l * 64 + lane];
+                        const double lo_c = UB ? (g == 0 ? lo_u0 : lo_u) : sLo[g * LW + jj], hi_c = UB ? (g == 0 ? hi_u0 : hi_u) : sHi[g * LW + jj];
+                        const double tt = xi + G[l];
+                        const double vn = vmin64(hi_c, vmax64(lo_c, tt));
+                        pmax = vmax_abs64(pmax, xi - vn);
+                        if constexpr (VL_) dmax = vmax_abs64(dmax, sV[l * SLOT + li] - vn); else dmax = vmax_abs64(dmax, VP[l] - vn);
+                        G[l] = tt - vn;
+                        VN[l] = vn;
                     }
                 }
                 iter += 1;
