@@ -131,6 +131,31 @@ def test_tile_kernel_matches_oracle(dims, B, max_iter):
     assert_match(run_cases_hip(warm), sc.run_cases(OracleSolver, warm), RTOL, f"tile warm {dims}")
 
 
+@pytest.mark.parametrize("dims", [(4, 2, 30), (4, 4, 30)])
+@pytest.mark.parametrize("dyn", [0, 1])
+def test_half_row_form_matches_oracle(dims, dyn):
+    """Round 3: shapes with nx+nu <= 8 can run TWO instances per DPP row (tile kernel, W = 0: 8 instances per wave, every column of a
+    mat-vec as a pair of bank-masked `v_fmac_f64_dpp row_newbcast` -- low halves first, one wait state, high halves, because a
+    bank-masked DPP op re-writes its disabled lanes with a vdst value it read WITHOUT interlock, tools/ubench/ubench_dpp_bankmask2.hip).
+    Ragged batch (37 = 4 full waves + 5), cold and warm solves, static tiles and dynamic slots, against the oracle."""
+    suite = sc.sweep_suite(*dims, B=37, max_iter=300)
+    opts = {"prefer_tile": 1, "tile_w": 0, "tile_dyn": dyn}
+    s = make_batch(suite)
+    for k, v in opts.items():
+        s.set_option(k, v)
+    assert s.kernel_path() == "tile"
+    s.close()
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite, options=opts)
+    assert_match(out, ref, RTOL, f"half rows {dims}")
+    assert len(np.unique(ref["iter"])) > 3
+    warm = dict(problem=suite["problem"], config=suite["config"], cases=dict(suite["cases"]))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        warm["cases"][k] = ref[k]
+    warm["cases"]["x0"] = suite["cases"]["x0"] * 0.7
+    assert_match(run_cases_hip(warm, options=opts), sc.run_cases(OracleSolver, warm), RTOL, f"half rows warm {dims}")
+
+
 def test_linear_constraints_register_resident_vs_coverage():
     """The LIN variants of the one-row kernel (half-space projections as DPP broadcast-FMA row sums) and the coverage
     kernel must agree with the oracle AND the fast path must really be the one that ran."""

@@ -139,6 +139,7 @@ static const TileEntry* pick_tile_entry(const TinyBatch* b, bool ub) {
         const TileEntry* t = g_tiles[i];
         if (t->nx != b->nx || t->nu != b->nu || t->N != b->N) continue;
         if (!(ub ? (t->kub != nullptr || t->k != nullptr) : (t->k != nullptr))) continue;
+        if (b->tile_w >= 0 && t->W != b->tile_w) continue;                  // option "tile_w" (experiments): 0 = half rows
         if (b->tile_r > 0 && t->R == b->tile_r && (b->tile_lm < 0 || t->lm == b->tile_lm)) return t;
         if (b->tile_r == 0 && b->tile_lm >= 0 && t->lm == b->tile_lm) return t;
         if (!first_ok) first_ok = t;
@@ -416,7 +417,7 @@ static int tile_lin_variant(const TinyBatch* b) {
     const int km = lin_kmax(b);
     if (km == 0) return 0;
     const int lv = ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
-    const long LW = 16L * b->tile->W;
+    const long LW = 16L * std::max(1, b->tile->W);
     const int r2 = b->tile_is_jit ? b->tile->R : variant_tile_r(b);
     const long lds = 8L * (2L * b->N * LW + (long)(b->N / r2) * 64 + ((lv & 1) ? 3L * km * LW : 1) + ((lv & 2) ? 3L * b->N * km * LW : 1));
     return lds <= 60 * 1024 ? lv : 0;
@@ -452,7 +453,7 @@ static int launch_tile(TinyBatch* b) {
         // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
         // register / LDS budget of THAT form, not from the compiled-in plain form's entry)
         if (!b->tile_is_jit) vR = variant_tile_r(b);
-        jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, b->tile->W, vR, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
+        jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
         if (!jit_fn) {                               // the coverage kernel takes over
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }
@@ -461,7 +462,7 @@ static int launch_tile(TinyBatch* b) {
         }
     }
     if (b->tab_dirty || b->h_ttab.empty()) {
-        if (b->tile->W == 1) build_tile_tables_w<1>(b); else build_tile_tables_w<2>(b);
+        if (b->tile->W <= 1) build_tile_tables_w<1>(b); else build_tile_tables_w<2>(b);      // (W = 0, half rows, reads the one-row tables)
         if (b->ttab_doubles < b->h_ttab.size()) {
             if (b->d_ttab) (void)hipFree(b->d_ttab);
             b->d_ttab = nullptr;
@@ -495,7 +496,7 @@ static int launch_tile(TinyBatch* b) {
     const TileEntry* te = jit_fn ? nullptr : pick_tile_entry(b, ub);
     if (!jit_fn && !te) return fail(b, TINY_ERR_UNSUPPORTED, "no compiled-in tile kernel form for (%d,%d,%d)", b->nx, b->nu, b->N);
     if (te) vR = te->R;
-    const int ipw = 4 / (b->tile->W * vR);
+    const int ipw = (te && te->W == 0) ? 8 / vR : 4 / (std::max(1, b->tile->W) * vR);         // instances per wave (half rows: two per DPP row)
     int grid = (b->batch + ipw - 1) / ipw;
     if (b->grid_waves_per_cu > 0) {
         const long cap = (long)b->num_cus * b->grid_waves_per_cu;
@@ -1027,7 +1028,7 @@ int launch_solve(TinyBatch* b) {
     // counts spread (3-32 % on 14 of the 16 N = 10 / 30 config-5 cells) and loses where they are short (config 3: 2.4x), so the
     // clock decides here as well: once the one-row kernel's own question (plain or split) is settled, ONE eligible solve runs on
     // the dynamic form, timed; it is kept if it beats the one-row kernel's best time per instance-iteration by 3 %.
-    const bool tile_alt_ok = auto_split && b->tile && !b->tile_is_jit && b->tile->W == 1 && b->tile_dyn_opt < 0 && !b->prefer_tile && !soc && !jk.lin &&
+    const bool tile_alt_ok = auto_split && b->tile && !b->tile_is_jit && b->tile->W <= 1 && b->tile_dyn_opt < 0 && !b->prefer_tile && !soc && !jk.lin &&
                              !jk.het && !jk.adapt && !jk.dbg && !b->d_traj && !b->reset_duals && b->store_primal == 1 && !b->no_tile && b->repack_after < 0;
     if (tile_alt_ok) {
         const bool one_row_settled = b->auto_plain_rate > 0.0 && (b->auto_verdict != 0 || b->auto_cap == 0);
@@ -1731,6 +1732,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "no_tile")) { b->no_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "tile_dyn")) b->tile_dyn_opt = (int)value;   // -1 (default): by batch size; 0: static tiles; 1: the dynamic form whenever it exists
+    else if (!strcmp(name, "tile_w")) b->tile_w = (int)value;      // experiments: only entries with this W (0 = half rows, -1 = any)
     else if (!strcmp(name, "tile_lm")) b->tile_lm = (int)value;    // experiments: the tile_dims.txt entry with this LM column
     else if (!strcmp(name, "tile_r")) b->tile_r = (int)value;      // experiments: the tile_dims.txt entry with this R (0: the first that fits)
     else if (!strcmp(name, "step_log")) b->step_log = value != 0;

@@ -37,6 +37,7 @@ struct TinyBatch {
     int tile_verdict = 0, tile_since = 0;        // the dynamic tile form tried on a one-row shape: 1 kept, -1 rejected, 0 open (batch_api.hip launch_solve)
     double tile_rate = 0.0;
     bool probe_was_tile = false;
+    int tile_w = -1;                             // option "tile_w"
     int tile_lm = -1;                            // option "tile_lm"
     int tile_dyn_opt = -1;                       // option "tile_dyn"
     bool last_tile_dyn = false;

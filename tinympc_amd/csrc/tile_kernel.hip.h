@@ -29,6 +29,46 @@ struct TileTab {
     static constexpr int doubles(int N, int kmax = LIN_KMAX) { return tlin_offset(N, kmax) + 3 * N * kmax * LW; }
 };
 
+// HALF rows: lanes 0-7 and 8-15 of a DPP row carry two different instances.  `row_newbcast:k` broadcasts ONE lane to the whole row, so
+// a column of the mat-vec takes two instructions, each writing one half only (bank_mask: write-enable per bank of 4 lanes; honoured by
+// the DP-ALU DPP form at no cost, tools/ubench/ubench_dpp_bankmask.hip): lanes 0-7 get lane k, lanes 8-15 get lane 8+k.  Per instance
+// that is the same number of FMA issue slots as a full row gives -- the gain is everywhere else: every lane-local instruction (the
+// slot update is 13 of the 25 instructions per slot at (4,2)) now serves twice the instances, and so does every register.
+// HARDWARE NOTE (measured, tools/ubench/ubench_dpp_bankmask2.hip; not in the LLVM hazard tables): a bank-masked DPP instruction
+// writes its DISABLED lanes back with the value of vdst it read at operand fetch ("old"), and that read is NOT interlocked against a
+// VALU write of vdst in the instruction before -- `fmac bank_mask:0x3` directly followed by `fmac bank_mask:0xc` on the same
+// accumulator loses the first one's result (the second writes the stale lanes 0-7 back).  One wait state in between is enough.
+// So a chain runs all its low-half FMAs (their enabled lanes accumulate through the interlocked src2 path; the disabled lanes keep
+// being re-written with a value that does not change), then `s_nop 0`, then all its high-half FMAs.
+#define THL_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:%2+" #k " row_mask:0xf bank_mask:0x3\n\t"
+#define THH_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:8+%2+" #k " row_mask:0xf bank_mask:0xc\n\t"
+#define THL1 THL_(3, 0)
+#define THL2 THL1 THL_(4, 1)
+#define THL3 THL2 THL_(5, 2)
+#define THL4 THL3 THL_(6, 3)
+#define THL5 THL4 THL_(7, 4)
+#define THL6 THL5 THL_(8, 5)
+#define THL7 THL6 THL_(9, 6)
+#define THL8 THL7 THL_(10, 7)
+#define THH1 THH_(3, 0)
+#define THH2 THH1 THH_(4, 1)
+#define THH3 THH2 THH_(5, 2)
+#define THH4 THH3 THH_(6, 3)
+#define THH5 THH4 THH_(7, 4)
+#define THH6 THH5 THH_(8, 5)
+#define THH7 THH6 THH_(9, 6)
+#define THH8 THH7 THH_(10, 7)
+#define RINGH_CASE(K)                                                                       \
+    if constexpr (NCOL == K) {                                                              \
+        asm("s_nop 1\n\t" THL##K "s_nop 0\n\t" THH##K : "+&v"(a0) : "v"(src), "i"(COL0), TM##K);   \
+    }
+// a0 += sum_k bcast_half(src, COL0+k) * m[k]   (each half of the row reads its OWN lanes COL0+k)
+template <int COL0, int NCOL>
+__device__ __forceinline__ void ring1_half(double& a0, double src, const double* m) {
+    static_assert(NCOL >= 1 && COL0 + NCOL <= 8, "one half row");
+    RINGH_CASE(1) RINGH_CASE(2) RINGH_CASE(3) RINGH_CASE(4) RINGH_CASE(5) RINGH_CASE(6) RINGH_CASE(7) RINGH_CASE(8)
+}
+
 // (a, b) = (values of the even DPP row, values of the odd DPP row) of each 32-lane half, visible in both rows
 __device__ __forceinline__ void swap16(double v, double& a, double& b) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
@@ -43,7 +83,9 @@ template <int W, int C0, int C1>
 __device__ __forceinline__ double tile_matvec(double init, double src, const double* m) {
     double acc = init;
     if constexpr (C1 > C0) {
-        if constexpr (W == 1) {
+        if constexpr (W == 0) {
+            ring1_half<C0, C1 - C0>(acc, src, m);
+        } else if constexpr (W == 1) {
             ring1<C0, C1 - C0>(acc, src, m);
         } else {
             double a, b;
@@ -68,10 +110,11 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
 enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_VP = 8, TILE_LM_ALL = 15 };
 constexpr int tile_lds_arrays(int lm) { return ((lm & TILE_LM_QX) ? 1 : 0) + ((lm & TILE_LM_DN) ? 1 : 0) + ((lm & TILE_LM_VP) ? 1 : 0); }
 constexpr int tile_reg_arrays(int lm) { return 5 - tile_lds_arrays(lm); }
-constexpr int tile_lds_slot(int nx, int nu, int w) { return (4 / w) * (nx + nu) + 1; }
+// (w = 0: HALF rows -- an instance with nx+nu <= 8 takes 8 lanes, two instances share a DPP row; see admm_tile_kernel)
+constexpr int tile_lds_slot(int nx, int nu, int w) { return (w == 0 ? 8 : 4 / w) * (nx + nu) + 1; }
 // bytes of wave-private LDS: bound tables (unless UB), the trajectory (unless REGEN), the offloaded arrays
 constexpr long tile_lds_bytes(int nx, int nu, int n, int w, int r, int lm, bool ub) {
-    return 8L * (2L * (ub ? 2 : n) * 16 * w + ((lm & TILE_LM_REGEN) ? 1 : (n / r) * 64) +
+    return 8L * (2L * (ub ? 2 : n) * 16 * (w == 0 ? 1 : w) + ((lm & TILE_LM_REGEN) ? 1 : (n / r) * 64) +
                  tile_lds_arrays(lm) * (long)(n / r) * tile_lds_slot(nx, nu, w));
 }
 // two waves per SIMD when the L-long register arrays + the matrix rows fit 256 VGPRs AND eight waves' LDS fits the CU
@@ -93,7 +136,10 @@ __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
-    constexpr int NZ = NX + NU, LW = 16 * W, L = N / R, RPI = W * R, IPW = 4 / RPI;
+    constexpr bool HR = W == 0;                                        // half rows: two instances per DPP row (nx+nu <= 8)
+    constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
+    constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
+    constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
     constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
     constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
     constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0;
@@ -106,13 +152,14 @@ void admm_tile_kernel(const SolveArgs P) {
     // Measured (profiles/r03_tile_forms_defer.md): +7-13 % on the wide R = 2 forms and on (8,8,50); neutral to -5 % on narrow shapes, whose
     // fused step blocks had the slot update's instructions fill DPP wait states for free -- so only from 16 rows on.
     constexpr bool DEFER = R > 1 && KEEPX && !SOC && LIN == 0 && NZ >= 16;
-    static_assert(N % R == 0 && NZ <= LW && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4) && L >= 2, "tile shape");
-    using T = TileTab<W>;
-    const int lane = threadIdx.x & 63, row = lane >> 4, j16 = lane & 15;
-    const int inst = row / RPI, sub = row % RPI, wrow = sub % W, hrow = sub / W;
+    static_assert(N % R == 0 && NZ <= (HR ? 8 : LW) && RPI <= 4 && (RPI == 1 || RPI == 2 || RPI == 4) && L >= 2, "tile shape");
+    static_assert(!HR || (!SOC && LIN == 0), "half rows: box constraints only");
+    using T = TileTab<WW>;
+    const int lane = threadIdx.x & 63, row = lane >> (HR ? 3 : 4), j16 = lane & (HR ? 7 : 15);
+    const int inst = row / RPI, sub = row % RPI, wrow = sub % WW, hrow = sub / WW;
     const int jj = wrow * 16 + j16;
     const bool is_state = jj < NX, is_input = jj >= NX && jj < NZ;
-    const int li = jj < NZ ? (row / W) * NZ + jj : (4 / W) * NZ;       // this lane's entry of a compact LDS slot (the dummy beyond nx+nu)
+    const int li = jj < NZ ? (row / WW) * NZ + jj : (SLOT - 1);       // this lane's entry of a compact LDS slot (the dummy beyond nx+nu)
 
     __shared__ double sLo[NB * LW];
     __shared__ double sHi[NB * LW];
@@ -157,15 +204,14 @@ void admm_tile_kernel(const SolveArgs P) {
     const int cone_c = proj_lane ? jj - cone_base : 0;
     const float cone_mu = (float)cone_mu_d;                            // admm.cpp:39 takes mu as float
     // lane that holds knot-vector row r of THIS instance and horizon row (the cone may straddle the two W rows)
-    const int group_lane0 = ((lane >> 4) - wrow) * 16;
+    const int group_lane0 = ((lane >> 4) - wrow) * 16;     // (cone variants only: never with half rows)
     auto lane_of_row = [&](const int r) { return group_lane0 + (r >> 4) * 16 + (r & 15); };
     const double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const double lo_u = sLo[LW + jj], hi_u = sHi[LW + jj], lo_u0 = sLo[jj], hi_u0 = sHi[jj];     // UB (N >= 2 always)
 
-    const unsigned long long inst_mask =
-        (RPI == 4) ? ~0ull : ((((1ull << (16 * RPI)) - 1ull)) << (inst * 16 * RPI));
+    const unsigned long long inst_mask = (LPI == 64) ? ~0ull : ((((1ull << (LPI & 63)) - 1ull)) << (inst * LPI));
     const int nsteps = P.steps > 1 ? P.steps : 1;
     const int g0 = hrow * L;                                           // first global slot of this row
     const int ntiles = (P.batch + IPW - 1) / IPW;
@@ -196,7 +242,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 int base = 0;
                 if (lane == first) base = atomicAdd(P.work_counter, n);
                 base = __shfl(base, first);
-                const int leader = (lane / (16 * RPI)) * (16 * RPI);                     // leader lane of this lane's slot
+                const int leader = (lane / LPI) * LPI;                     // leader lane of this lane's slot
                 if (need) { b = base + __popcll(m & ((1ull << leader) - 1ull)); fresh = b < P.batch; }
                 if (base + n >= P.batch) exhausted = true;
             }
@@ -277,8 +323,8 @@ void admm_tile_kernel(const SolveArgs P) {
 #pragma unroll
                 for (int ph = R - 1; ph >= 0; --ph) {
                     if (ph < R - 1) {                                  // p_{i+1} | r_i handed down from the row above
-                        pcur = __shfl(pcur, (lane + LW) & 63);
-                        qhi = __shfl(qhi, (lane + LW) & 63);
+                        pcur = __shfl(pcur, (lane + ROWL) & 63);
+                        qhi = __shfl(qhi, (lane + ROWL) & 63);
                     }
                     if (hrow == ph) {
                         // QX in LDS: read two steps ahead of its use (a lone wave per SIMD has nothing else to hide the LDS latency
@@ -321,7 +367,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 double pmax = 0.0, dmax = 0.0, xcarry = 0.0;
 #pragma unroll
                 for (int ph = 0; ph < R; ++ph) {
-                    if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);    // x_g | u_{g-1} of this row's first slot
+                    if (ph > 0) xcarry = __shfl(xcarry, (lane - ROWL) & 63);    // x_g | u_{g-1} of this row's first slot
                     if (hrow == ph) {
                         double xcur = (ph > 0) ? xcarry : x0v;         // x_g | u_{g-1} of the slot being processed
                         // the box of slot l+1 is read from LDS while slot l is worked on (as admm_kernel.hip.h does): a lone wave
@@ -515,7 +561,7 @@ void admm_tile_kernel(const SolveArgs P) {
                         double xcarry = 0.0;
 #pragma unroll
                         for (int ph = 0; ph < R; ++ph) {
-                            if (ph > 0) xcarry = __shfl(xcarry, (lane - LW) & 63);
+                            if (ph > 0) xcarry = __shfl(xcarry, (lane - ROWL) & 63);
                             if (hrow == ph) {
                                 double xcur = (ph > 0) ? xcarry : x0_last;
 #pragma unroll
@@ -567,7 +613,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 // residual maxima over the instance's lanes (state rows / input rows separately)
                 double ps = is_state ? rp : 0.0, pi = is_input ? rp : 0.0, ds = is_state ? rd : 0.0, di = is_input ? rd : 0.0;
 #pragma unroll
-                for (int off = 8 * RPI; off >= 1; off >>= 1) {
+                for (int off = LPI / 2; off >= 1; off >>= 1) {
                     ps = fmax(ps, __shfl_xor(ps, off)); pi = fmax(pi, __shfl_xor(pi, off));
                     ds = fmax(ds, __shfl_xor(ds, off)); di = fmax(di, __shfl_xor(di, off));
                 }

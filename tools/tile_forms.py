@@ -22,8 +22,8 @@ def forms():
         if len(f) >= 5:
             nx, nu, N, W, R = map(int, f[:5])
             lm = int(f[5]) if len(f) >= 6 else 99
-            if (R, lm) not in out.setdefault((nx, nu, N), []):
-                out[(nx, nu, N)].append((R, lm))
+            if (W, R, lm) not in out.setdefault((nx, nu, N), []):
+                out[(nx, nu, N)].append((W, R, lm))
     return out
 
 
@@ -65,11 +65,11 @@ def main():
         if nx + nu <= 16 and N <= 30:
             ms, iters, path = time_form(nx, nu, N, args.batch, args.reps + 2, {})
             rows.append(("one-row kernel (automatic split)", ms, iters, path))
-        for R, lm in fm.get(cell, []):
+        for W, R, lm in fm.get(cell, []):
             for dyn in (0, 1):
-                o = {"prefer_tile": 1, "tile_r": R, "tile_lm": lm, "tile_dyn": dyn}       # (LM 99 = the entry without an LM column)
+                o = {"prefer_tile": 1, "tile_w": W, "tile_r": R, "tile_lm": lm, "tile_dyn": dyn}       # (LM 99 = the entry without an LM column)
                 ms, iters, path = time_form(nx, nu, N, args.batch, args.reps, o)
-                rows.append(("R=%d LM=%s %s" % (R, "auto" if lm == 99 else lm, "dynamic" if dyn else "static"), ms, iters, path))
+                rows.append(("%sR=%d LM=%s %s" % ("half rows " if W == 0 else "", R, "auto" if lm == 99 else lm, "dynamic" if dyn else "static"), ms, iters, path))
         best = min(r[1] for r in rows)
         for name, ms, iters, path in rows:
             fl = tm.flops_per_iter(nx, nu, N)
