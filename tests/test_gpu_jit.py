@@ -110,6 +110,25 @@ def test_uninstantiated_wide_or_long_shape_runs_the_tile_kernel(dims, path):
         assert rel_err(out[k], ref[k]) < RTOL, k
 
 
+@pytest.mark.parametrize("dims", [(16, 8, 6), (6, 2, 60)])
+def test_uninstantiated_tile_shape_takes_the_dynamic_slot_form(dims):
+    """Round 3: a run-time instantiated tile shape gets the dynamic slot form as well (persistent grid, device-wide work counter) --
+    forced here on a small ragged batch (tile_dyn = 1); results = the static form's, bit for bit, and the oracle's."""
+    suite = sc.sweep_suite(*dims, B=37, max_iter=150)
+    ref = sc.run_cases(OracleSolver, suite)
+    static = run_cases_hip(suite, options={"tile_dyn": 0})
+    s = make_batch(suite)
+    s.set_option("tile_dyn", 1)
+    s.set_x0(suite["cases"]["x0"]); s.set("Xref", suite["cases"]["Xref"])
+    s.solve()
+    assert s.kernel_path() == "tile-jit" and s.get_option("last_tile_dyn") == 1
+    assert np.array_equal(s.status()["iter"], ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        assert np.array_equal(s.get(k), static[k]), k
+        assert rel_err(static[k], ref[k]) < RTOL, k
+    s.close()
+
+
 def test_many_halfspaces_stay_register_resident():
     """4 half-spaces per knot and family are compiled in; more get the KMAX = 8 / 16 / 32 variant at run time; 33 go to the
     coverage kernel.  Same results either way."""

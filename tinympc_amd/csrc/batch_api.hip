@@ -445,6 +445,7 @@ static int ensure_step_logs(TinyBatch* b, int steps) {
 
 static int launch_tile(TinyBatch* b) {
     hipFunction_t jit_fn = nullptr;
+    bool jit_dyn = false;
     const bool soc = soc_active(b);
     const int lv = tile_lin_variant(b);
     int vR = b->tile->R;                             // rows along the horizon of the form this launch takes
@@ -453,7 +454,16 @@ static int launch_tile(TinyBatch* b) {
         // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
         // register / LDS budget of THAT form, not from the compiled-in plain form's entry)
         if (!b->tile_is_jit) vR = variant_tile_r(b);
-        jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
+        // a shape outside tile_dims.txt with plain box constraints: large batches of more than one instance per wave take the dynamic
+        // slot form too (instantiated on first use like the static one; a failure falls back to the static form)
+        const int jipw = 4 / (std::max(1, b->tile->W) * vR);
+        jit_dyn = b->tile_is_jit && !soc && !lv && b->tile_dyn_opt != 0 && jipw >= 2 && b->grid_waves_per_cu <= 0 &&
+                  (b->tile_dyn_opt > 0 || (long)((b->batch + jipw - 1) / jipw) >= 16L * b->num_cus);
+        if (jit_dyn) {
+            jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, soc, lv, LIN_KMAX, &why, true);
+            if (!jit_fn) { jit_dyn = false; why.clear(); }
+        }
+        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
         if (!jit_fn) {                               // the coverage kernel takes over
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }
@@ -506,8 +516,17 @@ static int launch_tile(TinyBatch* b) {
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
 
     if (jit_fn) {
+        if (jit_dyn) {                              // persistent grid: what the chip holds at once
+            int per_cu = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, jit_fn, 64, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 4; }
+            if (!b->d_work_counter) HIP_TRY(b, hipMalloc(reinterpret_cast<void**>(&b->d_work_counter), sizeof(int)));
+            HIP_TRY(b, hipMemsetAsync(b->d_work_counter, 0, sizeof(int), b->stream));
+            a.work_counter = b->d_work_counter;
+            grid = std::min(grid, per_cu * b->num_cus);
+        }
         void* params[] = {&a};
         HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, b->stream, params, nullptr));
+        b->last_tile_dyn = jit_dyn;
     } else {
         // (jit_fn is null: no cone, no half-spaces.)  Dynamic form: a persistent grid -- as many waves as the chip holds at once --
         // whose slots draw instances from a device-wide counter; taken when more than one instance shares a wave (lock step makes

@@ -41,7 +41,7 @@ inline bool jit_tile_shape(int nx, int nu, int N, int* W, int* R) {
     }
     return false;
 }
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, int lin, int kmax, std::string* err);
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, int lin, int kmax, std::string* err, bool dyn = false);
 
 // Compile one instantiation ("tinympc_amd::admm_solve_kernel<...>" / "tinympc_amd::admm_tile_kernel<...>") without loading
 // it -- needs no GPU.  With TINYMPC_AMD_JIT_CACHE=<directory> set the code object is looked up / kept there (one file per
