@@ -156,6 +156,26 @@ def test_half_row_form_matches_oracle(dims, dyn):
     assert_match(run_cases_hip(warm, options=opts), sc.run_cases(OracleSolver, warm), RTOL, f"half rows warm {dims}")
 
 
+@pytest.mark.parametrize("dims", [(4, 2, 30), (8, 2, 10)])
+def test_one_row_shape_forms_are_interchangeable_with_an_affine_term(dims):
+    """The launch forms a one-row shape can take (one-row kernel; tile kernel in its one-row layout; half rows) are swapped by the
+    dispatcher from solve to solve, so they must agree BIT FOR BIT -- also with fdyn != 0, where the placement of the forward
+    constant decides the rounding ((f + A x) + B u in all of them)."""
+    suite = sc.sweep_suite(*dims, B=29, max_iter=200)
+    rng = np.random.default_rng(7)
+    suite["problem"] = dict(suite["problem"], f=rng.normal(0, 0.05, dims[0]))
+    ref = sc.run_cases(OracleSolver, suite)
+    one_row = run_cases_hip(suite)
+    assert_match(one_row, ref, RTOL, f"affine {dims}")
+    forms = [{"prefer_tile": 1, "tile_w": 1, "tile_dyn": 0}, {"prefer_tile": 1, "tile_w": 1, "tile_dyn": 1}]
+    if dims == (4, 2, 30):
+        forms += [{"prefer_tile": 1, "tile_w": 0, "tile_dyn": 0}, {"prefer_tile": 1, "tile_w": 0, "tile_dyn": 1}]
+    for o in forms:
+        out = run_cases_hip(suite, options=o)
+        for k in ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z"):
+            assert np.array_equal(out[k], one_row[k]), (k, o)
+
+
 def test_linear_constraints_register_resident_vs_coverage():
     """The LIN variants of the one-row kernel (half-space projections as DPP broadcast-FMA row sums) and the coverage
     kernel must agree with the oracle AND the fast path must really be the one that ran."""

@@ -356,7 +356,7 @@ void admm_tile_kernel(const SolveArgs P) {
                                 const double src = is_input ? qhi : pcur;
                                 const double res = tile_matvec<W, 0, NZ>(fma(qlo, smask, cb), src, mb);
                                 pcur = res;                                             // p_i | d_i
-                                const double dn = res * nim;
+                                const double dn = HR ? fma(res, nim, cf) : res * nim;   // (half rows: the one-row kernel's placement of the forward constant, so that the two are interchangeable bit for bit)
                                 if constexpr (DL) sD[l * SLOT + li] = dn; else Dn[l] = dn;
                             }
                             qhi = qlo;
@@ -406,7 +406,7 @@ void admm_tile_kernel(const SolveArgs P) {
                                         xn = tile_matvec<W, NX, NZ>(t, t, mf2);
                                     } else {
                                         const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
-                                        xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);
+                                        xn = tile_matvec<W, NX, NZ>(HR ? t : t + cf, t, mf2);
                                     }
                                     if (l + 1 < L) xcur = xn; else xcarry = xn;
                                     if (g == 0) x1v = xn;
@@ -431,7 +431,7 @@ void admm_tile_kernel(const SolveArgs P) {
                                     double dnl;
                                     if constexpr (DL) dnl = dcur; else dnl = Dn[l];
                                     const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);           // A x_i | u_i
-                                    const double xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);       // + f + B u_i | u_i
+                                    const double xn = tile_matvec<W, NX, NZ>(HR ? t : t + cf, t, mf2);   // + f + B u_i | u_i
                                     if (l + 1 < L) xcur = xn; else xcarry = xn;
                                     if (g == 0) x1v = xn;
                                 }
@@ -579,7 +579,7 @@ void admm_tile_kernel(const SolveArgs P) {
                                             fused_forward_step<NX, NU>(tt, vn, t, xn, xi, 0.0, 0.0, 0.0, mf1, mf2);
                                         } else {
                                             const double t = tile_matvec<W, 0, NX>(dnl, xi, mf1);
-                                            xn = tile_matvec<W, NX, NZ>(t + cf, t, mf2);
+                                            xn = tile_matvec<W, NX, NZ>(HR ? t : t + cf, t, mf2);
                                         }
                                         if (l + 1 < L) xcur = xn; else xcarry = xn;
                                     }
