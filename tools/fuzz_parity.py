@@ -63,6 +63,8 @@ def trial(seed):
     opts = {}
     if orng.random() < 0.35:                             # split solve: stop at K, carry the open instances on (must change nothing)
         opts = {"repack_after": int(orng.integers(1, max(2, kw["max_iter"]))), "repack_growth": int(orng.integers(2, 4))}
+    if orng.random() < 0.4:                              # round 3: the tile kernel's launch forms (must change nothing either): dynamic slots on
+        opts.update({"tile_dyn": int(orng.integers(0, 2)), "prefer_tile": int(orng.integers(0, 2)), "tile_r": int(orng.integers(0, 3))})   # a persistent grid, the one-row-layout / half-row forms of one-row shapes, the other R of a shape
     out = run_cases_hip(suite, options=opts)
     desc = f"seed {seed} shape {(nx, nu, N)} B {B} max_iter {kw['max_iter']} ct {kw['check_termination']} opts {opts} flags " + \
            "".join(str(cfg[k]) for k in ("en_state_bound", "en_input_bound", "en_state_soc", "en_input_soc", "en_state_linear",
