@@ -206,3 +206,39 @@ def test_the_clock_may_move_a_one_row_shape_to_the_dynamic_tile_form_and_nothing
         dyn_seen = dyn_seen or s.get_option("last_tile_dyn") == 1
     assert dyn_seen and verdicts[-1] != 0, verdicts               # the dynamic form was tried and the clock gave its verdict
     s.close()
+
+
+@pytest.mark.parametrize("name", ["tracking", "rocket_soc", "linear"])
+def test_a_launch_after_reset_does_not_read_the_zero_state_and_nothing_changes(name):
+    """Round 3: after tiny_batch_setup / tiny_batch_reset the library KNOWS every warm-start record is zero, and the next one-row
+    launch takes its state as zero without reading it (SolveArgs::cold; option auto_cold = 0 switches that off).  Same bits as the
+    launch that reads the zero records, equal to the oracle from the zero state; a second solve (warm) reads again."""
+    suite = {"tracking": lambda: sc.tracking_random_suite(B=41, seed=5), "rocket_soc": lambda: sc.rocket_random_suite(B=19, seed=6),
+             "linear": lambda: sc.random_linear_suite("quadrotor_20hz", B=9, seed=8)}[name]()
+    zero = {k: np.zeros_like(v) for k, v in suite["cases"].items() if k not in ("x0", "Xref", "Uref")}
+    cold = dict(problem=suite["problem"], config=suite["config"], cases=dict(suite["cases"], **zero))
+    ref = sc.run_cases(OracleSolver, cold)
+    outs = []
+    for auto in (1, 0):
+        s = make_batch(cold)
+        s.set_option("auto_cold", auto)
+        s.set_x0(cold["cases"]["x0"]); s.set("Xref", cold["cases"]["Xref"]); s.set("Uref", cold["cases"]["Uref"])
+        res = []
+        for rep in range(2):                                   # cold solve, then a warm one from what it left behind
+            s.solve()
+            o = {f: s.get(f) for f in ("x", "u", "vnew", "znew", "g", "y", "v", "z")}
+            o["iter"] = s.status()["iter"]
+            res.append(o)
+        s.reset()                                              # ... and the same cold solve again after a reset
+        s.solve()
+        o = {f: s.get(f) for f in ("x", "u", "vnew", "znew", "g", "y", "v", "z")}
+        o["iter"] = s.status()["iter"]
+        res.append(o)
+        s.close()
+        outs.append(res)
+    for a, b in zip(outs[0], outs[1]):
+        same(a, b, name)
+    same(outs[0][0], outs[0][2], name + " after reset")
+    assert np.array_equal(outs[0][0]["iter"], ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y"):
+        assert np.max(np.abs(outs[0][0][k] - ref[k])) <= 1e-9 * max(1.0, np.max(np.abs(ref[k]))), k

@@ -1,4 +1,10 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 1500 python tools/fuzz_parity.py 2500 50001 > $O/fuzz_parity.txt 2>&1; tail -4 $O/fuzz_parity.txt
-timeout 600 python tools/fuzz_closed_loop.py 300 9001 > $O/fuzz_closed_loop.txt 2>&1; tail -3 $O/fuzz_closed_loop.txt
+timeout 1200 python -m pytest tests -m gpu -q -x > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+python - <<'PY' 2>&1 | tee $O/config3_autocold.txt
+import sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import bench_configs
+e = bench_configs.config3()
+print("config3 ms %.3f plain %.3f auto %.3f frac %.3f" % (e["ms"], e["plain_launch_ms"], e["automatic_split_ms"], e["roofline"]["frac"]))
+PY
