@@ -1867,6 +1867,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "auto_split_k")) {
         if (b->hist_pending && hipEventSynchronize(b->hist_ev) == hipSuccess) {      // (a diagnostic may wait; a solve never does)
             b->hist_pending = false;
+            b->probe_was_tile = false;               // (the probe's clock reading is dropped with it: the next probe starts clean)
             b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
             b->auto_cap_max_iter = b->set.max_iter;
         }
