@@ -529,7 +529,8 @@ __device__ __forceinline__ void soc_project3(double s0, double s1, double s2, fl
     const double q0 = s0 * s0, q1 = s1 * s1;
     const double q = q0 + q1;
     r0 = s0; r1 = s1; r2 = s2;
-    const bool sure_inside = (u0 > 1e-30) && (q <= (u0 * u0) * (1.0 - 0x1p-20)) && (q < 1e70);     // see soc_component
+    // see soc_component; `&` on purpose: three compares and two s_and instead of nested EXEC-mask regions
+    const bool sure_inside = (u0 > 1e-30) & (q <= (u0 * u0) * (1.0 - 0x1p-20)) & (q < 1e70);
     if (__builtin_amdgcn_ballot_w64(!sure_inside) == 0ull) return;
     const float a = (float)sqrt(q);                                     // :42
     const double ad = (double)a;
@@ -544,6 +545,12 @@ __device__ __forceinline__ void soc_project3(double s0, double s1, double s2, fl
         r1 = outside ? scale * s1 : r1;
         r2 = outside ? scale * last : r2;
     }
+}
+// (cone, knot) items of a row whose cones start at the lanes of `heads`
+__device__ __forceinline__ int soc_items_of(unsigned heads, int nx, int n) {
+    int c = 0;
+    for (unsigned m = heads; m; m &= m - 1) c += (__builtin_ctz(m) < nx) ? n : n - 1;
+    return c;
 }
 // passes of 16 (cone, knot) items a row needs when every lane triple of the state / input rows carries a cone
 constexpr int soc_item_passes(int nx, int nu, int n) { return ((nx / 3) * n + (nu / 3) * (n - 1) + 15) / 16; }
@@ -600,7 +607,9 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sHi[N * 16];
     __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
     __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
-    __shared__ double sT[SOC ? 4 * N * 16 : 1];               // SOC: x + gc of every slot, transposed through LDS for the cone step
+    // SOC: x + gc of every slot, transposed through LDS for the cone step; + a dummy item (0, 0, 1) that the lanes without a
+    // (cone, knot) pair of their own project (onto itself) -- no EXEC-mask region around the gather / scatter of a pass
+    __shared__ double sT[SOC ? 4 * N * 16 + 4 : 1];
     __shared__ double sP[ADAPT ? 4 * NX * NX : 1];            // ADAPT: each row's own Pinf, column-major (lane j keeps column j current)
     // ADAPT: the lane tables every adaptation reads (ATAB_AT, ATAB_DK, ATAB_DP), lane-major [table][lane][AKC] so that a lane's
     // coefficients are consecutive (ds_read_b128), and each row's log of rho steps that C1 / C2 still have to take (flush_c)
@@ -646,19 +655,22 @@ void admm_solve_kernel(const SolveArgs P) {
     // item 16 p + j, counted cone by cone (ascending base lane): a state cone has N items (slots 0..N-1), an input cone N-1
     // (slots 1..N-1).  All four rows of a wave share the layout.
     constexpr int SOC_PASSES = SOC ? (soc_item_passes(NX, NU, N) > 0 ? soc_item_passes(NX, NU, N) : 1) : 1;
-    int item_at[SOC_PASSES];                                   // LDS offset (slot * 16 + base lane) of the item's first component, -1: none
+    int item_at[SOC_PASSES];                                   // LDS index of the item's first component (the dummy item: none)
     float item_mu[SOC_PASSES];
+    int soc_passes = 0;                                        // passes that hold an item (wave-uniform: a family whose cone is off has none)
     if constexpr (SOC) {
+        if (lane < 3) sT[4 * N * 16 + lane] = lane == 2 ? 1.0 : 0.0;
         const unsigned heads = (unsigned)(__builtin_amdgcn_ballot_w64(proj_lane && cone_c == 0) & 0xFFFFull);   // row 0 speaks for all
 #pragma unroll
         for (int p = 0; p < SOC_PASSES; ++p) {
             int t = p * 16 + j;
-            item_at[p] = -1; item_mu[p] = 1.0f;
+            item_at[p] = 4 * N * 16; item_mu[p] = 1.0f;
+            if (heads && p * 16 < soc_items_of(heads, NX, N)) soc_passes = p + 1;
             for (unsigned m = heads; m; m &= m - 1) {
                 const int hb = __builtin_ctz(m);
                 const int cnt = hb < NX ? N : N - 1;
                 if (t >= 0 && t < cnt) {
-                    item_at[p] = (t + (hb < NX ? 0 : 1)) * 16 + hb;
+                    item_at[p] = grp * N * 16 + (t + (hb < NX ? 0 : 1)) * 16 + hb;
                     item_mu[p] = (float)P.tab[TAB_VEC + VEC_CONE_MU * 16 + hb];
                     t = -1;
                 } else if (t >= 0) t -= cnt;
@@ -970,12 +982,12 @@ void admm_solve_kernel(const SolveArgs P) {
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int p = 0; p < SOC_PASSES; ++p) {
-                            const bool has = item_at[p] >= 0;
-                            const int at = grp * N * 16 + (has ? item_at[p] : 0);
-                            const double s0 = has ? sT[at] : 0.0, s1 = has ? sT[at + 1] : 0.0, s2 = has ? sT[at + 2] : 1.0;
+                            if (p > 0 && p >= soc_passes) break;            // wave-uniform
+                            const int at = item_at[p];
+                            const double s0 = sT[at], s1 = sT[at + 1], s2 = sT[at + 2];
                             double r0, r1, r2;
                             soc_project3(s0, s1, s2, item_mu[p], r0, r1, r2);
-                            if (has) { sT[at] = r0; sT[at + 1] = r1; sT[at + 2] = r2; }
+                            sT[at] = r0; sT[at + 1] = r1; sT[at + 2] = r2;  // (the dummy item: (0, 0, 1) onto itself, from every lane that has none)
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();

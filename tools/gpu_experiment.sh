@@ -1,3 +1,7 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 600 python -m pytest tests/test_gpu_repack.py -m gpu -q -x -k "reset" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+for v in abl1 abl2 abl3; do
+  echo "--- $v" >> $O/soc_abl.txt
+  TINYMPC_AMD_LIB=$PWD/tinympc_amd/libtinympc_amd_$v.so timeout 200 python tools/soc_iter_cost.py >> $O/soc_abl.txt 2>&1
+done
+cat $O/soc_abl.txt
