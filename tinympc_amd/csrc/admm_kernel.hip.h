@@ -994,8 +994,9 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                         for (int s = 0; s < N; ++s) {
                             const double tc = fma(X[s], socmask, GC[s]);
-                            const double pv = sT[(grp * N + s) * 16 + j];
-                            const double vc = (proj_lane && (is_state || s >= 1)) ? pv : tc;
+                            // what the passes left in this lane's cell: the projection where the lane belongs to an item, else the
+                            // x + gc the lane wrote itself (bit for bit tc: no select)
+                            const double vc = sT[(grp * N + s) * 16 + j];
                             GC[s] = tc - vc;                                        // :229 / :234  (gc + x) - vcnew
                             VC[s] = vc;
                         }
