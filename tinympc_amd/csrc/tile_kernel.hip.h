@@ -393,7 +393,7 @@ void admm_tile_kernel(const SolveArgs P) {
                             if constexpr (!UB) {
                                 lo_n = (l + 1 < L) ? sLo[(g + 1) * LW + jj] : 0.0; hi_n = (l + 1 < L) ? sHi[(g + 1) * LW + jj] : 0.0;
                             }
-                            if constexpr (!UB) __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (!UB || DL || VL_) __builtin_amdgcn_sched_barrier(0);   // (pins the reads ABOVE this step: the compiler otherwise sinks them to their use)
                             const double xi = xcur;
                             if constexpr (KEEPX) sX[l * 64 + lane] = xi;
                             if constexpr (DEFER) {                                       // the chains only; the slot update follows the sweep
