@@ -143,7 +143,8 @@ struct SolveArgs {
     // record -- one L2-resident line set instead of 8S bytes of HBM per instance
     int ref_shared;
     // tile kernel, dynamic form (tile_kernel.hip.h DYN): ONE device-wide counter of the instances handed out so far, zeroed by
-    // the host before the launch; a slot of a persistent wave takes the next instance off it the moment it is free
+    // the host before the launch; a slot of a persistent wave takes the next instance off it the moment it is free.
+    // one-row kernel: the counter of 4-instance tiles handed out BEYOND the grid's first ones (null: fixed grid stride)
     int* work_counter;
 };
 
@@ -692,7 +693,11 @@ void admm_solve_kernel(const SolveArgs P) {
     const int ninst = P.index ? *P.count : P.batch;
     const int ntiles = (ninst + 3) >> 2;
     const bool resumed = P.index != nullptr;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tiles of 4 instances: one per wave (grid = tiles), or -- a follow-up stage of a split solve, fewer waves than tiles -- the wave
+    // takes its next tile off the stage's counter the moment it is free (its tiles differ in depth: a fixed stride would make the
+    // stage wait for the slot that drew the deepest ones)
+    for (int tile = blockIdx.x; tile < ntiles;
+         tile = P.work_counter ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(P.work_counter, 1) : 0) + (int)gridDim.x : tile + (int)gridDim.x) {
         const int slot = tile * 4 + grp;
         if (slot < ninst) {
             const int b = resumed ? P.index[slot] : slot;

@@ -739,7 +739,7 @@ static __global__ __launch_bounds__(256) void iter_hist_kernel(const int4* __res
 // `cap` (0 = plain) with the stage schedule of launch_solve (cap, 2 cap, 4 cap, ... max_iter).  A stage costs its work
 // spread over the wave slots, or -- when it has fewer waves than slots -- the depth of its longest wave at a lone wave's
 // pace (half the paired pace), plus a launch and one record reload / store per instance it carries.
-static double predicted_time(const unsigned* hist, int max_iter, int cap, int growth, double slots, double launch_iters, double reload_iters) {
+static double predicted_time(const unsigned* hist, int max_iter, int cap, int growth, double slots, double launch_iters, double reload_iters, bool dynamic = false) {
     const int M = std::min(max_iter, (int)TinyBatch::HIST_BINS - 1);
     std::vector<double> cum(M + 2, 0.0);                     // cum[i] = instances with iter <= i
     double n = 0.0;
@@ -758,9 +758,11 @@ static double predicted_time(const unsigned* hist, int max_iter, int cap, int gr
             if (p > 1e-12) depth = i + 1 - lo;
         }
         const double waves = open / 4.0, per_slot = waves / slots;
-        // a follow-up stage walks its list with a fixed grid stride: a slot's time is the SUM of its waves' depths, the stage
-        // ends with the slowest slot (mean + 2.5 sigma of that sum); the first stage is balanced by the dispatcher
-        const double imbalance = first ? 0.0 : 2.5 * sqrt(std::max(per_slot, 1e-9) * std::max(second - work * work, 0.0));
+        // a follow-up stage that walks its list with a fixed grid stride: a slot's time is the SUM of its waves' depths, the stage
+        // ends with the slowest slot (mean + 2.5 sigma of that sum); the first stage is balanced by the dispatcher, a follow-up
+        // stage whose waves draw their tiles from a counter (`dynamic`) ends at most one wave's depth after the mean
+        const double imbalance = first ? 0.0 : (dynamic ? std::min(0.5 * depth, 2.5 * sqrt(std::max(second - work * work, 0.0)))
+                                                        : 2.5 * sqrt(std::max(per_slot, 1e-9) * std::max(second - work * work, 0.0)));
         const double t = std::max(work * per_slot + imbalance, 0.5 * depth);
         return t + launch_iters + (first ? 0.0 : reload_iters * std::max(1.0, waves / slots));
     };
@@ -775,7 +777,7 @@ static double predicted_time(const unsigned* hist, int max_iter, int cap, int gr
 }
 
 // the K (multiple of check_termination) with the smallest predicted time, 0 when a plain launch is within 5 % of it
-static int choose_split_for(int nx, int nu, int N, bool soc, int M, int ct, int gr, int num_cus, const unsigned* hist, double* ratio) {
+static int choose_split_for(int nx, int nu, int N, bool soc, int M, int ct, int gr, int num_cus, const unsigned* hist, double* ratio, int* growth_out = nullptr) {
     const int wps = solve_kernel_waves_per_simd(nx + nu, N, soc);
     const double slots = (double)num_cus * 4.0 * wps;         // wave slots of the chip
     // one wave-iteration (4 instances) in microseconds: its FLOPs at ~75 % of a SIMD's FP64 issue rate (76.8 GFLOP/s per SIMD),
@@ -785,20 +787,29 @@ static int choose_split_for(int nx, int nu, int N, bool soc, int M, int ct, int 
     const double fl = 4.0 * S + 2.0 * nx * nx + 3.0 * nx + (N - 1.0) * (4.0 * nx * nx + 8.0 * nx * nu + 2.0 * nu * nu + 4.0 * nu + 5.0 * nx) + 11.0 * S;
     const double t_it = 4.0 * fl * wps / (76.8e3 * (wps == 2 ? 0.75 : 0.45));
     const double launch_iters = 8.0 / t_it, reload_iters = 2.45 * (S / 156.0) / t_it;
-    const double plain = predicted_time(hist, M, 0, gr, slots, launch_iters, reload_iters);
+    const double plain = predicted_time(hist, M, 0, 2, slots, launch_iters, reload_iters);
     double best = plain;
-    int best_k = 0;
-    for (int k = std::max(ct, 4 - 4 % ct); k <= M / 2; k += ct) {
-        if (k > 64 && k % 8) continue;                        // coarser steps far out
-        const double t = predicted_time(hist, M, k, gr, slots, launch_iters, reload_iters);
-        if (t < best) { best = t; best_k = k; }
+    int best_k = 0, best_gr = gr > 0 ? gr : 2;
+    // gr <= 0: the stage schedule is part of the question -- K, 2K, 4K, ... or K, 4K, 16K, ... (fewer launches, deeper lock step)
+    const int grs[2] = {gr > 0 ? gr : 2, gr > 0 ? gr : 4};
+    for (int gi = 0; gi < (gr > 0 ? 1 : 2); ++gi) {
+        for (int k = std::max(ct, 4 - 4 % ct); k <= M / 2; k += ct) {
+            if (k > 64 && k % 8) continue;                    // coarser steps far out
+            const double t = predicted_time(hist, M, k, grs[gi], slots, launch_iters, reload_iters);
+            if (t < best) { best = t; best_k = k; best_gr = grs[gi]; }
+        }
     }
+    // One check interval of margin: the histogram is the LAST solve's, and being a step late costs next to nothing (measured on config 3,
+    // mode 8-9 of 262 144: K = 10 ... 14 within 3 %) while being a step early sends the whole mode through a second launch (K = 9
+    // +6 %, K = 8 +60 %)
+    if (best_k > 0 && best_k + ct <= M / 2 && predicted_time(hist, M, best_k + ct, best_gr, slots, launch_iters, reload_iters) <= 1.01 * best) best_k += ct;
     if (ratio) *ratio = plain > 0.0 ? best / plain : 1.0;
+    if (growth_out) *growth_out = best_gr;
     return (plain > 0.0 && best < 0.95 * plain) ? best_k : 0;
 }
 static int choose_split(const TinyBatch* b, const unsigned* hist, double* ratio) {
-    return choose_split_for(b->nx, b->nu, b->N, soc_active(b), b->set.max_iter, std::max(1, b->set.check_termination), std::max(2, b->repack_growth),
-                            b->num_cus, hist, ratio);
+    return choose_split_for(b->nx, b->nu, b->N, soc_active(b), b->set.max_iter, std::max(1, b->set.check_termination), b->repack_growth >= 2 ? b->repack_growth : 0,
+                            b->num_cus, hist, ratio, &const_cast<TinyBatch*>(b)->auto_growth);
 }
 
 // ---- adaptive rho: per-instance cache state + the lane tables of the adaptation step -----------------------------------
@@ -895,6 +906,14 @@ static int enqueue_iteration_histogram(TinyBatch* b) {
     HIP_TRY(b, hipMemcpyAsync(b->h_hist, b->d_hist, TinyBatch::HIST_BINS * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(b, hipEventRecord(b->hist_ev, b->stream));
     b->hist_pending = true;
+    return TINY_OK;
+}
+
+// index lists + per-stage counters of the split solve: [stage] list lengths, [32 + stage] tile counters
+static int ensure_repack_buffers(TinyBatch* b) {
+    if (b->d_repack_index) return TINY_OK;
+    HIP_TRY(b, hipMalloc(&b->d_repack_index, 2 * (size_t)b->batch * sizeof(int)));
+    HIP_TRY(b, hipMalloc(&b->d_repack_count, 2 * 32 * sizeof(int)));
     return TINY_OK;
 }
 
@@ -1020,8 +1039,10 @@ int launch_solve(TinyBatch* b) {
     // "repack_after" = -1 (the default): K comes from the iteration histogram of the previous eligible solve of this batch
     // (collected asynchronously; a solve never waits for it) through the cost model above -- a batch whose iteration
     // counts are uniform gets K = 0, i.e. the plain launch.
+    enum { MAX_STAGES = 32 };
     const bool split_ok = steps == 1 && !a.x0_next && !b->one_shot && !b->adaptive && a.check_termination > 0 && a.max_iter >= 16;
     const bool auto_split = b->repack_after < 0 && split_ok && b->batch >= 8192;
+    if (auto_split) { if (int rc = ensure_repack_buffers(b)) return rc; }      // (not inside a timed probe: the first split solve's clock reading must not pay for a hipMalloc)
     if (auto_split && b->hist_pending && hipEventQuery(b->hist_ev) == hipSuccess) {
         b->hist_pending = false;
         // the clock's word on the previous eligible solve: microseconds per instance-iteration, plain or split
@@ -1035,13 +1056,18 @@ int launch_solve(TinyBatch* b) {
                 b->tile_rate = rate;
                 const double best = (b->auto_verdict == 1 && b->auto_split_rate > 0.0) ? b->auto_split_rate : b->auto_plain_rate;
                 if (best > 0.0) b->tile_verdict = rate < 0.97 * best ? 1 : -1;
+            } else if (b->probe_was_growth) {
+                // the other stage schedule of a kept split (K, 4K, ... against K, 2K, ...): the cost model ranks them, the clock decides
+                if (b->auto_split_rate > 0.0 && rate < 0.97 * b->auto_split_rate) { b->auto_growth = b->growth_alt; b->auto_split_rate = rate; }
+                b->growth_verdict = 1;
             } else {
                 if (b->auto_last_cap > 0) b->auto_split_rate = rate; else b->auto_plain_rate = rate;
                 if (b->auto_last_cap > 0 && b->auto_plain_rate > 0.0 && b->auto_verdict == 0)
                     b->auto_verdict = b->auto_split_rate < 0.97 * b->auto_plain_rate ? 1 : -1;
             }
         }
-        b->probe_was_tile = false;
+        if (b->probe_was_growth) b->growth_verdict = 1;           // (asked once, whatever became of the reading)
+        b->probe_was_tile = false; b->probe_was_growth = false;
         if (b->auto_verdict == 0) {                   // (a kept split keeps its K; a rejected one stays rejected until the options change)
             b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
             b->auto_cap_max_iter = a.max_iter;
@@ -1055,11 +1081,11 @@ int launch_solve(TinyBatch* b) {
     const bool tile_alt_ok = auto_split && b->tile && !b->tile_is_jit && b->tile->W <= 1 && b->tile_dyn_opt < 0 && !b->prefer_tile && !soc && !jk.lin &&
                              !jk.het && !jk.adapt && !jk.dbg && !b->d_traj && !b->reset_duals && b->store_primal == 1 && !b->no_tile && b->repack_after < 0;
     if (tile_alt_ok) {
-        const bool one_row_settled = b->auto_plain_rate > 0.0 && (b->auto_verdict != 0 || b->auto_cap == 0);
+        const bool one_row_settled = b->auto_plain_rate > 0.0 && (b->auto_verdict == -1 || b->auto_cap == 0 || (b->auto_verdict == 1 && (b->growth_verdict != 0 || b->repack_growth >= 2)));
         const bool probe_tile = b->tile_verdict == 0 && one_row_settled && !b->hist_pending;
         if (b->tile_verdict == 1 || probe_tile) {
             if (b->tile_verdict == 1 && ++b->tile_since >= 32) {             // distributions drift: re-open both questions
-                b->tile_since = 0; b->tile_verdict = 0; b->auto_verdict = 0; b->auto_plain_rate = 0.0; b->auto_since = 0;
+                b->tile_since = 0; b->tile_verdict = 0; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = 0.0; b->auto_since = 0;
             } else {
                 if (probe_tile) {
                     if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
@@ -1083,11 +1109,14 @@ int launch_solve(TinyBatch* b) {
     const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
     if (auto_split && b->auto_verdict != 0 && ++b->auto_since >= 32) {      // distributions drift: ask the clock again now and then
-        b->auto_since = 0; b->auto_verdict = 0; b->auto_plain_rate = 0.0; b->tile_verdict = 0;
+        b->auto_since = 0; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = 0.0; b->tile_verdict = 0;
     }
     // this solve is timed and leaves its iteration histogram behind -- while the question is open; a decided batch launches
     // without the two event records (each costs the next launch a dispatch bubble) and without the histogram pass
-    const bool auto_probe = auto_split && !b->hist_pending && b->auto_verdict == 0;
+    // a kept split asks ONE more question: the other stage schedule, timed like the split itself was
+    const bool growth_probe = auto_split && !b->hist_pending && b->auto_verdict == 1 && b->growth_verdict == 0 && b->repack_growth < 2 &&
+                              b->auto_cap > 0 && b->auto_cap_max_iter == a.max_iter && b->auto_split_rate > 0.0;
+    const bool auto_probe = (auto_split && !b->hist_pending && b->auto_verdict == 0) || growth_probe;
     if (auto_probe) {
         if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
         HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
@@ -1104,25 +1133,22 @@ int launch_solve(TinyBatch* b) {
     };
     // split solve (repack_after = K): the launch stops at iteration K and lists the instances it leaves open (the kernel's
     // epilogue appends them, one atomic per wave that has any); a launch over that list carries on to 2K, the next one to 4K,
-    // ... max_iter (repack_growth = 2) -- four open instances per wave at every stage, and within a stage nearly all of them run the same number
+    // ... max_iter (repack_growth = 2; 4: K, 4K, 16K, ...; 0 = what the cost model picked) -- four open instances per wave at every stage, and within a stage nearly all of them run the same number
     // of iterations.  K is a multiple of check_termination so that the termination countdown of every stage is in phase.
     // Two index lists alternate; every stage has its own counter, all of them zeroed by one memset.
     int cap = b->repack_after > 0 ? b->repack_after
             : ((auto_split && b->auto_cap_max_iter == a.max_iter && b->auto_verdict >= 0 && b->auto_plain_rate > 0.0) ? b->auto_cap : 0);
     if (a.check_termination > 1) cap -= cap % a.check_termination;
     if (cap > 0 && cap < a.max_iter && split_ok) {
-        enum { MAX_STAGES = 32 };
-        if (!b->d_repack_index) {
-            HIP_TRY(b, hipMalloc(&b->d_repack_index, 2 * (size_t)b->batch * sizeof(int)));
-            HIP_TRY(b, hipMalloc(&b->d_repack_count, MAX_STAGES * sizeof(int)));
-        }
-        HIP_TRY(b, hipMemsetAsync(b->d_repack_count, 0, MAX_STAGES * sizeof(int), b->stream));
+        if (int rc = ensure_repack_buffers(b)) return rc;
+        HIP_TRY(b, hipMemsetAsync(b->d_repack_count, 0, 2 * MAX_STAGES * sizeof(int), b->stream));
         const int full = a.max_iter;
         int stage = 0;
         a.max_iter = cap;
         a.next_index = b->d_repack_index; a.next_count = b->d_repack_count;
         if (int rc = launch(grid)) return rc;
-        const int gr = std::max(2, b->repack_growth);
+        int gr = b->repack_growth >= 2 ? b->repack_growth : std::max(2, b->auto_growth);      // (option 0: the model's schedule, confirmed or overturned by the clock)
+        if (growth_probe) { gr = b->auto_growth == 2 ? 4 : 2; b->growth_alt = gr; b->probe_was_growth = true; }
         for (long base = cap; base < full; base *= gr, ++stage) {
             const bool last = gr * base >= full || stage + 2 >= MAX_STAGES;
             a.iter_base = (int)base; a.max_iter = last ? full : (int)(gr * base); a.reset_duals = 0;
@@ -1130,7 +1156,9 @@ int launch_solve(TinyBatch* b) {
             a.index = b->d_repack_index + (size_t)(stage & 1) * b->batch; a.count = b->d_repack_count + stage;
             a.next_index = last ? nullptr : b->d_repack_index + (size_t)((stage + 1) & 1) * b->batch;
             a.next_count = last ? nullptr : b->d_repack_count + stage + 1;
-            if (int rc = launch(std::min(grid, b->num_cus * b->repack_waves_per_cu))) return rc;      // its waves walk the list with a grid stride
+            // fewer waves than tiles: each takes its next tile off the stage's counter when it is free (repack_dynamic = 0: fixed grid stride)
+            a.work_counter = b->repack_dynamic ? b->d_repack_count + MAX_STAGES + stage : nullptr;
+            if (int rc = launch(std::min(grid, b->num_cus * b->repack_waves_per_cu))) return rc;
             if (last) break;
         }
     } else {
@@ -1772,9 +1800,10 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
-    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_pending = false; b->auto_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
+    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_pending = false; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);
-    else if (!strcmp(name, "repack_growth")) b->repack_growth = (int)value;
+    else if (!strcmp(name, "repack_growth")) { b->repack_growth = (int)value; b->growth_verdict = 0; }
+    else if (!strcmp(name, "repack_dynamic")) b->repack_dynamic = value != 0;   // follow-up stages: tiles off a counter (1) or a fixed grid stride (0)
     else if (!strcmp(name, "traj_step")) b->traj_step = value;
     else if (!strcmp(name, "timing")) {
         HIP_TRY(b, hipStreamSynchronize(b->stream));
@@ -1857,7 +1886,7 @@ int tiny_jit_used(char* out, int out_len) {
 // best split / plain launch.  What launch_solve consults with the histogram of the previous solve.
 int tiny_predict_split(const unsigned* hist, int nx, int nu, int N, int max_iter, int check_termination, int num_cus, double* ratio) {
     if (!hist || nx <= 0 || nu <= 0 || N < 2 || max_iter <= 0) return 0;
-    return choose_split_for(nx, nu, N, false, max_iter, std::max(1, check_termination), 2, num_cus > 0 ? num_cus : 256, hist, ratio);
+    return choose_split_for(nx, nu, N, false, max_iter, std::max(1, check_termination), 0, num_cus > 0 ? num_cus : 256, hist, ratio);
 }
 
 // read-back of derived state: "auto_split_k" (the K the automatic split picked from the last histogram, 0 = plain launch),
@@ -1867,12 +1896,14 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "auto_split_k")) {
         if (b->hist_pending && hipEventSynchronize(b->hist_ev) == hipSuccess) {      // (a diagnostic may wait; a solve never does)
             b->hist_pending = false;
-            b->probe_was_tile = false;               // (the probe's clock reading is dropped with it: the next probe starts clean)
+            b->probe_was_tile = b->probe_was_growth = false;   // (the probe's clock reading is dropped with it: the next probe starts clean)
             b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
             b->auto_cap_max_iter = b->set.max_iter;
         }
         return b->auto_cap;
     }
+    if (!strcmp(name, "auto_split_growth_verdict")) return b->growth_verdict;
+    if (!strcmp(name, "auto_split_growth")) return b->auto_growth;               // the stage schedule that goes with auto_split_k: K, g K, g^2 K, ...
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not

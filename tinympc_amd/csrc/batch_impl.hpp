@@ -102,7 +102,10 @@ struct TinyBatch {
     int auto_since = 0;                  // eligible solves since the last verdict: every 32nd one re-opens the question (plain + split timed again)
     int auto_verdict = 0;                // 0 undecided, 1 the split was measured faster (kept), -1 measured slower (plain launches from now on)
     double auto_gain = 0.0;              // predicted time of the split solve / plain solve (diagnostics)
-    int repack_waves_per_cu = 8, repack_growth = 2;   // grid of the follow-up stages; stage s runs to K * growth^s (measured best: 8, 2)
+    bool repack_dynamic = false;                 // follow-up stages of a split solve take their tiles off a per-stage counter (measured on config 3: 1-2 % SLOWER than the grid stride)
+    int repack_waves_per_cu = 8, repack_growth = 0;   // grid of the follow-up stages; stage s runs to K * growth^s (0: the cost model picks 2 or 4 with K)
+    int auto_growth = 2, growth_alt = 2, growth_verdict = 0;   // the stage schedule in use; the one on trial; 1 = the clock has compared the two
+    bool probe_was_growth = false;
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
     bool use_ub = true;                            // option "uniform_bounds": take the UB kernel variant when the box allows it
     bool bounds_uniform = false;                   // build_tables: every knot has the same box (admm_kernel.hip.h UB variant)

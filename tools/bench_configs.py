@@ -72,13 +72,14 @@ def config3(B=262144, device=0):
     plain = min(_cold_solves(s, 3))
     st = s.reduce_stats()
     s.set_option("repack_after", -1)                  # the default: automatic split (histogram -> K, kept if the clock confirms it)
-    auto = _cold_solves(s, 8)
+    auto = _cold_solves(s, 14)                        # (the first six settle the launch form: plain / split probes, stage schedule, tile alternative)
     st2 = s.reduce_stats()
     assert st2[0] == st[0] and st2[1] == st[1], "the split solve must reproduce the plain one"
-    best = min(min(auto[4:]), plain)
+    best = min(min(auto[6:]), plain)
     e = _entry("quadrotor_tracking (12,4,10) x %d, per-instance random Xref/Uref, one cold solve (BASELINE configs[2])" % B,
                best, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(),
-               plain_launch_ms=plain, automatic_split_ms=min(auto[4:]), automatic_split_k=s.get_option("auto_split_k"),
+               plain_launch_ms=plain, automatic_split_ms=min(auto[6:]), automatic_split_median_ms=float(np.median(auto[6:])), automatic_split_k=s.get_option("auto_split_k"),
+               automatic_split_growth=s.get_option("auto_split_growth"),
                automatic_split_verdict=s.get_option("auto_split_verdict"), solved_fraction=st[1] / B)
     s.close()
     del torch
