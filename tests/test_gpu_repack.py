@@ -78,6 +78,11 @@ def test_split_solve_large_divergent_batch_and_statistics():
     assert whole["iter"].max() > 2 * np.median(whole["iter"])
     for cap in (10, 24):
         same(whole, run({"repack_after": cap}), cap)
+    # the stage schedule (K, 2K, 4K, ... | K, 4K, 16K, ... | K, max_iter) and the way a follow-up stage hands out its tiles (fixed grid
+    # stride | one atomic per tile off the stage's counter, fewer waves than tiles) change nothing either
+    for opts in ({"repack_growth": 2}, {"repack_growth": 4}, {"repack_growth": 64}, {"repack_dynamic": 1, "repack_waves_per_cu": 1},
+                 {"repack_dynamic": 1, "repack_growth": 4, "repack_waves_per_cu": 2}, {"repack_dynamic": 0, "repack_waves_per_cu": 1}):
+        same(whole, run(dict(opts, repack_after=8)), opts)
     ref = sc.run_cases(OracleSolver, dict(base, cases={k: v[:32] for k, v in base["cases"].items()}))
     assert np.array_equal(whole["iter"][:32].astype(int), ref["iter"].astype(int))
 
