@@ -156,6 +156,31 @@ def test_half_row_form_matches_oracle(dims, dyn):
     assert_match(run_cases_hip(warm, options=opts), sc.run_cases(OracleSolver, warm), RTOL, f"half rows warm {dims}")
 
 
+@pytest.mark.parametrize("dims,lm,other", [((12, 2, 50), 22, 0), ((4, 2, 50), 23, 15), ((12, 4, 50), 23, 0), ((20, 4, 30), 20, 12)])
+@pytest.mark.parametrize("dyn", [0, 1])
+def test_tile_forms_that_keep_v_in_its_record_match_the_oracle(dims, lm, other, dyn):
+    """Round 3, LM bit 4: v|z (work->v, the slack of the iteration before) is held neither in registers nor in LDS -- the slot update
+    streams the old vnew|znew to the instance's v|z record, a solve's first iteration reads the record back, a solve that runs out of
+    iterations writes vnew over it (admm.cpp:431-446).  Cold, warm (v != vnew on entry: the first iteration's dual residual uses the
+    stored v) and out-of-iterations solves, ragged batch, against the oracle and bit for bit against the form that keeps v in LDS."""
+    suite = sc.sweep_suite(*dims, B=11, max_iter=120)
+    opts = {"tile_lm": lm, "tile_dyn": dyn}
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite, options=opts)
+    assert_match(out, ref, RTOL, f"v in its record {dims}")
+    assert 0 < ref["sol_solved"].sum() < len(ref["sol_solved"]) or ref["iter"].max() == 120 or len(np.unique(ref["iter"])) > 2
+    alt = run_cases_hip(suite, options={"tile_lm": other, "tile_dyn": dyn} if other else {"tile_lm": 0, "tile_r": 2, "tile_dyn": dyn})
+    for k in ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        assert np.array_equal(out[k], alt[k]), (k, dims)
+    warm = dict(problem=suite["problem"], config=dict(suite["config"], max_iter=7), cases=dict(suite["cases"]))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        warm["cases"][k] = ref[k]
+    warm["cases"]["x0"] = suite["cases"]["x0"] * 0.7
+    wref = sc.run_cases(OracleSolver, warm)
+    assert (wref["sol_solved"] == 0).any()                    # some run out of their 7 iterations: v = vnew on exit
+    assert_match(run_cases_hip(warm, options=opts), wref, RTOL, f"v in its record, warm {dims}")
+
+
 @pytest.mark.parametrize("dims", [(4, 2, 30), (8, 2, 10)])
 def test_one_row_shape_forms_are_interchangeable_with_an_affine_term(dims):
     """The launch forms a one-row shape can take (one-row kernel; tile kernel in its one-row layout; half rows) are swapped by the

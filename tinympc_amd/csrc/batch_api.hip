@@ -443,7 +443,9 @@ static int ensure_step_logs(TinyBatch* b, int steps) {
     return TINY_OK;
 }
 
-static int launch_tile(TinyBatch* b) {
+// dry: the launch form this batch would take, over ZERO instances -- everything a first launch pays once (code object load, occupancy
+// query, the work counter) without touching a record; the clock-decided dispatch does it in front of its timed probe
+static int launch_tile(TinyBatch* b, bool dry = false) {
     hipFunction_t jit_fn = nullptr;
     bool jit_dyn = false;
     const bool soc = soc_active(b);
@@ -497,7 +499,7 @@ static int launch_tile(TinyBatch* b) {
     const int steps = b->steps_per_launch > 1 ? b->steps_per_launch : 1;
     a.x0_next = (b->advance_x0 || steps > 1) ? b->d_x0 : nullptr;     // fused steps imply the plant step
     a.rho = b->cache.rho; a.tol_pri = b->set.abs_pri_tol; a.tol_dua = b->set.abs_dua_tol;
-    a.batch = b->batch; a.max_iter = b->set.max_iter; a.check_termination = b->set.check_termination; a.steps = steps;
+    a.batch = dry ? 0 : b->batch; a.max_iter = b->set.max_iter; a.check_termination = b->set.check_termination; a.steps = steps;
     if (steps > 1 && b->step_log) {
         if (int rc = ensure_step_logs(b, steps)) return rc;
         a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
@@ -512,7 +514,7 @@ static int launch_tile(TinyBatch* b) {
         const long cap = (long)b->num_cus * b->grid_waves_per_cu;
         if (cap < grid) grid = (int)cap;
     }
-    const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
+    const bool timed = !dry && b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
     if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
 
     if (jit_fn) {
@@ -1087,12 +1089,14 @@ int launch_solve(TinyBatch* b) {
             if (b->tile_verdict == 1 && ++b->tile_since >= 32) {             // distributions drift: re-open both questions
                 b->tile_since = 0; b->tile_verdict = 0; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = 0.0; b->auto_since = 0;
             } else {
+                const int save_dyn = b->tile_dyn_opt, save_lm = b->tile_lm, save_r = b->tile_r;
+                b->tile_dyn_opt = 1; b->tile_lm = -1; b->tile_r = 0;         // the first entry of the shape, dynamic slots
                 if (probe_tile) {
+                    // (what a kernel's FIRST launch pays once must not count against it: an empty launch of the same form goes first)
+                    if (int rc0 = launch_tile(b, true)) { b->tile_dyn_opt = save_dyn; b->tile_lm = save_lm; b->tile_r = save_r; return rc0; }
                     if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
                     HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
                 }
-                const int save_dyn = b->tile_dyn_opt, save_lm = b->tile_lm, save_r = b->tile_r;
-                b->tile_dyn_opt = 1; b->tile_lm = -1; b->tile_r = 0;         // the first entry of the shape, dynamic slots
                 const int rc = launch_tile(b);
                 b->tile_dyn_opt = save_dyn; b->tile_lm = save_lm; b->tile_r = save_r;
                 if (rc != TINY_OK) return rc;
@@ -1279,10 +1283,12 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     b->own_stream = true;
     const int nz = nx + nu;
     const size_t kpi_bytes = (size_t)batch * N * nz * sizeof(double);
+    // (+ one record and a little of zero padding: the tile kernel's VPG forms park the stores of lanes that hold no row there)
+    const size_t kpi_pad = (size_t)N * nz * sizeof(double) + 1024;
     double** kpis[] = {&b->d_ref, &b->d_prim, &b->d_slack, &b->d_dual, &b->d_slack_prev, &b->d_cslack, &b->d_cdual};
     for (double** p : kpis) {
-        if (hipMalloc(p, kpi_bytes) != hipSuccess) return bail(TINY_ERR_HIP);
-        if (hipMemsetAsync(*p, 0, kpi_bytes, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+        if (hipMalloc(p, kpi_bytes + kpi_pad) != hipSuccess) return bail(TINY_ERR_HIP);
+        if (hipMemsetAsync(*p, 0, kpi_bytes + kpi_pad, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
     }
     b->stage_doubles = (size_t)batch * std::max(nx * N, nu * (N - 1));       // the largest host-layout field (nu > nx happens)
     if (hipMalloc(&b->d_x0, (size_t)batch * nx * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);

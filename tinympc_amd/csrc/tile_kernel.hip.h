@@ -107,9 +107,16 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
 // what lets a lane hold a 50-knot horizon (R = 1: every row sweeps its own instance, no lanes idle in the sweeps) where round 2
 // had to split the horizon over two rows.  The LDS arrays are COMPACT: [slot][row group][NZ] + one dummy entry per slot that all
 // the lanes beyond nx+nu share (they only ever hold zeros).
-enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_VP = 8, TILE_LM_ALL = 15 };
+// bit 4 (VPG, instead of bit 3): v|z is not held at all.  Inside the iteration loop it is only ever the vnew|znew of the iteration
+// before -- which the slot update still has in its register when it needs it for the dual residual -- EXCEPT in a solve's first
+// iteration (work->v of the solve before: admm.cpp:431-441 returns before v = vnew).  So: the slot update streams the old
+// vnew|znew to the instance's v|z RECORD (one global store per slot, absorbed by L2: the resident instances' records fit it), a
+// solve's first iteration reads the record back into the dead vnew|znew registers behind its backward sweep, and a solve that
+// ends without converging writes vnew|znew over it (v = vnew, :445-446).  Frees the largest LDS array of the long wide shapes:
+// (20,8,50) 46 -> 23 KB per wave, four waves per CU instead of three.
+enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_VP = 8, TILE_LM_ALL = 15, TILE_LM_VPG = 16 };
 constexpr int tile_lds_arrays(int lm) { return ((lm & TILE_LM_QX) ? 1 : 0) + ((lm & TILE_LM_DN) ? 1 : 0) + ((lm & TILE_LM_VP) ? 1 : 0); }
-constexpr int tile_reg_arrays(int lm) { return 5 - tile_lds_arrays(lm); }
+constexpr int tile_reg_arrays(int lm) { return 5 - tile_lds_arrays(lm) - ((lm & TILE_LM_VPG) ? 1 : 0); }
 // (w = 0: HALF rows -- an instance with nx+nu <= 8 takes 8 lanes, two instances share a DPP row; see admm_tile_kernel)
 constexpr int tile_lds_slot(int nx, int nu, int w) { return (w == 0 ? 8 : 4 / w) * (nx + nu) + 1; }
 // bytes of wave-private LDS: bound tables (unless UB), the trajectory (unless REGEN), the offloaded arrays
@@ -142,7 +149,8 @@ void admm_tile_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
     constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
     constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
-    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0;
+    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0, VG = (LM & TILE_LM_VPG) != 0;
+    static_assert(!(VL_ && VG), "v|z: LDS or its record, not both");
     constexpr bool KEEPX = !(LM & TILE_LM_REGEN) || SOC || LIN != 0;    // the cone / half-space slacks of the next solve start from x|u
     constexpr int SLOT = tile_lds_slot(NX, NU, W);
     // DEFER (horizon split over R > 1 rows, trajectory kept in LDS): a sweep phase runs on ONE of the R horizon rows while the others
@@ -216,11 +224,12 @@ void admm_tile_kernel(const SolveArgs P) {
     const int g0 = hrow * L;                                           // first global slot of this row
     const int ntiles = (P.batch + IPW - 1) / IPW;
     // ---- the state of this lane's instance (one instance per SLOT of RPI rows; IPW slots per wave)
-    double G[L], VN[L], VP[VL_ ? 1 : L], QX[QL ? 1 : L], Dn[DL ? 1 : L];
+    double G[L], VN[L], VP[(VL_ || VG) ? 1 : L], QX[QL ? 1 : L], Dn[DL ? 1 : L];
     double VC[SOC ? L : 1], GC[SOC ? L : 1];
     double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
     double ref_last = 0.0, x0v = 0.0, x1v = 0.0, x0_last = 0.0, rp = 0.0, rd = 0.0;   // x1v: slot 1 (x_1 | u_0) of the last sweep; x0_last: the x0 the last solve started from
     int b = 0, iter = 0, solved = 0, checked = 0, countdown = 0, step = 0;
+    double *vpp = nullptr, *vpp0 = nullptr;                              // VPG: see the load
     unsigned acc_iter = 0, acc_solved = 0;
     bool have = false;                                                  // this slot holds an instance that is not finished yet
     int next_tile = blockIdx.x;                                         // static assignment: tiles of IPW instances, grid stride
@@ -263,7 +272,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 const double r = valid ? P.ref[off] : 0.0;
                 VN[l] = valid ? P.slack[off] : 0.0;
                 G[l] = valid ? P.dual[off] : 0.0;
-                if constexpr (VL_) sV[l * SLOT + li] = valid ? P.slack_prev[off] : 0.0; else VP[l] = valid ? P.slack_prev[off] : 0.0;
+                if constexpr (VL_) sV[l * SLOT + li] = valid ? P.slack_prev[off] : 0.0; else if constexpr (!VG) VP[l] = valid ? P.slack_prev[off] : 0.0;
                 if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else QX[l] = -(r * qr);
                 if constexpr (DL) sD[l * SLOT + li] = 0.0; else Dn[l] = 0.0;
                 if constexpr (SOC) {
@@ -275,6 +284,13 @@ void admm_tile_kernel(const SolveArgs P) {
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
             x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
+            if constexpr (VG) {
+                // this lane's column of the instance's v|z record (slot l at + l NZ); lanes that hold no row, and the input lanes' dummy
+                // slot 0, go to the pad behind the records (tiny_batch_setup: zeros, and zeros are all that is ever written there)
+                double* const pad = P.slack_prev + (size_t)P.batch * N * NZ + (lane & 15);
+                vpp = jj < NZ ? P.slack_prev + ((size_t)b * N + g0 - (is_input ? 1 : 0)) * NZ + jj : pad;
+                vpp0 = (hrow == 0 && is_input) ? pad : vpp;
+            }
             {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
                 double pt[NX];
 #pragma unroll
@@ -363,6 +379,13 @@ void admm_tile_kernel(const SolveArgs P) {
                         }
                     }
                 }
+                if constexpr (VG) {
+                    if (iter == 0) {                                   // a solve's first iteration: v|z of the solve before, from its record, into
+                        __builtin_amdgcn_s_waitcnt(0);                 // the vnew|znew registers (dead behind the backward sweep)
+#pragma unroll
+                        for (int l = 0; l < L; ++l) VN[l] = (l == 0 ? vpp0 : vpp)[l * NZ];     // (lanes without a row read the zero pad)
+                    }
+                }
                 // ---- forward_pass (admm.cpp:25-32) + slot updates, first row first
                 double pmax = 0.0, dmax = 0.0, xcarry = 0.0;
 #pragma unroll
@@ -440,7 +463,11 @@ void admm_tile_kernel(const SolveArgs P) {
                             }
                             lo_c = lo_n; hi_c = hi_n;
                             pmax = vmax_abs64(pmax, xi - vn);
-                            if constexpr (VL_) dmax = vmax_abs64(dmax, vcur - vn); else dmax = vmax_abs64(dmax, VP[l] - vn);
+                            if constexpr (VL_) dmax = vmax_abs64(dmax, vcur - vn);
+                            else if constexpr (VG) {
+                                dmax = vmax_abs64(dmax, VN[l] - vn);
+                                (l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];
+                            } else dmax = vmax_abs64(dmax, VP[l] - vn);
                             G[l] = tt - vn;
                             VN[l] = vn;
                             if constexpr (SOC) {
@@ -497,7 +524,11 @@ void admm_tile_kernel(const SolveArgs P) {
                         const double tt = xi + G[l];
                         const double vn = vmin64(hi_c, vmax64(lo_c, tt));
                         pmax = vmax_abs64(pmax, xi - vn);
-                        if constexpr (VL_) dmax = vmax_abs64(dmax, sV[l * SLOT + li] - vn); else dmax = vmax_abs64(dmax, VP[l] - vn);
+                        if constexpr (VL_) dmax = vmax_abs64(dmax, sV[l * SLOT + li] - vn);
+                        else if constexpr (VG) {
+                            dmax = vmax_abs64(dmax, VN[l] - vn);
+                            (l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];
+                        } else dmax = vmax_abs64(dmax, VP[l] - vn);
                         G[l] = tt - vn;
                         VN[l] = vn;
                     }
@@ -514,11 +545,17 @@ void admm_tile_kernel(const SolveArgs P) {
                 }
                 if (!conv) {
 #pragma unroll
-                    for (int l = 0; l < L; ++l) { if constexpr (VL_) sV[l * SLOT + li] = VN[l]; else VP[l] = VN[l]; }      // :445-446 (L LDS stores, no VALU work)
+                    for (int l = 0; l < L; ++l) { if constexpr (VL_) sV[l * SLOT + li] = VN[l]; else if constexpr (!VG) VP[l] = VN[l]; }      // :445-446 (L LDS stores, no VALU work)
                 }
             }
             if (conv || iter >= P.max_iter) {                            // this solve is over (admm.cpp:431-441 | :448-454)
                 solved = conv ? 1 : 0;
+                if constexpr (VG) {
+                    if (!conv && iter > 0) {                           // out of iterations: v = vnew was the last thing that happened (:445-446)
+#pragma unroll
+                        for (int l = 0; l < L; ++l) (l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];
+                    }
+                }
                 acc_iter += (unsigned)iter;
                 acc_solved += (unsigned)solved;
                 if (nsteps > 1) {
@@ -603,7 +640,7 @@ void admm_tile_kernel(const SolveArgs P) {
                         }
                         P.slack[off] = VN[l];
                         P.dual[off] = G[l];
-                        if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else P.slack_prev[off] = VP[l];
+                        if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else if constexpr (!VG) P.slack_prev[off] = VP[l];
                         if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
                         if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
                         if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
