@@ -181,6 +181,36 @@ def test_tile_forms_that_keep_v_in_its_record_match_the_oracle(dims, lm, other, 
     assert_match(run_cases_hip(warm, options=opts), wref, RTOL, f"v in its record, warm {dims}")
 
 
+@pytest.mark.parametrize("dims", [(4, 2, 50), (20, 2, 50)])
+def test_fused_steps_on_a_tile_form_that_keeps_v_in_its_record(dims):
+    """Closed loop on the long tile forms (v|z in its HBM record): T MPC steps fused into one launch leave exactly what T launches
+    leave -- every solve's first iteration must see the v|z its predecessor left (converged: the slack of ITS last but one
+    iteration; out of iterations: vnew), whether the predecessor ran in the same launch or the one before."""
+    T = 4
+    suite = sc.sweep_suite(*dims, B=9, max_iter=25)
+
+    def run(fused):
+        s = make_batch(suite)
+        assert s.kernel_path() == "tile"
+        s.set_option("advance_x0", 1)
+        s.set_x0(suite["cases"]["x0"]); s.set("Xref", suite["cases"]["Xref"]); s.set("Uref", suite["cases"]["Uref"])
+        if fused:
+            s.set_option("steps_per_launch", T)
+            s.solve_async()
+        else:
+            for _ in range(T):
+                s.solve_async()
+        out = {k: s.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "x0")}
+        out["iter"] = np.asarray(s.status()["iter"])
+        out["acc"] = np.asarray(s.reduce_stats()[7:9])
+        s.close()
+        return out
+    a, b = run(False), run(True)
+    assert a["acc"][0] > 0 and 0 < a["acc"][1] < 9 * T             # some solves converge, some run out of their 25 iterations
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("dims", [(4, 2, 30), (8, 2, 10)])
 def test_one_row_shape_forms_are_interchangeable_with_an_affine_term(dims):
     """The launch forms a one-row shape can take (one-row kernel; tile kernel in its one-row layout; half rows) are swapped by the
