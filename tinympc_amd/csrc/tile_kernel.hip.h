@@ -110,7 +110,7 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
 // bit 4 (VPG, instead of bit 3): v|z is not held at all.  Inside the iteration loop it is only ever the vnew|znew of the iteration
 // before -- which the slot update still has in its register when it needs it for the dual residual -- EXCEPT in a solve's first
 // iteration (work->v of the solve before: admm.cpp:431-441 returns before v = vnew).  So: the slot update streams the old
-// vnew|znew to the instance's v|z RECORD (one global store per slot, absorbed by L2: the resident instances' records fit it), a
+// vnew|znew to the instance's v|z RECORD (one global store per slot; ~1 TB/s of HBM writes at (20,8,50), far from a bound), a
 // solve's first iteration reads the record back into the dead vnew|znew registers behind its backward sweep, and a solve that
 // ends without converging writes vnew|znew over it (v = vnew, :445-446).  Frees the largest LDS array of the long wide shapes:
 // (20,8,50) 46 -> 23 KB per wave, four waves per CU instead of three.
