@@ -89,10 +89,10 @@ def run_cell(nx, nu, N, B, reps):
     x0 = rng.uniform(-1, 1, (B, nx))
     xr = np.repeat(rng.uniform(-0.2, 0.2, (B, nx, 1)), N, axis=2)
     best = None
+    s.set_x0(x0)                                      # inputs resident before the timed solves (reset() keeps x0 and the references):
+    s.set_x_ref(xr)                                   # a 200 MB upload in front of every solve lets the GPU clock down first
     for _ in range(reps + 1):
         s.reset()
-        s.set_x0(x0)
-        s.set_x_ref(xr)
         s.set_option("timing", 1)
         s.solve_async()
         ms = float(s.timing_ms()[0])
