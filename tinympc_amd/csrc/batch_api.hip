@@ -913,9 +913,9 @@ static int enqueue_iteration_histogram(TinyBatch* b) {
 
 // index lists + per-stage counters of the split solve: [stage] list lengths, [32 + stage] tile counters
 static int ensure_repack_buffers(TinyBatch* b) {
-    if (b->d_repack_index) return TINY_OK;
-    HIP_TRY(b, hipMalloc(&b->d_repack_index, 2 * (size_t)b->batch * sizeof(int)));
-    HIP_TRY(b, hipMalloc(&b->d_repack_count, 2 * 32 * sizeof(int)));
+    if (b->d_repack_index && b->d_repack_count) return TINY_OK;
+    if (!b->d_repack_index) HIP_TRY(b, hipMalloc(&b->d_repack_index, 2 * (size_t)b->batch * sizeof(int)));
+    if (!b->d_repack_count) HIP_TRY(b, hipMalloc(&b->d_repack_count, 2 * 32 * sizeof(int)));
     return TINY_OK;
 }
 
