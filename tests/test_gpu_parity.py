@@ -156,7 +156,7 @@ def test_half_row_form_matches_oracle(dims, dyn):
     assert_match(run_cases_hip(warm, options=opts), sc.run_cases(OracleSolver, warm), RTOL, f"half rows warm {dims}")
 
 
-@pytest.mark.parametrize("dims,lm,other", [((12, 2, 50), 22, 0), ((4, 2, 50), 23, 15), ((12, 4, 50), 23, 0), ((20, 4, 30), 20, 12), ((20, 8, 50), 23, 14)])
+@pytest.mark.parametrize("dims,lm,other", [((12, 2, 50), 22, 0), ((4, 2, 50), 23, 15), ((12, 4, 50), 23, 0), ((20, 4, 30), 20, 12), ((20, 8, 50), 23, 14), ((20, 8, 50), 54, 14), ((4, 4, 50), 54, 15), ((8, 2, 50), 54, 0)])
 @pytest.mark.parametrize("dyn", [0, 1])
 def test_tile_forms_that_keep_v_in_its_record_match_the_oracle(dims, lm, other, dyn):
     """Round 3, LM bit 4: v|z (work->v, the slack of the iteration before) is held neither in registers nor in LDS -- the slot update

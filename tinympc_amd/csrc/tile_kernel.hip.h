@@ -114,9 +114,13 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
 // solve's first iteration reads the record back into the dead vnew|znew registers behind its backward sweep, and a solve that
 // ends without converging writes vnew|znew over it (v = vnew, :445-446).  Frees the largest LDS array of the long wide shapes:
 // (20,8,50) 46 -> 23 KB per wave, four waves per CU instead of three.
-enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_VP = 8, TILE_LM_ALL = 15, TILE_LM_VPG = 16 };
+// bit 5 (QXR, instead of bit 0): QX is not held either -- it is -(ref * Q|R diagonal) of a record that does not change during a solve, so
+// the backward sweep reads the reference record again, TILE_QXR_DEPTH steps ahead of its use (global loads need that distance with
+// one wave per SIMD), and forms the product on the way; only the terminal term of the last knot keeps a register.
+enum : int { TILE_LM_QX = 1, TILE_LM_DN = 2, TILE_LM_REGEN = 4, TILE_LM_VP = 8, TILE_LM_ALL = 15, TILE_LM_VPG = 16, TILE_LM_QXR = 32 };
+constexpr int TILE_QXR_DEPTH = 12;
 constexpr int tile_lds_arrays(int lm) { return ((lm & TILE_LM_QX) ? 1 : 0) + ((lm & TILE_LM_DN) ? 1 : 0) + ((lm & TILE_LM_VP) ? 1 : 0); }
-constexpr int tile_reg_arrays(int lm) { return 5 - tile_lds_arrays(lm) - ((lm & TILE_LM_VPG) ? 1 : 0); }
+constexpr int tile_reg_arrays(int lm) { return 5 - tile_lds_arrays(lm) - ((lm & TILE_LM_VPG) ? 1 : 0) - ((lm & TILE_LM_QXR) ? 1 : 0); }
 // (w = 0: HALF rows -- an instance with nx+nu <= 8 takes 8 lanes, two instances share a DPP row; see admm_tile_kernel)
 constexpr int tile_lds_slot(int nx, int nu, int w) { return (w == 0 ? 8 : 4 / w) * (nx + nu) + 1; }
 // bytes of wave-private LDS: bound tables (unless UB), the trajectory (unless REGEN), the offloaded arrays
@@ -149,8 +153,9 @@ void admm_tile_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
     constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
     constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
-    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0, VG = (LM & TILE_LM_VPG) != 0;
-    static_assert(!(VL_ && VG), "v|z: LDS or its record, not both");
+    constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0, VG = (LM & TILE_LM_VPG) != 0,
+                   QR = (LM & TILE_LM_QXR) != 0;
+    static_assert(!(VL_ && VG) && !(QL && QR) && (!QR || VG), "v|z: LDS or its record, not both; QX likewise (QXR rides on the VPG pointers)");
     constexpr bool KEEPX = !(LM & TILE_LM_REGEN) || SOC || LIN != 0;    // the cone / half-space slacks of the next solve start from x|u
     constexpr int SLOT = tile_lds_slot(NX, NU, W);
     // DEFER (horizon split over R > 1 rows, trajectory kept in LDS): a sweep phase runs on ONE of the R horizon rows while the others
@@ -224,12 +229,14 @@ void admm_tile_kernel(const SolveArgs P) {
     const int g0 = hrow * L;                                           // first global slot of this row
     const int ntiles = (P.batch + IPW - 1) / IPW;
     // ---- the state of this lane's instance (one instance per SLOT of RPI rows; IPW slots per wave)
-    double G[L], VN[L], VP[(VL_ || VG) ? 1 : L], QX[QL ? 1 : L], Dn[DL ? 1 : L];
+    double G[L], VN[L], VP[(VL_ || VG) ? 1 : L], QX[(QL || QR) ? 1 : L], Dn[DL ? 1 : L];
     double VC[SOC ? L : 1], GC[SOC ? L : 1];
     double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
     double ref_last = 0.0, x0v = 0.0, x1v = 0.0, x0_last = 0.0, rp = 0.0, rd = 0.0;   // x1v: slot 1 (x_1 | u_0) of the last sweep; x0_last: the x0 the last solve started from
     int b = 0, iter = 0, solved = 0, checked = 0, countdown = 0, step = 0;
     double *vpp = nullptr, *vpp0 = nullptr;                              // VPG: see the load
+    const double *rpp = nullptr, *rpp0 = nullptr;                        // QXR: the same column of the reference record
+    double qx_term = 0.0;                                               // QXR: -(Xref[:,N-1]' Pinf) of this lane (admm.cpp:292)
     unsigned acc_iter = 0, acc_solved = 0;
     bool have = false;                                                  // this slot holds an instance that is not finished yet
     int next_tile = blockIdx.x;                                         // static assignment: tiles of IPW instances, grid stride
@@ -273,7 +280,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 VN[l] = valid ? P.slack[off] : 0.0;
                 G[l] = valid ? P.dual[off] : 0.0;
                 if constexpr (VL_) sV[l * SLOT + li] = valid ? P.slack_prev[off] : 0.0; else if constexpr (!VG) VP[l] = valid ? P.slack_prev[off] : 0.0;
-                if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else QX[l] = -(r * qr);
+                if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else if constexpr (!QR) QX[l] = -(r * qr);
                 if constexpr (DL) sD[l * SLOT + li] = 0.0; else Dn[l] = 0.0;
                 if constexpr (SOC) {
                     VC[l] = (valid && soc_lane) ? P.prim[off] : 0.0;                    // vcnew = x, zcnew = u (admm.cpp:352-357)
@@ -290,13 +297,15 @@ void admm_tile_kernel(const SolveArgs P) {
                 double* const pad = P.slack_prev + (size_t)P.batch * N * NZ + (lane & 15);
                 vpp = jj < NZ ? P.slack_prev + ((size_t)b * N + g0 - (is_input ? 1 : 0)) * NZ + jj : pad;
                 vpp0 = (hrow == 0 && is_input) ? pad : vpp;
+                if constexpr (QR) { rpp = P.ref + (vpp - P.slack_prev); rpp0 = P.ref + (vpp0 - P.slack_prev); }
             }
             {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
                 double pt[NX];
 #pragma unroll
                 for (int k = 0; k < NX; ++k) pt[k] = P.tab[T::PT + k * LW + jj];
                 const double xp = tile_matvec<W, 0, NX>(0.0, ref_last, pt);
-                if (hrow == R - 1 && is_state) { if constexpr (QL) sQ[(L - 1) * SLOT + li] = -xp; else QX[L - 1] = -xp; }
+                if constexpr (QR) qx_term = -xp;
+                else if (hrow == R - 1 && is_state) { if constexpr (QL) sQ[(L - 1) * SLOT + li] = -xp; else QX[L - 1] = -xp; }
             }
             if constexpr (QL || DL || VL_) {                           // (each lane only ever reads its own entries back: no barrier needed,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the fence keeps the compiler from moving LDS reads above these writes)
@@ -348,12 +357,26 @@ void admm_tile_kernel(const SolveArgs P) {
                         // to the top of the sweep, which is what turns 3 register arrays into 1 KB of scratch per lane
                         double qa = 0.0, qb = 0.0;
                         if constexpr (QL) { qa = sQ[(L - 1) * SLOT + li]; qb = sQ[(L - 2) * SLOT + li]; }
+                        // QXR: the reference record again, QD steps ahead (a ring of QD values in flight; the sweep is unrolled, so the
+                        // ring index is a constant at every step)
+                        constexpr int QD = L < TILE_QXR_DEPTH ? L : TILE_QXR_DEPTH;
+                        double rq[QR ? QD : 1];
+                        if constexpr (QR) {
+#pragma unroll
+                            for (int d = 0; d < QD; ++d) rq[d] = (L - 1 - d == 0 ? rpp0 : rpp)[(L - 1 - d) * NZ];
+                        }
 #pragma unroll
                         for (int l = L - 1; l >= 0; --l) {
                             double qxl;
                             if constexpr (QL) {
                                 qxl = qa; qa = qb;
                                 if (l >= 2) qb = sQ[(l - 2) * SLOT + li];
+                            } else if constexpr (QR) {
+                                const double r = rq[(L - 1 - l) % QD];
+                                if (l - QD >= 0) rq[(L - 1 - l) % QD] = (l - QD == 0 ? rpp0 : rpp)[(l - QD) * NZ];
+                                __builtin_amdgcn_sched_barrier(0);                      // (the load stays HERE: QD steps ahead of its use, no further)
+                                qxl = -(r * qr);                                        // admm.cpp:266 / :279
+                                if (l == L - 1) qxl = (hrow == R - 1 && is_state) ? qx_term : qxl;
                             } else qxl = QX[l];
                             double qlo = fma(-rho, VN[l] - G[l], qxl);                  // admm.cpp:267 | :280 | :293
                             if constexpr (SOC) qlo = fma(-rho, VC[l] - GC[l], qlo);     // :269 | :282 | :295

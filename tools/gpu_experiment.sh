@@ -1,3 +1,3 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 900 python tools/tile_forms.py --reps 1 --cells "4,2,30;4,4,30;4,8,30;8,2,30;8,4,30" > $O/tile_forms_vpg6.md 2> $O/tile_forms_vpg6.err; grep "dynamic\|regs" $O/tile_forms_vpg6.md; tail -3 $O/tile_forms_vpg6.err
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_repack.py tests/test_gpu_sharding.py -m gpu -q > $O/pytest.txt 2>&1; grep -n "passed\|failed\|Error" $O/pytest.txt | tail -5
