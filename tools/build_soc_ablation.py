@@ -33,7 +33,12 @@ P1 = [("if (p > 0 && p >= soc_passes) break;            // wave-uniform", "break
 P2 = P1 + [("const double pv = sT[(grp * N + s) * 16 + j];", "const double pv = tc;")]
 P3 = P2 + [("if constexpr (SOC) sT[(grp * N + i) * 16 + j] = fma(xi, socmask, GC[i]);", ""),
            ("sT[(grp * N + s) * 16 + j] = tc;", "")]
-VARIANTS = {"abl1": P1, "abl2": P2, "abl3": P3}
+# abl_vp: v|z not held (timing only: what the registers of the cone kernel's VP array are worth)
+PVP = [("VP[s] = warm ? P.slack_prev[off] : 0.0;", ""), ("dmax = resid_max<(N > 12)>(dmax, VP[s] - vn);", "dmax = resid_max<(N > 12)>(dmax, VN[s] - vn);"),
+       ("dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);", "dmax = resid_max<(N > 12)>(dmax, VN[i] - vn);"),
+       ("for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446", "for (int s = 0; s < 1; ++s) {}"),
+       ("P.slack_prev[off] = VP[s];", "P.slack_prev[off] = VN[s];"), ("double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];", "double X[N], G[N], VN[N], QX[N], Dn[N - 1];")]
+VARIANTS = {"abl1": P1, "abl2": P2, "abl3": P3, "abl_vp": PVP}
 if __name__ == "__main__":
     for t in (sys.argv[1:] or VARIANTS):
         build(t, VARIANTS[t])

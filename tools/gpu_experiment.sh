@@ -1,5 +1,7 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 300 python tools/fuzz_parity.py 400 8101 > $O/fuzz_parity_c.txt 2>&1; tail -2 $O/fuzz_parity_c.txt
-timeout 200 python tools/fuzz_closed_loop.py 60 8102 > $O/fuzz_cl_c.txt 2>&1; tail -1 $O/fuzz_cl_c.txt
-timeout 200 python tools/fuzz_compat.py 40 8103 > $O/fuzz_compat_c.txt 2>&1; tail -1 $O/fuzz_compat_c.txt
+for v in "" _abl_vp; do
+  echo "--- lib$v" >> $O/soc_vp.txt
+  TINYMPC_AMD_LIB=$PWD/tinympc_amd/libtinympc_amd$v.so timeout 200 python tools/soc_iter_cost.py >> $O/soc_vp.txt 2>&1
+done
+cat $O/soc_vp.txt
