@@ -1,7 +1,4 @@
 #!/bin/bash
+# stage "exp" of tools/gpu_stage.sh: whatever kernel experiment is being measured at the moment (this default: the cone step's cost)
 O=$1; mkdir -p $O; export O
-for v in "" _abl_vp; do
-  echo "--- lib$v" >> $O/soc_vp.txt
-  TINYMPC_AMD_LIB=$PWD/tinympc_amd/libtinympc_amd$v.so timeout 200 python tools/soc_iter_cost.py >> $O/soc_vp.txt 2>&1
-done
-cat $O/soc_vp.txt
+timeout 300 python tools/soc_iter_cost.py > $O/soc_iter_cost.txt 2>&1; cat $O/soc_iter_cost.txt
