@@ -111,7 +111,8 @@ def test_hip_matches_oracle_seeded(maker):
 
 
 @pytest.mark.parametrize("dims,B,max_iter", [((12, 8, 10), 7, 150), ((20, 2, 10), 5, 150), ((20, 4, 10), 6, 150), ((20, 8, 10), 9, 200),
-                                              ((4, 2, 50), 9, 200), ((12, 4, 50), 6, 120), ((8, 8, 50), 5, 120),
+                                              ((4, 2, 50), 9, 200), ((12, 4, 50), 6, 120), ((8, 8, 50), 5, 120), ((4, 4, 50), 9, 120), ((4, 8, 50), 5, 120), ((8, 2, 50), 6, 120),
+                                              ((8, 4, 50), 5, 120), ((12, 2, 50), 5, 120), ((12, 8, 50), 3, 100), ((20, 2, 50), 3, 100), ((20, 2, 30), 3, 100), ((20, 4, 30), 3, 100),
                                               ((12, 8, 30), 3, 120), ((20, 8, 30), 3, 120), ((20, 4, 50), 3, 80), ((20, 8, 50), 2, 80)])
 def test_tile_kernel_matches_oracle(dims, B, max_iter):
     """Wide (nx+nu > 16: W = 2 rows across the knot vector) and long (R = 2 rows along the horizon) shapes on the
