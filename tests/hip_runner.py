@@ -80,5 +80,6 @@ def run_cases_hip(suite, replicate=1, debug=False, options=None):
                dual_residual_state=st["dual_residual_state"], dual_residual_input=st["dual_residual_input"])
     out["sol_x"], out["sol_u"] = out["vnew"], out["znew"]          # solution = slack (admm.cpp:436-437)
     out["batch_ret"] = ret
+    out["tile_form"] = s.get_option("last_tile_form") if s.kernel_path() == "tile" else -1     # (W, R, LM) of the tile_dims.txt entry that ran
     s.close()
     return out

@@ -157,7 +157,7 @@ def test_half_row_form_matches_oracle(dims, dyn):
     assert_match(run_cases_hip(warm, options=opts), sc.run_cases(OracleSolver, warm), RTOL, f"half rows warm {dims}")
 
 
-@pytest.mark.parametrize("dims,lm,other", [((12, 2, 50), 22, 0), ((4, 2, 50), 23, 15), ((12, 4, 50), 23, 0), ((20, 4, 30), 20, 12), ((20, 8, 50), 23, 14), ((20, 8, 50), 54, 14), ((4, 4, 50), 54, 15), ((8, 2, 50), 54, 0)])
+@pytest.mark.parametrize("dims,lm,other", [((12, 2, 50), 22, 0), ((4, 2, 50), 23, 99), ((12, 4, 50), 23, 0), ((20, 4, 30), 20, 12), ((20, 8, 50), 23, 14), ((20, 8, 50), 54, 14), ((4, 4, 50), 54, 99), ((8, 2, 50), 54, 0)])
 @pytest.mark.parametrize("dyn", [0, 1])
 def test_tile_forms_that_keep_v_in_its_record_match_the_oracle(dims, lm, other, dyn):
     """Round 3, LM bit 4: v|z (work->v, the slack of the iteration before) is held neither in registers nor in LDS -- the slot update
@@ -168,9 +168,11 @@ def test_tile_forms_that_keep_v_in_its_record_match_the_oracle(dims, lm, other, 
     opts = {"tile_lm": lm, "tile_dyn": dyn}
     ref = sc.run_cases(OracleSolver, suite)
     out = run_cases_hip(suite, options=opts)
+    assert out["tile_form"] % 1000 == lm, out["tile_form"]     # the entry asked for is the one that ran
     assert_match(out, ref, RTOL, f"v in its record {dims}")
     assert 0 < ref["sol_solved"].sum() < len(ref["sol_solved"]) or ref["iter"].max() == 120 or len(np.unique(ref["iter"])) > 2
     alt = run_cases_hip(suite, options={"tile_lm": other, "tile_dyn": dyn} if other else {"tile_lm": 0, "tile_r": 2, "tile_dyn": dyn})
+    assert alt["tile_form"] % 1000 == other and alt["tile_form"] != out["tile_form"]     # (a form that holds v|z in LDS or registers; 99 = the shape's automatic LDS set)
     for k in ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z"):
         assert np.array_equal(out[k], alt[k]), (k, dims)
     warm = dict(problem=suite["problem"], config=dict(suite["config"], max_iter=7), cases=dict(suite["cases"]))

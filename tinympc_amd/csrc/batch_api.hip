@@ -553,6 +553,7 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         HIP_TRY(b, hipGetLastError());
         b->last_tile_dyn = dyn;
     }
+    b->last_tile_form = te ? (te->W * 1000000 + te->R * 1000 + te->lm) : -1;      // which tile_dims.txt entry ran (-1: run-time instantiated)
     if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
     return TINY_OK;
 }
@@ -1913,6 +1914,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
+    if (!strcmp(name, "last_tile_form")) return b->last_tile_form;          // W * 1e6 + R * 1e3 + LM of the tile_dims.txt entry the last tile launch took (-1: run-time instantiated)
     if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form
     if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;
     if (!strcmp(name, "repack_after")) return b->repack_after;

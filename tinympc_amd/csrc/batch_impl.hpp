@@ -41,6 +41,7 @@ struct TinyBatch {
     int tile_lm = -1;                            // option "tile_lm"
     int tile_dyn_opt = -1;                       // option "tile_dyn"
     bool last_tile_dyn = false;
+    int last_tile_form = -1;                     // W * 1e6 + R * 1e3 + LM of the entry the last tile launch took
     int* d_work_counter = nullptr;               // the dynamic tile form's device-wide instance counter
     int tile_r = 0;                              // option "tile_r": pick the tile_dims.txt entry with this many rows along the horizon
     bool no_tile = false, prefer_tile = false;   // prefer_tile: take the tile kernel even where a one-row instantiation exists
