@@ -146,6 +146,11 @@ struct SolveArgs {
     // the host before the launch; a slot of a persistent wave takes the next instance off it the moment it is free.
     // one-row kernel: the counter of 4-instance tiles handed out BEYOND the grid's first ones (null: fixed grid stride)
     int* work_counter;
+    // one-row kernel, plain launches: 1 = the grid walks the tiles from the LAST one down.  Successive warm launches over one batch
+    // alternate the direction, so that a launch begins with the records its predecessor touched last -- the ones the 256 MiB
+    // Infinity Cache in front of HBM still holds (a batch whose records exceed it would otherwise stream through it without a hit).
+    // Instances are independent: the order changes nothing in the results.
+    int reverse;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -403,18 +408,18 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
             : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
               [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                                         \
     }
-// the same with the cone slack's linear-cost term (admm.cpp:269 | :282 | :295): qlo = fma(-rho, vc - gc, fma(-rho, vn - g, qx))
+// the same with the cone slack's linear-cost term (admm.cpp:269 | :282 | :295): qlo = fma(-rho, w, fma(-rho, vn - g, qx)), w = vcnew - gc
+// (formed once, by the cone step: the W plane of the cone slack cells)
 #define FUSED_BWD_SOC_CASE(NA_, NB_) FUSED_BWD_SOC_CASE_(NA_, NB_)
 #define FUSED_BWD_SOC_CASE_(NA_, NB_)                                                                                   \
     if constexpr (NA == NA_ && NB == NB_) {                                                                             \
         asm("v_add_f64 %[tmp], %[vn], -%[g]\n\t"                                                                        \
             "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
-            "v_add_f64 %[tmp], %[vc], -%[gc]\n\t"                                                                       \
-            "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qlo]\n\t"                                                             \
+            "v_fma_f64 %[qlo], -%[rho], %[w], %[qlo]\n\t"                                                               \
             "v_fma_f64 %[acc], %[qlo], %[smask], %[cb]\n\t" FCA##NA_ FCB##NB_                                           \
             : [qlo] "=&v"(qlo), [acc] "=&v"(acc), [tmp] "=&v"(tmp)                                                      \
             : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
-              [sb] "v"(sb), [vc] "v"(vc), [gc] "v"(gc), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                             \
+              [sb] "v"(sb), [w] "v"(w), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                             \
     }
 #define FUSED_FWD_CASE(NA_, NB_) FUSED_FWD_CASE_(NA_, NB_)
 #define FUSED_FWD_CASE_(NA_, NB_)                                                                                       \
@@ -444,7 +449,7 @@ __device__ __forceinline__ void fused_backward_step(double& qlo, double& acc, do
     (void)tmp;
 }
 template <int NA, int NB>
-__device__ __forceinline__ void fused_backward_step_soc(double& qlo, double& acc, double vn, double g, double qx, double vc, double gc, double rho,
+__device__ __forceinline__ void fused_backward_step_soc(double& qlo, double& acc, double vn, double g, double qx, double w, double rho,
                                                         double smask, double cb, double sa, double sb, const double* ma, const double* mb_) {
     double tmp;
     FUSED_SHAPES(FUSED_BWD_SOC_CASE)
@@ -524,7 +529,9 @@ __device__ __forceinline__ double soc_component(double s0, double s1, double s2,
 
 // The same projection for a whole 3-cone held by ONE lane (s0, s1, s2) -> (r0, r1, r2): the transposed form of the cone step
 // (one lane per (cone, knot) pair) pays the square root and the two divisions once per iteration instead of once per knot.
-__device__ __forceinline__ void soc_project3(double s0, double s1, double s2, float mu, double& r0, double& r1, double& r2) {
+// rmu_exact: every mu of the wave is a power of two and rmu = 1 / mu exactly (wave-uniform) -- then a * rmu IS a / mu, rounded once
+// like the division (2^k scalings are exact, overflow and gradual underflow included), without the ten instructions of one.
+__device__ __forceinline__ void soc_project3(double s0, double s1, double s2, float mu, float rmu, bool rmu_exact, double& r0, double& r1, double& r2) {
 #pragma clang fp contract(off)
     const double u0 = s2 * (double)mu;                                  // :40
     const double q0 = s0 * s0, q1 = s1 * s1;
@@ -541,7 +548,7 @@ __device__ __forceinline__ void soc_project3(double s0, double s1, double s2, fl
     r0 = zero ? 0.0 : s0; r1 = zero ? 0.0 : s1; r2 = zero ? 0.0 : s2;
     if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {
         const double scale = 0.5 * (1.0 + u0 / ad);                     // :55
-        const double last = (double)(a / mu);                           // :54
+        const double last = (double)(rmu_exact ? a * rmu : a / mu);      // :54
         r0 = outside ? scale * s0 : r0;
         r1 = outside ? scale * s1 : r1;
         r2 = outside ? scale * last : r2;
@@ -608,9 +615,22 @@ void admm_solve_kernel(const SolveArgs P) {
     __shared__ double sHi[N * 16];
     __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
     __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
-    // SOC: x + gc of every slot, transposed through LDS for the cone step; + a dummy item (0, 0, 1) that the lanes without a
-    // (cone, knot) pair of their own project (onto itself) -- no EXEC-mask region around the gather / scatter of a pass
-    __shared__ double sT[SOC ? 4 * N * 16 + 4 : 1];
+    // SOC: the cone slack lives in LDS, not in registers.  Per row and slot three planes of CS cells (lane j: cell j; the lanes beyond
+    // NZ share cell NZ):
+    //   W   what the next backward sweep adds to the linear cost: vcnew - gc (admm.cpp:269 | :282 | :295).  Between the forward
+    //       sweep and the cone step it holds x + gc, the vector the cone step projects (:102-109)
+    //   GC  gc | yc (:229 / :234)
+    //   VC  vcnew | zcnew of the cells that belong to a (cone, knot) item (the other cells: W holds it, see below)
+    // The cone step is transposed -- lane j of pass p owns ONE (cone, knot) item: it gathers the item's three components from W,
+    // projects them (one square root / division sequence per pass instead of one per knot) and writes all three planes; the sweeps
+    // read W (backward) and GC (forward) one step ahead of their use.  Cells outside every item: the projection is the identity,
+    // vcnew = x + gc bit for bit, so gc = 0 and W = x + gc -- what the forward sweep leaves there.  A slot is 3 CS doubles, an ODD
+    // number: the item gathers of a pass (stride = one slot) fall into distinct LDS banks.  + a dummy slot whose item (0, 0, 1)
+    // the lanes without an item project (onto itself): no EXEC-mask region around the gather / scatter of a pass.
+    constexpr int CS = SOC ? ((NZ + 1) | 1) : 1;
+    constexpr int SLOT_D = 3 * CS;
+    constexpr int PL_GC = CS, PL_VC = 2 * CS;
+    __shared__ double sC[SOC ? (4 * N + 1) * SLOT_D : 1];
     __shared__ double sP[ADAPT ? 4 * NX * NX : 1];            // ADAPT: each row's own Pinf, column-major (lane j keeps column j current)
     // ADAPT: the lane tables every adaptation reads (ATAB_AT, ATAB_DK, ATAB_DP), lane-major [table][lane][AKC] so that a lane's
     // coefficients are consecutive (ds_read_b128), and each row's log of rho steps that C1 / C2 still have to take (flush_c)
@@ -656,26 +676,35 @@ void admm_solve_kernel(const SolveArgs P) {
     // item 16 p + j, counted cone by cone (ascending base lane): a state cone has N items (slots 0..N-1), an input cone N-1
     // (slots 1..N-1).  All four rows of a wave share the layout.
     constexpr int SOC_PASSES = SOC ? (soc_item_passes(NX, NU, N) > 0 ? soc_item_passes(NX, NU, N) : 1) : 1;
-    int item_at[SOC_PASSES];                                   // LDS index of the item's first component (the dummy item: none)
-    float item_mu[SOC_PASSES];
+    int item_at[SOC_PASSES];                                   // LDS index (W plane) of the item's first component; the dummy item for lanes without one
+    float item_mu[SOC_PASSES], item_rmu[SOC_PASSES];
+    bool mu_pow2 = true;                                       // every cone coefficient of the launch is 2^k, |k| <= 60 (wave-uniform): soc_project3 multiplies
     int soc_passes = 0;                                        // passes that hold an item (wave-uniform: a family whose cone is off has none)
     if constexpr (SOC) {
-        if (lane < 3) sT[4 * N * 16 + lane] = lane == 2 ? 1.0 : 0.0;
+        if (lane < 3) {                                        // the dummy item: W = VC = (0, 0, 1), GC = 0
+            sC[4 * N * SLOT_D + lane] = lane == 2 ? 1.0 : 0.0;
+            sC[4 * N * SLOT_D + PL_GC + lane] = 0.0;
+            sC[4 * N * SLOT_D + PL_VC + lane] = lane == 2 ? 1.0 : 0.0;
+        }
         const unsigned heads = (unsigned)(__builtin_amdgcn_ballot_w64(proj_lane && cone_c == 0) & 0xFFFFull);   // row 0 speaks for all
 #pragma unroll
         for (int p = 0; p < SOC_PASSES; ++p) {
             int t = p * 16 + j;
-            item_at[p] = 4 * N * 16; item_mu[p] = 1.0f;
+            item_at[p] = 4 * N * SLOT_D; item_mu[p] = 1.0f;
             if (heads && p * 16 < soc_items_of(heads, NX, N)) soc_passes = p + 1;
             for (unsigned m = heads; m; m &= m - 1) {
                 const int hb = __builtin_ctz(m);
                 const int cnt = hb < NX ? N : N - 1;
                 if (t >= 0 && t < cnt) {
-                    item_at[p] = grp * N * 16 + (t + (hb < NX ? 0 : 1)) * 16 + hb;
+                    item_at[p] = (grp * N + t + (hb < NX ? 0 : 1)) * SLOT_D + hb;
                     item_mu[p] = (float)P.tab[TAB_VEC + VEC_CONE_MU * 16 + hb];
                     t = -1;
                 } else if (t >= 0) t -= cnt;
             }
+            item_rmu[p] = 1.0f / item_mu[p];
+            const unsigned mb_ = __float_as_uint(item_mu[p]);
+            const bool p2 = (mb_ & 0x807FFFFFu) == 0u && (mb_ >> 23) >= 127u - 60u && (mb_ >> 23) <= 127u + 60u;
+            if (__builtin_amdgcn_ballot_w64(!p2) != 0ull) mu_pow2 = false;
         }
     }
     bool lin_lane = false, tlin_lane = false;
@@ -698,7 +727,7 @@ void admm_solve_kernel(const SolveArgs P) {
     // stage wait for the slot that drew the deepest ones)
     for (int tile = blockIdx.x; tile < ntiles;
          tile = P.work_counter ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(P.work_counter, 1) : 0) + (int)gridDim.x : tile + (int)gridDim.x) {
-        const int slot = tile * 4 + grp;
+        const int slot = (P.reverse ? ntiles - 1 - tile : tile) * 4 + grp;
         if (slot < ninst) {
             const int b = resumed ? P.index[slot] : slot;
             const double* het = nullptr;
@@ -733,7 +762,9 @@ void admm_solve_kernel(const SolveArgs P) {
             // record base of this lane: input lanes read knot s-1 at slot s
             const size_t lbase = (size_t)b * (N * NZ) + j - (is_input ? NZ : 0);
             double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
-            double VC[SOC ? N : 1], GC[SOC ? N : 1];
+            // cone slack cells of this lane (W plane of slot 0): sC[cw + s * SLOT_D (+ PL_GC | PL_VC)]
+            const int cw = grp * N * SLOT_D + (j < NZ ? j : NZ);
+            const double x0v_in = is_state ? P.x0[(size_t)b * NX + j] : 0.0;      // tiny_set_x0
             double VL[LS ? N : 1], GL[LS ? N : 1], VT[LT ? N : 1], GT[LT ? N : 1];
             double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
             double ref_last = 0.0, qx_last_plain = 0.0;
@@ -751,8 +782,13 @@ void admm_solve_kernel(const SolveArgs P) {
                 X[s] = 0.0;
                 if (s == N - 1) ref_last = r;
                 if constexpr (SOC) {
-                    VC[s] = (warm && soc_lane) ? (resumed ? P.cslack : P.prim)[off] : 0.0;         // admm.cpp:352-357
-                    GC[s] = (warm && soc_lane) ? P.cdual[off] : 0.0;
+                    // vcnew = x, zcnew = u of the solve before (admm.cpp:352-357; x[:,0] = x0 is already in place then); gc | yc
+                    double vc0 = (warm && soc_lane) ? (resumed ? P.cslack : P.prim)[off] : 0.0;
+                    const double gc0 = (warm && soc_lane) ? P.cdual[off] : 0.0;
+                    if (s == 0 && is_state && soc_lane && !resumed) vc0 = x0v_in;
+                    sC[cw + s * SLOT_D] = vc0 - gc0;
+                    sC[cw + s * SLOT_D + PL_GC] = gc0;
+                    sC[cw + s * SLOT_D + PL_VC] = vc0;
                 }
                 if constexpr (LS) {
                     VL[s] = (warm && lin_lane) ? (resumed ? P.lslack : P.prim)[off] : 0.0;         // admm.cpp:361-365
@@ -764,7 +800,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
-            double x0v = is_state ? P.x0[(size_t)b * NX + j] : 0.0;           // tiny_set_x0
+            double x0v = x0v_in;
             auto terminal_term = [&]() {   // -(Xref[:,N-1]^T Pinf) (admm.cpp:292); only state lanes' ref_last is broadcast
                 double pt[NX];
 #pragma unroll
@@ -813,6 +849,7 @@ void admm_solve_kernel(const SolveArgs P) {
             bool vp_touched = false;                           // v|z differ from what was loaded (a solve that converges at its first check leaves them alone)
             double rp = 0.0, rd = 0.0;
             const int nsteps = P.steps > 1 ? P.steps : 1;
+            const int iter_first = resumed ? P.iter_base : 0;  // (a multiple of check_termination: the countdown restarts in phase)
             for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch
                 X[0] = x0v;                                    // work->x.col(0) = x0
                 if (P.traj) {                                  // work->Xref = Xref_total.block(0, k, nx, N)
@@ -835,9 +872,11 @@ void admm_solve_kernel(const SolveArgs P) {
                 if constexpr (SOC) {
                     if (step > 0) {                            // vcnew = x, zcnew = u of the previous solve (admm.cpp:352-357)
 #pragma unroll
-                        for (int s = 0; s < N; ++s) VC[s] = soc_lane ? X[s] : 0.0;
-                    } else if (is_state && soc_lane && !resumed) {
-                        VC[0] = x0v;
+                        for (int s = 0; s < N; ++s) {
+                            const double vc0 = soc_lane ? X[s] : 0.0;
+                            sC[cw + s * SLOT_D] = vc0 - sC[cw + s * SLOT_D + PL_GC];
+                            sC[cw + s * SLOT_D + PL_VC] = vc0;
+                        }
                     }
                 }
                 if constexpr (LS) {                            // vlnew = x, zlnew = u (admm.cpp:361-365)
@@ -852,23 +891,30 @@ void admm_solve_kernel(const SolveArgs P) {
                         for (int s = 0; s < N; ++s) VT[s] = tlin_lane ? X[s] : 0.0;
                     } else if (is_state && tlin_lane && !resumed) VT[0] = x0v;
                 }
-                const int iter0 = resumed ? P.iter_base : 0;   // (a multiple of check_termination: the countdown restarts in phase)
+                const int iter0 = iter_first;
                 iter = iter0; solved = 0;
                 if (resumed && P.check_termination > 0) checked = 1;
                 int countdown = P.check_termination;
+                // SOC: vcnew - gc of slot i comes out of the W plane two sweep steps before its use (a ring of three registers); the
+                // first two of a sweep are read at the end of the iteration before
+                double wr[SOC ? 3 : 1];
+                if constexpr (SOC) {
+                    wr[(N - 1) % 3] = sC[cw + (N - 1) * SLOT_D];
+                    if constexpr (N >= 2) wr[(N - 2) % 3] = sC[cw + (N - 2) * SLOT_D];
+                }
                 for (int it = iter0; it < P.max_iter; ++it) {
                     // ---- update_linear_cost (lane-local) fused into the backward sweep.
                     // qv(s): state lanes q_s (s = N-1: the terminal p), input lanes r_{s-1}.
                     double qhi;
                     {
                         double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293 | :280
-                        if constexpr (SOC) t = fma(-rho, VC[N - 1] - GC[N - 1], t); // :295 | :282
+                        if constexpr (SOC) t = fma(-rho, wr[(N - 1) % 3], t);       // :295 | :282
                         if constexpr (LS) t = fma(-rho, VL[N - 1] - GL[N - 1], t);  // :298 | :285
                         if constexpr (LT) t = fma(-rho, VT[N - 1] - GT[N - 1], t);  // :301 | :288
                         qhi = t;
                         if constexpr (DBG) {
                             double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
-                            if constexpr (SOC) ql = fma(-rho, VC[N - 1] - GC[N - 1], ql);   // :269
+                            if constexpr (SOC) ql = fma(-rho, wr[(N - 1) % 3], ql);         // :269
                             if constexpr (LS) ql = fma(-rho, VL[N - 1] - GL[N - 1], ql);    // :272
                             if constexpr (LT) ql = fma(-rho, VT[N - 1] - GT[N - 1], ql);    // :275
                             Qd[N - 1] = is_state ? ql : t;
@@ -879,9 +925,13 @@ void admm_solve_kernel(const SolveArgs P) {
                     // ---- backward_pass_grad, admm.cpp:13-20
 #pragma unroll
                     for (int i = N - 2; i >= 0; --i) {
+                        if constexpr (SOC) {
+                            if (i >= 1) wr[(i - 1) % 3] = sC[cw + (i - 1) * SLOT_D];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
-                            if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], VC[i], GC[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                            if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % 3], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             else fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             pcur = res;                                                 // p_i | d_i
                             Dn[i] = fma(res, nim, cf);
@@ -890,7 +940,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             continue;
                         }
                         double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
-                        if constexpr (SOC) qlo = fma(-rho, VC[i] - GC[i], qlo);     // :269 | :282
+                        if constexpr (SOC) qlo = fma(-rho, wr[i % 3], qlo);         // :269 | :282
                         if constexpr (LS) qlo = fma(-rho, VL[i] - GL[i], qlo);      // :272 | :285
                         if constexpr (LT) qlo = fma(-rho, VT[i] - GT[i], qlo);      // :275 | :288
                         // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
@@ -905,7 +955,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     // the lane-local element-wise work (and its LDS bound reads) fills the dependency stalls of
                     // the next step's FMA chain instead of forming a separate, latency-exposed phase.
                     double pmax = 0.0, dmax = 0.0;
-                    auto slot_update = [&](const int s, const double lo, const double hi) {
+                    auto slot_update = [&](const int s, const double lo, const double hi, const double gcv) {
                         const double xi = X[s];
                         const double t = xi + G[s];                                 // :85 / :88
                         const double vn = vmin64(hi, vmax64(lo, t));                // :91-98
@@ -914,10 +964,12 @@ void admm_solve_kernel(const SolveArgs P) {
                         G[s] = t - vn;                      // :222 / :225  g + x - vnew; (g + x) == t bit-for-bit
                         VN[s] = vn;
                         if constexpr (SOC) {
-                            // vcnew = x + gc on every row of a family whose cone slack is on (:102-109); GC is 0 on the
-                            // other rows, so one FMA against the 0/1 mask does the add and the select
-                            const double tc = fma(xi, socmask, GC[s]);
-                            sT[(grp * N + s) * 16 + j] = tc;       // projected after the sweep, one lane per (cone, knot): the cone step below
+                            // vcnew = x + gc on every row of a family whose cone slack is on (:102-109); gc is 0 on the
+                            // other rows, so one FMA against the 0/1 mask does the add and the select.  Projected after the
+                            // sweep, one lane per (cone, knot): the cone step below; a cell outside every item keeps this
+                            // value as its vcnew, so its gc = (x + gc) - vcnew = 0
+                            sC[cw + s * SLOT_D] = fma(xi, socmask, gcv);
+                            sC[cw + s * SLOT_D + PL_GC] = 0.0;
                         }
                         // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over
                         // the row with the broadcast-FMA chain (against a vector of ones), separately for the state
@@ -956,9 +1008,15 @@ void admm_solve_kernel(const SolveArgs P) {
                     // scheduled together with the FMA chain of step i -- both only need x_i.
                     double lo_c = sLo[j], hi_c = sHi[j];
                     if constexpr (UB) { lo_c = lo_u0; hi_c = hi_u0; }
+                    double gr[SOC ? 3 : 1];                     // SOC: gc of slot i, read from its plane two steps ahead
+                    if constexpr (SOC) {
+                        gr[0] = sC[cw + PL_GC];
+                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];
+                    } else gr[0] = 0.0;
 #pragma unroll
                     for (int i = 0; i < N - 1; ++i) {
                         const double lo_n = UB ? lo_u : sLo[(i + 1) * 16 + j], hi_n = UB ? hi_u : sHi[(i + 1) * 16 + j];
+                        if constexpr (SOC) { if (i + 2 < N) gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC]; }
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
                             double tt, vn, xn, t = Dn[i];
@@ -969,42 +1027,60 @@ void admm_solve_kernel(const SolveArgs P) {
                             dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
                             G[i] = tt - vn;
                             VN[i] = vn;
-                            if constexpr (SOC) sT[(grp * N + i) * 16 + j] = fma(xi, socmask, GC[i]);     // x + gc -> cone step (below)
+                            if constexpr (SOC) {                                      // x + gc -> cone step (below); see slot_update
+                                sC[cw + i * SLOT_D] = fma(xi, socmask, gr[i % 3]);
+                                sC[cw + i * SLOT_D + PL_GC] = 0.0;
+                            }
                             lo_c = lo_n; hi_c = hi_n;
                             continue;
                         }
                         const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
                         X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)
-                        slot_update(i, lo_c, hi_c);
+                        slot_update(i, lo_c, hi_c, gr[SOC ? i % 3 : 0]);
                         lo_c = lo_n; hi_c = hi_n;
                     }
-                    slot_update(N - 1, lo_c, hi_c);
+                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % 3 : 0]);
+                    // ---- termination_condition, admm.cpp:310-328 (the box residuals: the cone slacks do not enter them)
+                    bool conv = false;
+                    auto termination = [&]() {
+                        if (countdown > 0 && --countdown == 0) {
+                            countdown = P.check_termination;
+                            checked = 1;
+                            rp = pmax;
+                            rd = dmax * rho;
+                            const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
+                            const unsigned long long bal = __ballot(ok);
+                            conv = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
+                        }
+                    };
                     if constexpr (SOC) {
                         // ---- cone step (admm.cpp:112-135, 228-235), transposed: x + gc of every slot went to LDS above; lane j
                         // of pass p gathers the three components of its (cone, knot) item, projects them -- ONE square root /
-                        // division sequence per pass instead of one per knot -- and puts the result back in place
+                        // division sequence per pass instead of one per knot -- and writes the item's cells of the three planes.
+                        // The termination test needs nothing from it and stands between the first gather and its use.
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+                        double n0 = sC[item_at[0]], n1 = sC[item_at[0] + 1], n2 = sC[item_at[0] + 2];
+                        termination();
 #pragma unroll
                         for (int p = 0; p < SOC_PASSES; ++p) {
                             if (p > 0 && p >= soc_passes) break;            // wave-uniform
                             const int at = item_at[p];
-                            const double s0 = sT[at], s1 = sT[at + 1], s2 = sT[at + 2];
+                            if (p > 0) { n0 = sC[at]; n1 = sC[at + 1]; n2 = sC[at + 2]; }
+                            const double s0 = n0, s1 = n1, s2 = n2;
                             double r0, r1, r2;
-                            soc_project3(s0, s1, s2, item_mu[p], r0, r1, r2);
-                            sT[at] = r0; sT[at + 1] = r1; sT[at + 2] = r2;  // (the dummy item: (0, 0, 1) onto itself, from every lane that has none)
+                            soc_project3(s0, s1, s2, item_mu[p], item_rmu[p], mu_pow2, r0, r1, r2);
+                            // the item's three cells of every plane (the dummy item: (0, 0, 1) onto itself, from every lane that has none)
+                            const double g0 = s0 - r0, g1 = s1 - r1, g2 = s2 - r2;      // :229 / :234  (gc + x) - vcnew
+                            sC[at + PL_VC] = r0; sC[at + PL_VC + 1] = r1; sC[at + PL_VC + 2] = r2;
+                            sC[at + PL_GC] = g0; sC[at + PL_GC + 1] = g1; sC[at + PL_GC + 2] = g2;
+                            sC[at] = r0 - g0; sC[at + 1] = r1 - g1; sC[at + 2] = r2 - g2;   // vcnew - gc: the next backward sweep's term
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int s = 0; s < N; ++s) {
-                            const double tc = fma(X[s], socmask, GC[s]);
-                            // what the passes left in this lane's cell: the projection where the lane belongs to an item, else the
-                            // x + gc the lane wrote itself (bit for bit tc: no select)
-                            const double vc = sT[(grp * N + s) * 16 + j];
-                            GC[s] = tc - vc;                                        // :229 / :234  (gc + x) - vcnew
-                            VC[s] = vc;
-                        }
+                        // the next backward sweep's first two terms, on their way while this iteration closes
+                        wr[(N - 1) % 3] = sC[cw + (N - 1) * SLOT_D];
+                        if constexpr (N >= 2) wr[(N - 2) % 3] = sC[cw + (N - 2) * SLOT_D];
                     }
                     iter += 1;                                                      // :394
                     if constexpr (ADAPT) {
@@ -1088,17 +1164,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             terminal_term();
                         }
                     }
-                    // ---- termination_condition, admm.cpp:310-328
-                    bool conv = false;
-                    if (countdown > 0 && --countdown == 0) {
-                        countdown = P.check_termination;
-                        checked = 1;
-                        rp = pmax;
-                        rd = dmax * rho;
-                        const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
-                        const unsigned long long bal = __ballot(ok);
-                        conv = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
-                    }
+                    if constexpr (!SOC) termination();                             // (after the adaptation: it may have moved rho)
                     if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)
 #pragma unroll
                     for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446
@@ -1128,8 +1194,13 @@ void admm_solve_kernel(const SolveArgs P) {
                     if (P.store_mask & 4) P.dual[off] = G[s];
                     if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];   // admm.cpp:431-441 returns before v = vnew
                     if constexpr (SOC) {
-                        // a family whose cone switch is off keeps its records (admm.cpp:102-109, 228-235)
-                        if (soc_lane && (P.store_mask & 16)) { P.cslack[off] = VC[s]; P.cdual[off] = GC[s]; }
+                        // a family whose cone switch is off keeps its records (admm.cpp:102-109, 228-235).  vcnew: the VC plane where the
+                        // cell belongs to an item (or no iteration ran: what the solve started from), else what the last forward sweep
+                        // left in the W plane
+                        if (soc_lane && (P.store_mask & 16)) {
+                            P.cslack[off] = sC[cw + s * SLOT_D + ((proj_lane || iter <= iter_first) ? PL_VC : 0)];
+                            P.cdual[off] = sC[cw + s * SLOT_D + PL_GC];
+                        }
                     }
                     if constexpr (LS) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
                     if constexpr (LT) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }

@@ -949,7 +949,7 @@ int launch_solve(TinyBatch* b) {
     if (int rc = upload_tables(b)) return rc;
     const bool soc = soc_active(b);
     SolveArgs a;
-    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0; a.work_counter = nullptr;
+    a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0; a.work_counter = nullptr; a.reverse = 0;
     a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
@@ -1012,7 +1012,7 @@ int launch_solve(TinyBatch* b) {
     SolveKernel k = nullptr;
     if (b->kernel) {
         if (jk.adapt) k = jk.soc ? nullptr : b->kernel->kadapt[jk.dbg];
-        else if (!jk.lin && !jk.het && !jk.soc && !jk.dbg && jk.mode == 2 && b->bounds_uniform && b->use_ub) k = b->kernel->kub;
+        else if (!jk.lin && !jk.het && !jk.dbg && jk.mode == 2 && b->bounds_uniform && b->use_ub) k = jk.soc ? b->kernel->kubsoc : b->kernel->kub;
         else if (!jk.lin && !jk.het) k = b->kernel->k[jk.soc][jk.dbg][jk.mode];
         else if (jk.lin && !jk.het && !jk.dbg && jk.kmax == LIN_KMAX) k = b->kernel->klin[jk.soc][jk.lin];
         else if (jk.het && !jk.lin && !jk.dbg) k = b->kernel->khet[jk.soc];
@@ -1167,6 +1167,9 @@ int launch_solve(TinyBatch* b) {
             if (last) break;
         }
     } else {
+        // option "launch_order" = 1: successive plain launches walk the batch in alternating directions (SolveArgs::reverse)
+        a.reverse = (b->launch_order == 2 || (b->launch_order == 1 && b->order_flip)) ? 1 : 0;
+        b->order_flip = !b->order_flip;
         if (int rc = launch(grid)) return rc;
     }
     if (timed) {
@@ -1804,6 +1807,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
     else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
+    else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
