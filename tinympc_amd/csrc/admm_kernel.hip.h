@@ -492,6 +492,26 @@ __device__ __forceinline__ double resid_max(double a, double b) {
     else return fmax(a, fabs(b));
 }
 
+// The x|u trajectory is written once per launch and never read back by a kernel: it need not displace the warm-start records
+// (vnew|znew, g|y, v|z: 240 MiB at 65 536 quadrotor instances) from the 256 MiB Infinity Cache in front of HBM.
+// TINYMPC_PRIM_STORE: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (experiment builds, tools/build_variants.py)
+#ifndef TINYMPC_PRIM_STORE
+#define TINYMPC_PRIM_STORE 0
+#endif
+__device__ __forceinline__ void store_primal(double* p, double v) {
+#if TINYMPC_PRIM_STORE == 1
+    __builtin_nontemporal_store(v, p);
+#elif TINYMPC_PRIM_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif TINYMPC_PRIM_STORE == 3
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#elif TINYMPC_PRIM_STORE == 4
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ double grp_max16(double v) {
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 16));
@@ -901,6 +921,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 if constexpr (SOC) {
                     wr[(N - 1) % 3] = sC[cw + (N - 1) * SLOT_D];
                     if constexpr (N >= 2) wr[(N - 2) % 3] = sC[cw + (N - 2) * SLOT_D];
+                    if constexpr (N >= 3) wr[(N - 3) % 3] = sC[cw + (N - 3) * SLOT_D];
                 }
                 for (int it = iter0; it < P.max_iter; ++it) {
                     // ---- update_linear_cost (lane-local) fused into the backward sweep.
@@ -926,7 +947,7 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                     for (int i = N - 2; i >= 0; --i) {
                         if constexpr (SOC) {
-                            if (i >= 1) wr[(i - 1) % 3] = sC[cw + (i - 1) * SLOT_D];
+                            if (i >= 2) wr[(i - 2) % 3] = sC[cw + (i - 2) * SLOT_D];      // (slot i + 1's register is free by now)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
@@ -1078,9 +1099,10 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        // the next backward sweep's first two terms, on their way while this iteration closes
+                        // the next backward sweep's first three terms, on their way while this iteration closes
                         wr[(N - 1) % 3] = sC[cw + (N - 1) * SLOT_D];
                         if constexpr (N >= 2) wr[(N - 2) % 3] = sC[cw + (N - 2) * SLOT_D];
+                        if constexpr (N >= 3) wr[(N - 3) % 3] = sC[cw + (N - 3) * SLOT_D];
                     }
                     iter += 1;                                                      // :394
                     if constexpr (ADAPT) {
@@ -1189,7 +1211,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 if (valid) {
                     // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
                     // bit 0: the whole x|u trajectory; bit 5: only its first knot (x_0, x_1, u_0: what a closed-loop caller applies)
-                    if (((P.store_mask & 1) || ((P.store_mask & 32) && s <= 1)) && (acc_iter > 0 || (s == 0 && is_state))) P.prim[off] = X[s];
+                    if (((P.store_mask & 1) || ((P.store_mask & 32) && s <= 1)) && (acc_iter > 0 || (s == 0 && is_state))) store_primal(P.prim + off, X[s]);
                     if (P.store_mask & 2) P.slack[off] = VN[s];
                     if (P.store_mask & 4) P.dual[off] = G[s];
                     if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];   // admm.cpp:431-441 returns before v = vnew

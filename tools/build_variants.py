@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Experiment builds: copies of the product library in which ONE kernel translation unit is rebuilt with extra -D flags and / or a
+patched COPY of admm_kernel.hip.h (nothing in csrc/ is modified); run a tool against one with TINYMPC_AMD_LIB=<path>.
+    python tools/build_variants.py [tag ...]        -> tinympc_amd/libtinympc_amd_<tag>.so
+  prim1..prim4  (12,4,10): the x|u store as nontemporal / sc1 / sc0 sc1 / sc0 sc1 nt (TINYMPC_PRIM_STORE)
+  socclk        (6,3,10): s_memtime phase clocks of the cone kernel's iteration (backward, forward, cone step, tail) in the four
+                residual outputs (shader cycles summed over the iterations of a solve)"""
+import os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tinympc_amd", "csrc")
+FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-but-set-variable -Wno-unused-variable".split()
+
+SOCCLK = [
+    ("                for (int it = iter0; it < P.max_iter; ++it) {\n",
+     "                long long clkB = 0, clkF = 0, clkC = 0, clkT = 0;\n                for (int it = iter0; it < P.max_iter; ++it) {\n                    const long long t0 = clock64();\n"),
+    ("                    double pmax = 0.0, dmax = 0.0;\n",
+     "                    const long long t1 = clock64();\n                    double pmax = 0.0, dmax = 0.0;\n"),
+    ("                    // ---- termination_condition, admm.cpp:310-328 (the box residuals: the cone slacks do not enter them)\n",
+     "                    const long long t2 = clock64();\n"),
+    ("                    iter += 1;                                                      // :394\n",
+     "                    const long long t3 = clock64();\n                    iter += 1;\n"),
+    ("                    if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)\n#pragma unroll\n                    for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446\n                    vp_touched = true;\n",
+     "                    if (conv) { solved = 1; break; }\n#pragma unroll\n                    for (int s = 0; s < N; ++s) VP[s] = VN[s];\n                    vp_touched = true;\n"
+     "                    const long long t4 = clock64();\n                    clkB += t1 - t0; clkF += t2 - t1; clkC += t3 - t2; clkT += t4 - t3;\n"),
+    ("                acc_iter += (unsigned)(iter - iter0);\n",
+     "                acc_iter += (unsigned)(iter - iter0);\n                rp = (double)clkB; rd = (double)clkF; rc_ = (double)clkC; rt_ = (double)clkT;\n"),
+    ("            double rp = 0.0, rd = 0.0;\n", "            double rp = 0.0, rd = 0.0, rc_ = 0.0, rt_ = 0.0;\n"),
+    ("            const double ps = grp_max16(is_state ? rp : 0.0), pi = grp_max16(is_input ? rp : 0.0);\n            const double ds = grp_max16(is_state ? rd : 0.0), di = grp_max16(is_input ? rd : 0.0);\n",
+     "            const double ps = rp, pi = rd, ds = rc_, di = rt_;\n"),
+]
+VARIANTS = {
+    "prim1": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=1"], []),
+    "prim2": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=2"], []),
+    "prim3": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
+    "prim4": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
+    "socclk": ("k_6_3_10", [], SOCCLK),
+}
+
+
+def build(tag):
+    unit, defs, patches = VARIANTS[tag]
+    tmp = "/tmp/variant_" + tag
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp + "/_gen")
+    for f in os.listdir(SRC):
+        if f.endswith((".h", ".hpp", ".hip")):
+            shutil.copy(os.path.join(SRC, f), tmp)
+    shutil.copy(os.path.join(SRC, "_gen", unit + ".hip"), tmp + "/_gen")
+    p = tmp + "/admm_kernel.hip.h"
+    s = open(p).read()
+    for a, b in patches:
+        assert a in s, a
+        s = s.replace(a, b, 1)
+    open(p, "w").write(s)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *defs, "-c", tmp + "/_gen/" + unit + ".hip", "-o", tmp + "/k.o"])
+    objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != unit + ".o" and "_chk" not in f]
+    out = os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_%s.so" % tag)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-Wl,-Bsymbolic", "-o", out, *objs, tmp + "/k.o", "-ldl"])
+    print("built", out)
+
+
+if __name__ == "__main__":
+    for t in (sys.argv[1:] or VARIANTS):
+        build(t)

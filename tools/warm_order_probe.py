@@ -24,9 +24,10 @@ for B in [int(b) for b in os.environ.get("BATCHES", "65536").split(",")]:
     print("| store_primal | share_ref | grid waves/CU | launch_order | steps 70-99: us mean | us min | moved B/solve | moved TB/s | formula TB/s |")
     print("|---|---|---|---|---|---|---|---|---|")
     its = None
-    for sp in (1, 0):
+    quick = bool(os.environ.get("QUICK"))
+    for sp in ((1,) if quick else (1, 0)):
         for sr in (1, 0):
-            for g in (0, 8):
+            for g in ((0,) if quick else (0, 8)):
                 for lo in (0, 1):
                     s.set_option("store_primal", sp); s.set_option("share_ref", sr); s.set_option("grid_waves_per_cu", g); s.set_option("launch_order", lo)
                     runs = []
@@ -47,4 +48,6 @@ for B in [int(b) for b in os.environ.get("BATCHES", "65536").split(",")]:
                     moved = np.mean([bw - (8 * S if sr else 0) - (8 * S if i == 1 else 0) - (8 * S if sp == 0 else 0) for i in its[70:]])
                     t = ms.mean() * 1e-3
                     print(f"| {sp} | {sr} | {g} | {lo} | {ms.mean()*1e3:.1f} | {ms.min()*1e3:.1f} | {moved:.0f} | {moved*B/t/1e12:.2f} | {bw*B/t/1e12:.2f} |", flush=True)
+                    if quick:
+                        print("    per step us:", " ".join(f"{v*1e3:.0f}" for v in ms), " iters:", " ".join(str(i) for i in its[70:]), flush=True)
     s.close()
