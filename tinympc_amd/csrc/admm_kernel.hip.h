@@ -496,8 +496,19 @@ __device__ __forceinline__ double resid_max(double a, double b) {
 // (vnew|znew, g|y, v|z: 240 MiB at 65 536 quadrotor instances) from the 256 MiB Infinity Cache in front of HBM.
 // TINYMPC_PRIM_STORE: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (experiment builds, tools/build_variants.py)
 #ifndef TINYMPC_PRIM_STORE
-#define TINYMPC_PRIM_STORE 0
+#define TINYMPC_PRIM_STORE 1
 #endif
+#ifndef TINYMPC_REF_LOAD
+#define TINYMPC_REF_LOAD 0
+#endif
+// per-instance Xref|Uref records are read once per launch and never written by a kernel: the same argument (1 = nontemporal load)
+__device__ __forceinline__ double load_ref(const double* p) {
+#if TINYMPC_REF_LOAD == 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ void store_primal(double* p, double v) {
 #if TINYMPC_PRIM_STORE == 1
     __builtin_nontemporal_store(v, p);
@@ -794,7 +805,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
                 const bool warm = valid && !P.cold;
-                const double r = valid ? P.ref[P.ref_shared ? (off - (size_t)b * (N * NZ)) : off] : 0.0;
+                const double r = valid ? (P.ref_shared ? P.ref[off - (size_t)b * (N * NZ)] : load_ref(P.ref + off)) : 0.0;
                 VN[s] = warm ? P.slack[off] : 0.0;
                 G[s] = warm ? P.dual[off] : 0.0;
                 VP[s] = warm ? P.slack_prev[off] : 0.0;
@@ -988,9 +999,8 @@ void admm_solve_kernel(const SolveArgs P) {
                             // vcnew = x + gc on every row of a family whose cone slack is on (:102-109); gc is 0 on the
                             // other rows, so one FMA against the 0/1 mask does the add and the select.  Projected after the
                             // sweep, one lane per (cone, knot): the cone step below; a cell outside every item keeps this
-                            // value as its vcnew, so its gc = (x + gc) - vcnew = 0
+                            // value as its vcnew, so its gc = (x + gc) - vcnew = 0 (written once per solve, behind the cone step)
                             sC[cw + s * SLOT_D] = fma(xi, socmask, gcv);
-                            sC[cw + s * SLOT_D + PL_GC] = 0.0;
                         }
                         // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over
                         // the row with the broadcast-FMA chain (against a vector of ones), separately for the state
@@ -1048,10 +1058,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
                             G[i] = tt - vn;
                             VN[i] = vn;
-                            if constexpr (SOC) {                                      // x + gc -> cone step (below); see slot_update
-                                sC[cw + i * SLOT_D] = fma(xi, socmask, gr[i % 3]);
-                                sC[cw + i * SLOT_D + PL_GC] = 0.0;
-                            }
+                            if constexpr (SOC) sC[cw + i * SLOT_D] = fma(xi, socmask, gr[i % 3]);     // x + gc -> cone step (below); see slot_update
                             lo_c = lo_n; hi_c = hi_n;
                             continue;
                         }
@@ -1096,6 +1103,12 @@ void admm_solve_kernel(const SolveArgs P) {
                             sC[at + PL_VC] = r0; sC[at + PL_VC + 1] = r1; sC[at + PL_VC + 2] = r2;
                             sC[at + PL_GC] = g0; sC[at + PL_GC + 1] = g1; sC[at + PL_GC + 2] = g2;
                             sC[at] = r0 - g0; sC[at + 1] = r1 - g1; sC[at + 2] = r2 - g2;   // vcnew - gc: the next backward sweep's term
+                        }
+                        // a cell outside every item: gc = (x + gc) - vcnew = 0 from the solve's first iteration on (whatever the warm start
+                        // held there); once per solve, wave-uniform (the rows of a wave open their solves together)
+                        if (it == iter0 && !proj_lane) {
+#pragma unroll
+                            for (int s = 0; s < N; ++s) sC[cw + s * SLOT_D + PL_GC] = 0.0;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
@@ -1211,7 +1224,11 @@ void admm_solve_kernel(const SolveArgs P) {
                 if (valid) {
                     // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
                     // bit 0: the whole x|u trajectory; bit 5: only its first knot (x_0, x_1, u_0: what a closed-loop caller applies)
-                    if (((P.store_mask & 1) || ((P.store_mask & 32) && s <= 1)) && (acc_iter > 0 || (s == 0 && is_state))) store_primal(P.prim + off, X[s]);
+                    if (((P.store_mask & 1) || ((P.store_mask & 32) && s <= 1)) && (acc_iter > 0 || (s == 0 && is_state))) {
+                        // (a cone / half-space variant reads x|u back at the start of the next solve, admm.cpp:352-374: plain store)
+                        if constexpr (SOC || LIN != 0) P.prim[off] = X[s];
+                        else store_primal(P.prim + off, X[s]);
+                    }
                     if (P.store_mask & 2) P.slack[off] = VN[s];
                     if (P.store_mask & 4) P.dual[off] = G[s];
                     if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];   // admm.cpp:431-441 returns before v = vnew

@@ -2,7 +2,8 @@
 """Experiment builds: copies of the product library in which ONE kernel translation unit is rebuilt with extra -D flags and / or a
 patched COPY of admm_kernel.hip.h (nothing in csrc/ is modified); run a tool against one with TINYMPC_AMD_LIB=<path>.
     python tools/build_variants.py [tag ...]        -> tinympc_amd/libtinympc_amd_<tag>.so
-  prim1..prim4  (12,4,10): the x|u store as nontemporal / sc1 / sc0 sc1 / sc0 sc1 nt (TINYMPC_PRIM_STORE)
+  prim0..prim4  (12,4,10): the x|u store plain / nontemporal (the default) / sc1 / sc0 sc1 / sc0 sc1 nt (TINYMPC_PRIM_STORE)
+  refnt         (12,4,10): per-instance Xref|Uref records read with nontemporal loads (TINYMPC_REF_LOAD=1)
   socclk        (6,3,10): s_memtime phase clocks of the cone kernel's iteration (backward, forward, cone step, tail) in the four
                 residual outputs (shader cycles summed over the iterations of a solve)"""
 import os, shutil, subprocess, sys
@@ -29,6 +30,8 @@ SOCCLK = [
      "            const double ps = rp, pi = rd, ds = rc_, di = rt_;\n"),
 ]
 VARIANTS = {
+    "prim0": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=0"], []),
+    "refnt": ("k_12_4_10", ["-DTINYMPC_REF_LOAD=1"], []),
     "prim1": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=1"], []),
     "prim2": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=2"], []),
     "prim3": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
