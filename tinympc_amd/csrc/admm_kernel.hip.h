@@ -499,7 +499,7 @@ __device__ __forceinline__ double resid_max(double a, double b) {
 #define TINYMPC_PRIM_STORE 1
 #endif
 #ifndef TINYMPC_REF_LOAD
-#define TINYMPC_REF_LOAD 0
+#define TINYMPC_REF_LOAD 1
 #endif
 // per-instance Xref|Uref records are read once per launch and never written by a kernel: the same argument (1 = nontemporal load)
 __device__ __forceinline__ double load_ref(const double* p) {

@@ -50,8 +50,14 @@ def reduce_table(table, total_batch=None):
     reduce_wire_table."""
     import torch
     t = torch.as_tensor(table, dtype=torch.float64)
-    cols = t.shape[-1] if t.dim() == 2 else len(WIRE_IDX)
-    t = t.reshape(-1, cols)
+    if t.dim() == 1:                                                # one message: its length says whether the size column is there
+        if t.numel() not in (len(WIRE_IDX), len(WIRE_IDX) + 1):
+            raise ValueError("reduce_table: a flat table must be ONE wire message (8 doubles, or 9 with the shard size); "
+                             "pass a 2-D [ranks][8 | 9] table otherwise")
+        t = t.reshape(1, -1)
+    if t.dim() != 2 or t.shape[1] not in (len(WIRE_IDX), len(WIRE_IDX) + 1):
+        raise ValueError("reduce_table: expected a [ranks][8 | 9] table, got shape %s" % (tuple(t.shape),))
+    cols = t.shape[1]
     out = torch.zeros(10, dtype=torch.float64)
     sums = t[:, :4].sum(dim=0)
     out[0], out[1], out[7], out[8] = sums[0], sums[1], sums[2], sums[3]
@@ -115,9 +121,8 @@ class StatsExchange:
             can = can and tm.rccl_available() and 0 <= device_index < tm.device_count()
         except Exception:                            # noqa: BLE001
             can = False
-        flag = torch.tensor([1.0 if can else 0.0], device=f"cuda:{device_index}")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        ok = float(flag.item()) >= 1.0
+        ok = self._agree(can)
+        self.timeout_s = float(os.environ.get("TINYMPC_DIST_TIMEOUT", "120"))
         if ok:
             try:
                 box = [tm.rccl_unique_id() if self.rank == 0 else None]
@@ -129,12 +134,11 @@ class StatsExchange:
                 try:
                     self.comm = tm.rccl_comm_init_rank(self.world, bytes(box[0]), self.rank, device_index)
                     self.comm_ranks = tm.rccl_comm_count(self.comm)
+                    ok = self.comm_ranks == self.world          # a communicator of another size is not the one the job agreed on
                 except Exception:                    # noqa: BLE001
                     ok = False
         # all ranks or none: a rank whose join failed must not leave the others waiting inside the all-gather
-        flag = torch.tensor([1.0 if ok else 0.0], device=f"cuda:{device_index}")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if float(flag.item()) < 1.0:
+        if not self._agree(ok):
             # Still RCCL, through torch.distributed: the same 64-byte messages as a one-hot all-reduce (allreduce_stats)
             if self.comm:
                 tm.rccl_comm_destroy(self.comm)
@@ -142,6 +146,20 @@ class StatsExchange:
             self._stats = torch.zeros(10, dtype=torch.float64, device=f"cuda:{device_index}")
             import sys
             print("tinympc_amd: native RCCL communicator unavailable, statistics exchange through torch.distributed", file=sys.stderr)
+
+    def _agree(self, mine):
+        """MIN over the ranks of a 0/1 flag.  The flag lives where the process group can certainly reach it -- the device the
+        group was initialised on (torch.cuda.current_device(): a rank whose OWN device_index is bad still enters the collective
+        and votes 0 instead of raising on its own and leaving the others inside it), host memory for gloo."""
+        import torch
+        backend = str(self.dist.get_backend(self.group)) if hasattr(self.dist, "get_backend") else "nccl"
+        try:
+            dev = torch.device("cpu") if "gloo" in backend else torch.device("cuda", torch.cuda.current_device())
+            flag = torch.tensor([1.0 if mine else 0.0], device=dev)
+        except Exception:                            # noqa: BLE001  (no usable device at all: vote 0 from the host if the backend lets us)
+            flag = torch.tensor([0.0])
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return float(flag.item()) >= 1.0
 
     def __call__(self):
         import torch

@@ -3,7 +3,7 @@
 patched COPY of admm_kernel.hip.h (nothing in csrc/ is modified); run a tool against one with TINYMPC_AMD_LIB=<path>.
     python tools/build_variants.py [tag ...]        -> tinympc_amd/libtinympc_amd_<tag>.so
   prim0..prim4  (12,4,10): the x|u store plain / nontemporal (the default) / sc1 / sc0 sc1 / sc0 sc1 nt (TINYMPC_PRIM_STORE)
-  refnt         (12,4,10): per-instance Xref|Uref records read with nontemporal loads (TINYMPC_REF_LOAD=1)
+  ref0          (12,4,10): per-instance Xref|Uref records read with plain loads (TINYMPC_REF_LOAD=0; the default is nontemporal)
   socclk        (6,3,10): s_memtime phase clocks of the cone kernel's iteration (backward, forward, cone step, tail) in the four
                 residual outputs (shader cycles summed over the iterations of a solve)"""
 import os, shutil, subprocess, sys
@@ -31,12 +31,18 @@ SOCCLK = [
 ]
 VARIANTS = {
     "prim0": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=0"], []),
-    "refnt": ("k_12_4_10", ["-DTINYMPC_REF_LOAD=1"], []),
+    "ref0": ("k_12_4_10", ["-DTINYMPC_REF_LOAD=0"], []),
     "prim1": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=1"], []),
     "prim2": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=2"], []),
     "prim3": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
     "prim4": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
     "socclk": ("k_6_3_10", [], SOCCLK),
+    # timing-only ablations of the cone kernel (results are WRONG by construction)
+    "abl_fwd_nogc": ("k_6_3_10", [], [("gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC];", "gr[(i + 2) % 3] = 0.0;"),
+                                     ("                        gr[0] = sC[cw + PL_GC];\n                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];\n",
+                                      "                        gr[0] = 0.0; gr[1] = 0.0;\n")]),
+    "abl_bwd_now": ("k_6_3_10", [], [("if (i >= 2) wr[(i - 2) % 3] = sC[cw + (i - 2) * SLOT_D];", "if (i >= 2) wr[(i - 2) % 3] = 0.0;")]),
+    "abl_nopass": ("k_6_3_10", [], [("                            if (p > 0 && p >= soc_passes) break;            // wave-uniform\n", "                            break;\n")]),
 }
 
 
