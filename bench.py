@@ -33,7 +33,8 @@ Rooflines (all in the one JSON line):
   regimes          an untimed replay of the reference episode with ONE launch per MPC step after the
                    timed region: cold steps 0-4 (FP64 fraction) and steady state steps 70-99 -- `hbm_frac` counts the
                    bytes the launch form really moves, `hbm_frac_formula` SURVEY.md 8(d)'s bytes_warm
-  configs          (1 GPU) BASELINE configs 3, 4 and six cells of config 5, each with its own roofline (tools/bench_configs.py)
+  configs          (1 GPU) BASELINE configs 3, 4 (input cone / state cone / both) and six cells of config 5, each with its own
+                   roofline (median), a parity sample against the oracle and the reference timed on the same records
   cpu_baseline     (1 GPU) the real reference on the host cores, AFTER the GPU legs, in processes of its own
 """
 import argparse
@@ -134,30 +135,94 @@ def parse_args(argv=None):
     ap.add_argument("--no-regimes", action="store_true", help="skip the untimed one-launch-per-step replay")
     ap.add_argument("--regimes", action="store_true", help="(kept for old command lines: the replay is always on)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3 / 4 / 5-slice (1-GPU runs carry them by default)")
-    ap.add_argument("--configs-budget", type=float, default=30.0, help="seconds after which no further config entry is started")
+    ap.add_argument("--configs-budget", type=float, default=60.0, help="seconds after which no further config entry is started")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, weak scaling: skip the additional strong-scaling measurement")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--configs-cpu-seconds", type=float, default=1.0,
+                    help="seconds of reference solve time per host core and `configs` entry (oracle/config_check.py)")
+    ap.add_argument("--dist-timeout", type=float, default=120.0,
+                    help="N > 1: seconds a rendezvous / process-group collective / communicator setup may take before the rank gives up")
+    ap.add_argument("--run-timeout", type=float, default=900.0,
+                    help="N > 1, plain process: seconds the self-spawned ranks get for the measurement itself, on top of --dist-timeout")
     return ap.parse_args(argv)
+
+
+def error_line(args, world, message, **extra):
+    """The ONE JSON line of a run that could not produce a measurement: same envelope (metric, n_gpus, steps, ...), `value` null,
+    `error` says why, `preflight` what this process can see of the node (GPU count, RCCL loadable) -- so that a failed N > 1 run
+    leaves a record instead of silence."""
+    out = {"metric": "QP solves/sec (+ ADMM iters/sec), 64k-batch quadrotor hover", "value": None, "unit": "QP solves/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic", "config": {"workload": "quadrotor_hovering (nx=12, nu=4, N=10) x %d (BASELINE configs[1])" % args.batch},
+           "error": message}
+    pre = {}
+    try:
+        import tinympc_amd as tm
+        pre["gpus_visible"] = tm.device_count()
+        pre["rccl_loadable"] = bool(tm.rccl_available())
+    except Exception as e:                               # noqa: BLE001
+        pre["library_error"] = repr(e)
+    pre["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    out["preflight"] = pre
+    out.update(extra)
+    return json.dumps(out)
 
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` as a PLAIN process: start N ranks of this very script under torch.distributed.run (one process
-    per GPU, rendezvous on 127.0.0.1) and hand rank 0's one JSON line through.  Same code path as the launcher form."""
+    per GPU, rendezvous on 127.0.0.1) and hand rank 0's one JSON line through.  Same code path as the launcher form.  The ranks run
+    in a process group of their own under a deadline (--dist-timeout for the rendezvous / communicator setup + --run-timeout for the
+    measurement): whatever happens to them -- a rank that dies, a rendezvous or ncclCommInitRank that never returns -- this process
+    still prints exactly one JSON line (error_line) and returns non-zero."""
+    import signal
     import tinympc_amd as tm
     have = tm.device_count()
     if have < args.gpus and not os.environ.get("TINYMPC_BENCH_SHARE_GPU"):
-        sys.exit("bench.py --gpus %d: this node shows %d GPU(s) (TINYMPC_BENCH_SHARE_GPU=1 lets the ranks share devices over gloo: "
-                 "a smoke run of the control flow, not a measurement)" % (args.gpus, have))
+        print(error_line(args, args.gpus, "bench.py --gpus %d: this node shows %d GPU(s) (TINYMPC_BENCH_SHARE_GPU=1 lets the ranks share devices "
+                                           "over gloo: a smoke run of the control flow, not a measurement)" % (args.gpus, have)), flush=True)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TINYMPC_BENCH_SELF_SPAWNED="1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TINYMPC_BENCH_SELF_SPAWNED="1",
+               TINYMPC_DIST_TIMEOUT=str(args.dist_timeout))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
-    return subprocess.call(cmd, env=env)
+    deadline = args.dist_timeout + args.run_timeout
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        out, _ = p.communicate(timeout=deadline)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig in (signal.SIGTERM, signal.SIGKILL):     # the launcher AND its ranks: they share the session started above
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        out = ""
+        try:
+            out = p.stdout.read() or ""
+        except Exception:                                # noqa: BLE001
+            pass
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    if not timed_out and len(lines) == 1:                # rank 0's line: the result, or its own account of what stopped the job
+        print(lines[0], flush=True)
+        return p.returncode if p.returncode else (1 if '"error"' in lines[0] else 0)
+    why = ("the ranks did not finish within %.0f s (--dist-timeout %.0f + --run-timeout %.0f): killed" % (deadline, args.dist_timeout, args.run_timeout)
+           if timed_out else "the ranks ended with rc %s and %d JSON line(s) on stdout" % (p.returncode, len(lines)))
+    print(error_line(args, args.gpus, "self-spawned torch.distributed.run: " + why, launcher_rc=p.returncode,
+                     launcher_seconds=time.perf_counter() - t0, partial_lines=lines[:2]), flush=True)
+    return 1 if (timed_out or p.returncode == 0) else (p.returncode if 0 < p.returncode < 256 else 1)
 
 
 class Job:
@@ -178,13 +243,22 @@ class Job:
         self.dev = f"cuda:{self.local_rank}"
         self.dist = None
         if self.world > 1 or os.environ.get("TINYMPC_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path on one GPU
+            import datetime
             import torch.distributed as dist
             self.dist = dist
+            # test hook (tests/test_gpu_sharding.py): TINYMPC_BENCH_FAULT="<rank>:exit" | "<rank>:hang" makes that rank die / stall
+            # in front of the rendezvous -- what the deadline handling in spawn_ranks and the collective timeout here are for
+            fault = os.environ.get("TINYMPC_BENCH_FAULT", "")
+            if fault and int(fault.split(":")[0]) == self.rank:
+                if fault.endswith("hang"):
+                    time.sleep(1e6)
+                os._exit(17)
+            to = datetime.timedelta(seconds=float(os.environ.get("TINYMPC_DIST_TIMEOUT", args.dist_timeout)))
             if self.share_gpu:
                 os.environ["TINYMPC_EXCHANGE"] = "torch"
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=to)
             else:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))   # "nccl" is RCCL on ROCm
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), timeout=to)   # "nccl" is RCCL on ROCm
         self.one = torch.zeros(1, device=self.dev)
         self.stream = torch.cuda.Stream(device=self.local_rank)
 
@@ -385,6 +459,19 @@ def cpu_baseline_subprocess(seconds, steps):
         return {"error": repr(e)}
 
 
+def config_check_subprocess(spec_path, seconds):
+    code = ("import sys, json; sys.path.insert(0, %r); import config_check; "
+            "print('@@CHK@@' + json.dumps(config_check.run(%r, seconds=%r)))" % (os.path.join(ROOT, "oracle"), spec_path, seconds))
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=max(300.0, 200 * seconds))
+        for line in p.stdout.splitlines():
+            if line.startswith("@@CHK@@"):
+                return json.loads(line[7:])
+        return {"error": (p.stderr or p.stdout)[-600:]}
+    except Exception as e:                               # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL across ranks)
@@ -395,6 +482,36 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    # A rank of an N > 1 job must never end in silence: whatever stops it -- an exception out of a collective that timed out
+    # (--dist-timeout), a setup phase that never returns (watchdog below: ncclCommInitRank has no timeout of its own) -- rank 0
+    # still writes ONE JSON line with "error" before it leaves.
+    setup_done = [False]
+
+    def give_up(message):
+        if env_rank == 0:
+            os.write(result_fd, (error_line(args, env_world, message) + "\n").encode())
+        os._exit(3)
+
+    if env_world > 1:
+        import threading
+
+        def watchdog():
+            time.sleep(args.dist_timeout)
+            if not setup_done[0]:
+                give_up("rank %d: process group / RCCL communicator setup did not finish within --dist-timeout %.0f s" % (env_rank, args.dist_timeout))
+        threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        run(args, result_fd, setup_done)
+    except SystemExit:
+        raise
+    except BaseException as e:                           # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        give_up("rank %d: %r" % (env_rank, e))
+
+
+def run(args, result_fd, setup_done):
     t_start = time.perf_counter()
 
     import numpy as np
@@ -410,6 +527,11 @@ def main():
     B = shard_size(args.batch, rank, world) if strong else args.batch
     total = args.batch if strong else world * args.batch
     hv = Hover(job, args, B, total)
+    if job.dist is not None:                             # the communicator has carried one exchange: setup is over
+        with job.torch.cuda.stream(job.stream):
+            hv.exchange()
+            job.barrier()
+    setup_done[0] = True
     nx, nu, N, T, launches = hv.nx, hv.nu, hv.N, hv.T, hv.launches
     m = hv.measure(args.min_seconds)
     elapsed, rep_s, st = m["elapsed"], m["rep_s"], m["st"]
@@ -444,17 +566,28 @@ def main():
                         "note": "the same timed region with 65 536 instances in TOTAL, sharded over the ranks (BASELINE: '64k-batch ... 1/2/4/8 GPU')"}
         hs.close()
 
-    configs = None
+    configs, spec_path = None, None
     if rank == 0 and world == 1 and not args.no_configs:
+        import tempfile
         import bench_configs
+        spec_path = os.path.join(tempfile.mkdtemp(prefix="tinympc_bench_"), "config_samples.pkl")
         configs = bench_configs.run_all(device=job.local_rank, budget_s=args.configs_budget,
-                                        log=lambda msg: print(msg, file=sys.stderr, flush=True))
+                                        log=lambda msg: print(msg, file=sys.stderr, flush=True), spec_out=spec_path)
     gpu_phase_s = time.perf_counter() - t_start
 
     # CPU baseline LAST (rank 0, N = 1 only): the real reference on every host core, the SAME workload as the timed region
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(args.cpu_seconds, args.steps)
+        # ... and the checker of the `configs` entries: the oracle on a sample of each entry's own records (`parity_sample`), the
+        # real reference timed on the same records (`cpu_baseline` of the entry) -- oracle/config_check.py, processes of its own
+        if configs is not None and spec_path and os.path.exists(spec_path):
+            chk = config_check_subprocess(spec_path, args.configs_cpu_seconds)
+            for name, e in configs.items():
+                if isinstance(chk.get(name), dict) and "error" not in e and "skipped" not in e:
+                    e.update(chk[name])
+                elif "error" in chk and "error" not in e and "skipped" not in e:
+                    e["parity_sample"] = {"error": chk["error"]}
 
     solves = float(total) * args.steps
     value = solves / elapsed

@@ -87,6 +87,9 @@ class _CpuSolver:
             f = getattr(lib, p + "closed_loop")
             f.restype = C.c_long
             f.argtypes = [C.c_void_p, _dp, C.c_int, _ip, _dp]
+            f = getattr(lib, p + "closed_loop_traj")
+            f.restype = C.c_long
+            f.argtypes = [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _ip, _dp]
             cls._libs[cls.so] = lib
         return cls._libs[cls.so]
 
@@ -199,6 +202,17 @@ class _CpuSolver:
         u0 = np.zeros((steps, self.nu))
         total = self._f("closed_loop")(self.h, x0.ctypes.data_as(_dp), steps, iters.ctypes.data_as(_ip),
                                        u0.ctypes.data_as(_dp))
+        return int(total), iters, u0, x0
+
+    def closed_loop_traj(self, x0, steps, traj, k0=0):
+        """closed loop with the state reference of step k = points k0 + k ... k0 + k + N - 1 of traj [points, nx] (clamped to the
+        last point); -> (total iterations, iters[steps] (negative: max_iter hit), u0[steps, nu], final x0)"""
+        x0 = _d(x0).copy()
+        t = np.ascontiguousarray(np.asarray(traj, dtype=np.float64).reshape(-1, self.nx))
+        iters = np.zeros(steps, dtype=np.int32)
+        u0 = np.zeros((steps, self.nu))
+        total = self._f("closed_loop_traj")(self.h, x0.ctypes.data_as(_dp), steps, t.ctypes.data_as(_dp), t.shape[0], int(k0),
+                                            iters.ctypes.data_as(_ip), u0.ctypes.data_as(_dp))
         return int(total), iters, u0, x0
 
     STATE_FIELDS = ("x", "u", "q", "r", "p", "d", "v", "vnew", "z", "znew", "g", "y",

@@ -249,4 +249,28 @@ long ref_closed_loop(void* hv, double* x0, int steps, int* iters_out, double* u0
     return total;
 }
 
+// the same with a moving state-reference window (see oracle_closed_loop_traj): examples/rocket_landing_mpc.cpp:120-135
+long ref_closed_loop_traj(void* hv, double* x0, int steps, const double* traj, int points, int k0, int* iters_out, double* u0_out) {
+    TinySolver* s = static_cast<RefHandle*>(hv)->solver;
+    TinyWorkspace* w = s->work;
+    const int nx = w->nx, nu = w->nu, N = w->N;
+    tinyVector x = cm(x0, nx, 1);
+    long total = 0;
+    for (int k = 0; k < steps; ++k) {
+        w->x.col(0) = x;
+        for (int i = 0; i < N; ++i) {
+            int kk = k0 + k + i;
+            if (kk > points - 1) kk = points - 1;
+            w->Xref.col(i) = cm(traj + (size_t)nx * kk, nx, 1);
+        }
+        tiny_solve(s);
+        total += s->solution->iter;
+        if (iters_out) iters_out[k] = s->solution->solved ? s->solution->iter : -s->solution->iter;
+        if (u0_out) std::memcpy(u0_out + (size_t)nu * k, w->u.data(), sizeof(double) * nu);
+        x = w->Adyn * x + w->Bdyn * w->u.col(0) + w->fdyn;
+    }
+    std::memcpy(x0, x.data(), sizeof(double) * nx);
+    return total;
+}
+
 }  // extern "C"

@@ -81,6 +81,7 @@ void oracle_project_soc(double* s, int n, double mu);
  * steps x { x[:,0] = x0; solve; x0 = A x0 + B u[:,0] + f }.  iters_out[steps],
  * u0_out[steps*nu] may be NULL. x0 is updated in place. Returns total iterations. */
 long oracle_closed_loop(OracleSolver* s, double* x0, int steps, int* iters_out, double* u0_out);
+long oracle_closed_loop_traj(OracleSolver* s, double* x0, int steps, const double* traj, int points, int k0, int* iters_out, double* u0_out);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,30 @@ def test_bench_plain_process_spawns_its_own_ranks_weak_and_strong():
     assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9
 
 
+@pytest.mark.parametrize("fault", ["1:exit", "1:hang", "0:exit"])
+def test_bench_with_a_lost_rank_still_prints_one_json_line(fault):
+    """the first real N > 1 run must not be able to end in silence.  One of two self-spawned ranks dies (or
+    stalls for ever) in front of the rendezvous: within the deadline the plain process prints exactly ONE JSON line -- `error`,
+    `value` null, the preflight of the node -- and returns non-zero; nothing is left running."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ, TINYMPC_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TINYMPC_BENCH_FAULT=fault)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-regimes",
+                        "--min-seconds", "0.05", "--batch", "8192", "--dist-timeout", "20", "--run-timeout", "60"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert time.time() - t0 < 120
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["error"] and d["n_gpus"] == 2 and d["preflight"]["gpus_visible"] >= 1
+    assert d["metric"].startswith("QP solves/sec") and d["steps"] == 20
+
+
 def test_bench_line_carries_the_other_configs_and_honest_hbm_fields():
     """the 1-GPU line holds `configs` (BASELINE configs 3, 4 and six sweep cells, each with a
     roofline that recomputes from its own fields), `regimes` with hbm_frac from the bytes really moved next to the formula
@@ -122,13 +146,23 @@ def test_bench_line_carries_the_other_configs_and_honest_hbm_fields():
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["launcher"] == "plain process"
     assert d["roofline"]["traffic_source"] is None or "traffic.json" in d["roofline"]["traffic_source"]
     cf = d["configs"]
-    assert set(cf) == {"config3", "config4", "sweep_4_2_10", "sweep_12_4_30", "sweep_4_2_50", "sweep_12_8_30", "sweep_20_8_10", "sweep_20_8_50"}
+    assert set(cf) == {"config3", "config4", "config4_state_cone", "config4_both_cones", "sweep_4_2_10", "sweep_12_4_30", "sweep_4_2_50",
+                       "sweep_12_8_30", "sweep_20_8_10", "sweep_20_8_50"}
     for name, e in cf.items():
         assert "error" not in e and "skipped" not in e, (name, e)
         r = e["roofline"]
+        # every entry is as checkable as the headline: the fraction recomputes from the entry's own fields, `ms` is
+        # the median of its repetitions, a sample of its own records agrees with the oracle, the reference was timed on the same records
         assert abs(r["frac"] - e["iters"] * r["flops_per_iter"] / (e["ms"] * 1e-3) / (r["peak"] * 1e12)) < 1e-12 + 1e-9 * r["frac"], name
         assert abs(e["solves_per_s"] - e["solves"] / (e["ms"] * 1e-3)) < 1e-6 * e["solves_per_s"]
+        assert e["ms_min"] <= e["ms"] <= e["ms_max"] and e["timed_repetitions"] >= 3, name
+        ps = e["parity_sample"]
+        assert ps["iteration_count_mismatches"] == 0 and ps["iter_sum_gpu"] == ps["iter_sum_oracle"] and ps["instances"] >= 200, (name, ps)
+        assert ps["max_rel_err_u0"] < 1e-5, (name, ps)                     # BASELINE's tolerance; the suite's own bar (1e-9) is in test_gpu_parity.py
+        cb = e["cpu_baseline"]
+        assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "QP solves/s", (name, cb)
     assert cf["config3"]["solves"] == 262144 and cf["config4"]["solves"] == 65536 * 90 and cf["sweep_20_8_50"]["kernel"] == "tile"
+    assert cf["config4_both_cones"]["en_state_soc"] == 1 and cf["config4_both_cones"]["en_input_soc"] == 1
     rg = d["regimes"]
     for k in ("steady_state", "steady_state_per_instance_refs", "steady_state_no_primal_store", "steady_state_first_knot_store"):
         assert rg[k]["bytes_moved_per_solve"] <= rg[k]["algorithmic_bytes_per_solve"] and rg[k]["hbm_frac"] <= rg[k]["hbm_frac_formula"] + 1e-12

@@ -1,46 +1,69 @@
-"""The other BASELINE configs as entries of bench.py's one JSON line: after the timed region of
-config 2, rank 0 of a 1-GPU run times -- untimed by the headline, HIP events on the solver's stream --
+"""The other BASELINE configs as entries of bench.py's one JSON line: after the timed region of config 2, rank 0 of a 1-GPU run
+times -- untimed by the headline, HIP events on the solver's stream --
 
-  config3   quadrotor_tracking (12,4,10) x 262 144, per-instance random references (SURVEY.md 8(d) recipe), ONE cold solve
-            (reference workload: examples/quadrotor_tracking.cpp:77-106)
-  config4   rocket_landing (6,3,10) x 65 536, input second-order cone on, the 90-step closed loop fused into one launch
-            (examples/rocket_landing_mpc.cpp:94-135)
-  sweep_*   six cells of the config-5 sweep x 131 072, one cold solve each (tools/sweep_bench.py runs all 36)
+  config3          quadrotor_tracking (12,4,10) x 262 144, per-instance random references (SURVEY.md 8(d) recipe), ONE cold solve
+                   (reference workload: examples/quadrotor_tracking.cpp:77-106)
+  config4          rocket_landing (6,3,10) x 65 536, input second-order cone on, the 90-step closed loop fused into one launch
+                   (examples/rocket_landing_mpc.cpp:94-135)
+  config4_state_cone / config4_both_cones   the same episode with en_state_soc = 1 / both switches on (the example passes both
+                   cone sets, rocket_landing_mpc.cpp:94; admm.cpp:102-122)
+  sweep_*          six cells of the config-5 sweep x 131 072, one cold solve each (tools/sweep_bench.py runs all 36)
 
-Every entry carries what its roofline fraction is made of: frac == iters * flops_per_iter / (ms * 1e-3) / (peak * 1e12).
+Every entry carries what its roofline fraction is made of -- frac == iters * flops_per_iter / (ms * 1e-3) / (peak * 1e12), `ms` the
+MEDIAN of its timed repetitions (`ms_min` beside it) -- and leaves a SAMPLE of its own input records + what the GPU computed for
+them (SAMPLE instances, evenly spaced through the batch) for the checker that runs after the GPU legs (oracle/config_check.py, in
+processes of its own): `parity_sample` (iteration counts and u[:,0] against the oracle) and `cpu_baseline` (the real reference timed
+on the same records) are merged into the entry by bench.py.  This module itself never touches oracle/.
 The inputs are the recipes of tools/config_bench.py / tools/sweep_bench.py (same seeds); the reference / initial-state
 arrays are expanded along the horizon ON the device (torch) instead of being built as GB-sized host arrays.
 """
+import json
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import tinympc_amd as tm  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0
 SWEEP_CELLS = ((4, 2, 10), (12, 4, 30), (4, 2, 50), (12, 8, 30), (20, 8, 10), (20, 8, 50))
+SAMPLE = 256
 
 
-def _entry(workload, ms, solves, iters, nx, nu, N, bytes_per_solve, kernel, **extra):
+def _traffic(name):
+    """HBM bytes per launch of this entry's kernel from a committed rocprofv3 PMC run, when profiles/ holds one"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("configs", {}).get(name)
+        return t
+    except Exception:                                   # noqa: BLE001
+        return None
+
+
+def _entry(name, workload, ms_all, solves, iters, nx, nu, N, bytes_per_solve, kernel, **extra):
     fl = tm.flops_per_iter(nx, nu, N)
+    ms = float(np.median(ms_all))
     t = ms * 1e-3
     tf = iters * fl / t / 1e12
-    e = dict(workload=workload, kernel=kernel, ms=ms, solves=int(solves), iters=int(iters), solves_per_s=solves / t, iters_per_s=iters / t,
+    e = dict(workload=workload, kernel=kernel, ms=ms, ms_min=float(np.min(ms_all)), ms_max=float(np.max(ms_all)), timed_repetitions=len(ms_all),
+             solves=int(solves), iters=int(iters), solves_per_s=solves / t, iters_per_s=iters / t,
              iters_per_solve=iters / solves,
              roofline=dict(bound="fp64-valu", frac=tf / FP64_PEAK_TFLOPS, achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                            flops_per_iter=fl, flops=iters * fl,
-                           note="frac = iters x flops_per_iter / (ms x 1e-3) / (peak x 1e12); flops_per_iter = SURVEY.md 8 footnote 1 (box iteration)"),
+                           note="frac = iters x flops_per_iter / (ms x 1e-3) / (peak x 1e12), ms = the median repetition; flops_per_iter = SURVEY.md 8 footnote 1 (box iteration)"),
              hbm=dict(algorithmic_bytes_per_solve=int(bytes_per_solve), gbs=bytes_per_solve * solves / t / 1e9,
                       frac_formula=bytes_per_solve * solves / t / 1e9 / HBM_PEAK_GBS))
+    tr = _traffic(name)
+    if tr is not None:
+        e["traffic"] = tr
     e.update(extra)
     return e
 
 
-def _cold_solves(s, n, stream_sync=True):
+def _cold_solves(s, n):
     """n cold solves of the batch as it stands (reset -> solve), kernel time of each from HIP events on the solver's stream"""
     ms = []
     for _ in range(n):
@@ -51,8 +74,15 @@ def _cold_solves(s, n, stream_sync=True):
     return ms
 
 
+def _sample_idx(B):
+    return np.unique(np.linspace(0, B - 1, SAMPLE).astype(np.int64))
+
+
+def _prob_plain(prob):
+    return {k: (np.asarray(v) if isinstance(v, (list, np.ndarray)) else v) for k, v in prob.items()}
+
+
 def config3(B=262144, device=0):
-    import torch
     prob, extra = tm.load_problem("quadrotor_20hz")
     nx, nu, N = prob["nx"], prob["nu"], prob["N"]
     traj = np.array(extra["y_axis_line"])
@@ -69,24 +99,30 @@ def config3(B=262144, device=0):
     s.set_u_ref(Uref)
     s.set_x0(x0)
     s.set_option("repack_after", 0)                   # the plain launch
-    plain = min(_cold_solves(s, 3))
+    plain = _cold_solves(s, 3)
     st = s.reduce_stats()
     s.set_option("repack_after", -1)                  # the default: automatic split (histogram -> K, kept if the clock confirms it)
-    auto = _cold_solves(s, 14)                        # (the first six settle the launch form: plain / split probes, stage schedule, tile alternative)
+    auto = _cold_solves(s, 17)                        # (the first six settle the launch form: plain / split probes, stage schedule, tile alternative)
     st2 = s.reduce_stats()
     assert st2[0] == st[0] and st2[1] == st[1], "the split solve must reproduce the plain one"
-    best = min(min(auto[6:]), plain)
-    e = _entry("quadrotor_tracking (12,4,10) x %d, per-instance random Xref/Uref, one cold solve (BASELINE configs[2])" % B,
-               best, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(),
-               plain_launch_ms=plain, automatic_split_ms=min(auto[6:]), automatic_split_median_ms=float(np.median(auto[6:])), automatic_split_k=s.get_option("auto_split_k"),
-               automatic_split_growth=s.get_option("auto_split_growth"),
+    settled = auto[6:]
+    e = _entry("config3", "quadrotor_tracking (12,4,10) x %d, per-instance random Xref/Uref, one cold solve (BASELINE configs[2])" % B,
+               settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(),
+               launch_form="the library's default dispatch (automatic split solve, clock-checked), repetitions 7-17 of 17",
+               plain_launch_ms=float(np.median(plain)), plain_launch_ms_min=float(np.min(plain)),
+               automatic_split_k=s.get_option("auto_split_k"), automatic_split_growth=s.get_option("auto_split_growth"),
                automatic_split_verdict=s.get_option("auto_split_verdict"), solved_fraction=st[1] / B)
+    idx = _sample_idx(B)
+    stt = s.status()
+    it = np.where(stt["solved"][idx] != 0, stt["iter"][idx], -stt["iter"][idx])
+    spec = dict(name="config3", kind="single", problem=_prob_plain(prob),
+                cfg_kw=dict(max_iter=100, x_min=np.full((nx, 1), -5.0), x_max=np.full((nx, 1), 5.0), u_min=np.full((nu, 1), -0.5), u_max=np.full((nu, 1), 0.5)),
+                x0=x0[idx], Xref=Xref[idx], Uref=Uref[idx], gpu_iter=it.astype(np.int32), gpu_u0=s.get("u")[idx][:, :, 0])
     s.close()
-    del torch
-    return e
+    return e, spec
 
 
-def config4(B=65536, device=0):
+def config4(B=65536, device=0, en_state_soc=0, en_input_soc=1, name="config4"):
     prob, extra = tm.load_problem("rocket_landing_20hz")
     m = extra["mpc"]
     nx, nu, N = prob["nx"], prob["nu"], prob["N"]
@@ -98,31 +134,45 @@ def config4(B=65536, device=0):
     s.set_bound_constraints(np.array(m["x_min"]), np.array(m["x_max"]), np.full((nu, 1), m["u_min"]), np.full((nu, 1), m["u_max"]))
     s.set_cone_constraints(m["state_cone"]["A"], m["state_cone"]["q"], m["state_cone"]["c"],
                            m["input_cone"]["A"], m["input_cone"]["q"], m["input_cone"]["c"])
-    s.update_settings(abs_pri_tol=m["abs_pri_tol"], max_iter=m["max_iter"], en_input_soc=1)
+    s.update_settings(abs_pri_tol=m["abs_pri_tol"], max_iter=m["max_iter"], en_state_soc=en_state_soc, en_input_soc=en_input_soc)
     uref = np.zeros((nu, N - 1)); uref[2, :] = m["uref_z"]
     steps = m["NTOTAL"] - N
     s.set_option("advance_x0", 1)
     s.set_option("steps_per_launch", steps)
-    ms, st = [], None
-    for _ in range(3):
+
+    def episode(log):
         s.reset()
         s.set_u_ref(uref, broadcast=True)
         s.set_reference_trajectory(traj)              # examples/rocket_landing_mpc.cpp:111-113 (window k .. k+N-1)
         s.set_x0(x0)
+        s.set_option("step_log", log)
         s.set_option("timing", 1)
         s.solve_async()
-        ms.append(float(np.sum(s.timing_ms())))
+        return float(np.sum(s.timing_ms()))
+    ms, st = [], None
+    for _ in range(5):
+        ms.append(episode(0))
         st = s.reduce_stats()
     S = nx * N + nu * (N - 1)
-    e = _entry("rocket_landing (6,3,10) x %d, input second-order cone on, %d-step closed loop fused into one launch (BASELINE configs[3])" % (B, steps),
-               min(ms), B * steps, st[7], nx, nu, N, s.algorithmic_bytes() + 8 * 3 * nu * (N - 1), s.kernel_path(),
-               solved_fraction=st[8] / (B * steps), mpc_steps_per_launch=steps,
+    cones = "input second-order cone on" if (en_input_soc and not en_state_soc) else ("state second-order cone on" if not en_input_soc else "state AND input second-order cones on")
+    e = _entry(name, "rocket_landing (6,3,10) x %d, %s, %d-step closed loop fused into one launch (BASELINE configs[3])" % (B, cones, steps),
+               ms, B * steps, st[7], nx, nu, N, s.algorithmic_bytes() + 8 * 3 * nu * (N - 1), s.kernel_path(),
+               solved_fraction=st[8] / (B * steps), mpc_steps_per_launch=steps, en_state_soc=en_state_soc, en_input_soc=en_input_soc,
                note="flops_per_iter counts the box iteration only (the cone projection's sqrt / divisions are extra work, not extra credit); "
                     "bytes: bytes_warm + the cone slack records, once per LAUNCH (S = %d)" % S)
     e["hbm"]["gbs"] /= steps                           # the records move once per launch, not once per fused step
     e["hbm"]["frac_formula"] /= steps
+    episode(1)                                         # untimed: the same episode once more with the per-step log on, for the checker
+    idx = _sample_idx(B)
+    it, u0 = s.step_log(steps)
+    spec = dict(name=name, kind="episode", problem=_prob_plain(prob), steps=steps, traj=traj,
+                cfg_kw=dict(max_iter=m["max_iter"], abs_pri_tol=m["abs_pri_tol"], x_min=np.array(m["x_min"]), x_max=np.array(m["x_max"]),
+                            u_min=np.full((nu, 1), m["u_min"]), u_max=np.full((nu, 1), m["u_max"]), en_state_soc=en_state_soc, en_input_soc=en_input_soc,
+                            state_cone=(m["state_cone"]["A"], m["state_cone"]["q"], m["state_cone"]["c"]),
+                            input_cone=(m["input_cone"]["A"], m["input_cone"]["q"], m["input_cone"]["c"])),
+                x0=x0[idx], Xref=np.zeros((nx, N)), Uref=uref, gpu_iter=it[:, idx].astype(np.int32), gpu_u0=u0[:, idx, :])
     s.close()
-    return e
+    return e, spec
 
 
 def sweep_cell(nx, nu, N, B=131072, device=0):
@@ -142,20 +192,33 @@ def sweep_cell(nx, nu, N, B=131072, device=0):
     s.synchronize()
     del xr_d
     # (a shape the one-row kernel holds settles its launch form over the first solves: plain, split, the tile kernel's dynamic form)
-    ms = _cold_solves(s, 3 if s.kernel_path() == "tile" else 8)
+    tile = s.kernel_path() == "tile"
+    ms = _cold_solves(s, 4 if tile else 11)
+    settled = ms[1:] if tile else ms[6:]
     st = s.reduce_stats()
-    e = _entry("random sweep cell (nx=%d, nu=%d, N=%d) x %d, one cold solve, max_iter 500 (BASELINE configs[4])" % (nx, nu, N, B),
-               min(ms), B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B,
+    name = "sweep_%d_%d_%d" % (nx, nu, N)
+    e = _entry(name, "random sweep cell (nx=%d, nu=%d, N=%d) x %d, one cold solve, max_iter 500 (BASELINE configs[4])" % (nx, nu, N, B),
+               settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B,
                automatic_split_k=s.get_option("auto_split_k"), tile_alt_verdict=s.get_option("tile_alt_verdict"))
+    idx = _sample_idx(B)
+    stt = s.status()
+    it = np.where(stt["solved"][idx] != 0, stt["iter"][idx], -stt["iter"][idx])
+    spec = dict(name=name, kind="single", problem=_prob_plain(prob),
+                cfg_kw=dict(max_iter=500, u_min=np.full((nu, 1), -0.5), u_max=np.full((nu, 1), 0.5)),
+                x0=x0[idx], Xref=np.tile(xr[idx], (1, 1, N)), Uref=np.zeros((nu, N - 1)), gpu_iter=it.astype(np.int32), gpu_u0=s.get("u")[idx][:, :, 0])
     s.close()
-    return e
+    return e, spec
 
 
-def run_all(device=0, budget_s=30.0, log=None):
+def run_all(device=0, budget_s=45.0, log=None, spec_out=None):
     """-> {"config3": ..., "config4": ..., "sweep_4_2_10": ...}; an entry that fails is reported as {"error": ...}, entries that
-    would start after the budget is spent as {"skipped": ...} (the bench line must appear whatever happens here)"""
-    out, t0 = {}, time.perf_counter()
-    jobs = [("config3", lambda: config3(device=device)), ("config4", lambda: config4(device=device))]
+    would start after the budget is spent as {"skipped": ...} (the bench line must appear whatever happens here).  spec_out: where
+    the samples for oracle/config_check.py are pickled."""
+    import pickle
+    out, specs, t0 = {}, [], time.perf_counter()
+    jobs = [("config3", lambda: config3(device=device)), ("config4", lambda: config4(device=device)),
+            ("config4_state_cone", lambda: config4(device=device, en_state_soc=1, en_input_soc=0, name="config4_state_cone")),
+            ("config4_both_cones", lambda: config4(device=device, en_state_soc=1, en_input_soc=1, name="config4_both_cones"))]
     jobs += [("sweep_%d_%d_%d" % c, (lambda c=c: sweep_cell(*c, device=device))) for c in SWEEP_CELLS]
     for name, fn in jobs:
         if time.perf_counter() - t0 > budget_s:
@@ -163,15 +226,18 @@ def run_all(device=0, budget_s=30.0, log=None):
             continue
         t1 = time.perf_counter()
         try:
-            out[name] = fn()
+            out[name], spec = fn()
+            specs.append(spec)
             out[name]["wall_s_incl_setup"] = time.perf_counter() - t1
         except Exception as e:                         # noqa: BLE001
             out[name] = {"error": repr(e)}
         if log:
             log("configs: %s done in %.1f s" % (name, time.perf_counter() - t1))
+    if spec_out and specs:
+        with open(spec_out, "wb") as f:
+            pickle.dump(specs, f)
     return out
 
 
 if __name__ == "__main__":
-    import json
     print(json.dumps(run_all(log=lambda m: print(m, file=sys.stderr)), indent=1))
