@@ -219,7 +219,7 @@ def test_dropin_example_setup_output_matches_reference(ex):
 def test_headline_kernel_register_budget():
     """The quadrotor instantiation of the one-row kernel must stay at two waves per SIMD without scratch (a feature
     added to the shared template once pushed it to 256 VGPRs + 236 B of scratch unnoticed)."""
-    src = os.path.join(ROOT, "tinympc_amd", "csrc", "_gen", "k_12_4_10.hip")
+    src = os.path.join(ROOT, "tinympc_amd", "csrc", "_gen", "u_12_4_10.hip")
     if not os.path.exists(src):
         pytest.skip("library not built through the Makefile")
     p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -232,6 +232,23 @@ def test_headline_kernel_register_budget():
     assert len(head) == 2, [b[0] for b in blocks][:4]
     for _, vgpr, agpr, scratch, occ in head:
         assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, head
+
+
+def test_cone_kernel_register_budget():
+    """the rocket instantiation of the cone variant -- its slack lives in LDS planes since round 4 -- runs two
+    waves per SIMD WITHOUT scratch, in the per-knot-box form and in the knot-invariant one (UB) config 4 launches."""
+    src = os.path.join(ROOT, "tinympc_amd", "csrc", "_gen", "u_6_3_10.hip")
+    if not os.path.exists(src):
+        pytest.skip("library not built through the Makefile")
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
+                        p.stderr, re.S)
+    cone = [b for b in blocks if "ILi6ELi3ELi10ELb1ELb0ELi2ELi0ELb0ELi4ELb0ELb0EE" in b[0] or "ILi6ELi3ELi10ELb1ELb0ELi2ELi0ELb0ELi4ELb0ELb1EE" in b[0]]
+    assert len(cone) == 2, [b[0] for b in blocks][:6]
+    for _, vgpr, agpr, scratch, occ in cone:
+        assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, cone
 
 
 def test_header_is_plain_c_and_links(tmp_path):

@@ -473,7 +473,10 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
             return launch_solve(b);
         }
     }
-    if (b->tab_dirty || b->h_ttab.empty()) {
+    // the tile tables follow the problem's generation, not the one-row path's dirty flag: a one-row shape whose clock-decided
+    // dispatch keeps the tile form launches it from INSIDE path 0, after upload_tables() has cleared tab_dirty
+    if (b->ttab_gen != b->tab_gen || b->h_ttab.empty()) {
+        b->ttab_gen = b->tab_gen;
         if (b->tile->W <= 1) build_tile_tables_w<1>(b); else build_tile_tables_w<2>(b);      // (W = 0, half rows, reads the one-row tables)
         if (b->ttab_doubles < b->h_ttab.size()) {
             if (b->d_ttab) (void)hipFree(b->d_ttab);
@@ -926,6 +929,7 @@ int launch_solve(TinyBatch* b) {
     // solve saved (the first solve after a reset: BASELINE configs 3 and 5, every cold start).  Any launch ends that knowledge.
     const bool zero_state = b->records_zero;
     b->records_zero = false;
+    if (b->tab_dirty) b->tab_gen++;                  // something the tables are built from has changed since the last launch
     if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
         return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
     if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
@@ -939,7 +943,6 @@ int launch_solve(TinyBatch* b) {
         if (rc == TINY_OK) b->tab_dirty = false;
         return rc;
     }
-    b->h_ttab.clear();
     if (use_general(b)) {
         const int rc = launch_general(b);
         if (rc == TINY_OK) b->tab_dirty = false;
@@ -1090,16 +1093,19 @@ int launch_solve(TinyBatch* b) {
             if (b->tile_verdict == 1 && ++b->tile_since >= 32) {             // distributions drift: re-open both questions
                 b->tile_since = 0; b->tile_verdict = 0; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = 0.0; b->auto_since = 0;
             } else {
-                const int save_dyn = b->tile_dyn_opt, save_lm = b->tile_lm, save_r = b->tile_r;
-                b->tile_dyn_opt = 1; b->tile_lm = -1; b->tile_r = 0;         // the first entry of the shape, dynamic slots
+                // the first entry of the shape, dynamic slots -- for THIS launch: the caller's options come back on every way out
+                struct Restore {
+                    TinyBatch* b; int dyn, lm, r;
+                    ~Restore() { b->tile_dyn_opt = dyn; b->tile_lm = lm; b->tile_r = r; }
+                } restore{b, b->tile_dyn_opt, b->tile_lm, b->tile_r};
+                b->tile_dyn_opt = 1; b->tile_lm = -1; b->tile_r = 0;
                 if (probe_tile) {
                     // (what a kernel's FIRST launch pays once must not count against it: an empty launch of the same form goes first)
-                    if (int rc0 = launch_tile(b, true)) { b->tile_dyn_opt = save_dyn; b->tile_lm = save_lm; b->tile_r = save_r; return rc0; }
+                    if (int rc0 = launch_tile(b, true)) return rc0;
                     if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
                     HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
                 }
                 const int rc = launch_tile(b);
-                b->tile_dyn_opt = save_dyn; b->tile_lm = save_lm; b->tile_r = save_r;
                 if (rc != TINY_OK) return rc;
                 if (probe_tile) {
                     HIP_TRY(b, hipEventRecord(b->auto_ev1, b->stream));
@@ -1908,8 +1914,10 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
         if (b->hist_pending && hipEventSynchronize(b->hist_ev) == hipSuccess) {      // (a diagnostic may wait; a solve never does)
             b->hist_pending = false;
             b->probe_was_tile = b->probe_was_growth = false;   // (the probe's clock reading is dropped with it: the next probe starts clean)
-            b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
-            b->auto_cap_max_iter = b->set.max_iter;
+            if (b->auto_verdict == 0) {                        // (a decided batch keeps its K AND the stage schedule the clock chose)
+                b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
+                b->auto_cap_max_iter = b->set.max_iter;
+            }
         }
         return b->auto_cap;
     }

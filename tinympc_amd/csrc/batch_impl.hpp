@@ -78,6 +78,7 @@ struct TinyBatch {
     size_t stage_doubles = 0;
     std::vector<double> h_tab;
     bool tab_dirty = true;
+    unsigned tab_gen = 1, ttab_gen = 0;          // generation of the problem data (bumped by the first launch that sees tab_dirty) / the one h_ttab was built from
     int last_path = -1;
     // options
     bool advance_x0 = false, debug = false;

@@ -38,3 +38,12 @@ struct TileEntry {
         tinympc_amd::admm_solve_kernel<NX, NU, NN, false, true, 2, 0, false, tinympc_amd::LIN_KMAX, true> },  \
       tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>,         \
       tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true> }
+// the LEAN set of a shape that only the sweep of BASELINE configs[4] asks for: the box kernel in its two bound forms; its cone /
+// half-space / per-instance-data / adaptive / debug / dpp-mode variants are instantiated at run time on first use (jit.hip) --
+// compiled in, every one of them cost build time and library size for launches nobody has measured
+#define KERNELS_LEAN(NX, NU, NN)                                                                  \
+    { NX, NU, NN, { { { nullptr, nullptr, tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2> }, { nullptr, nullptr, nullptr } },   \
+                    { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } } },                       \
+      { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } },                     \
+      { nullptr, nullptr }, { nullptr, nullptr },                                                             \
+      tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>, nullptr }

@@ -406,7 +406,13 @@ void admm_tile_kernel(const SolveArgs P) {
                     if (iter == 0) {                                   // a solve's first iteration: v|z of the solve before, from its record, into
                         __builtin_amdgcn_s_waitcnt(0);                 // the vnew|znew registers (dead behind the backward sweep)
 #pragma unroll
-                        for (int l = 0; l < L; ++l) VN[l] = (l == 0 ? vpp0 : vpp)[l * NZ];     // (lanes without a row read the zero pad)
+                        for (int l = 0; l < L; ++l) {
+                            // lanes without a row (and the input lanes' dummy slot 0) point at the pad behind the records, which EVERY
+                            // instance's such lanes stream into: whatever it holds -- the non-finite leftovers of a diverged instance
+                            // included -- is not taken (once per solve: the select costs nothing in the iteration)
+                            const double vz = (l == 0 ? vpp0 : vpp)[l * NZ];
+                            VN[l] = (jj >= NZ || (l == 0 && hrow == 0 && is_input)) ? 0.0 : vz;
+                        }
                     }
                 }
                 // ---- forward_pass (admm.cpp:25-32) + slot updates, first row first

@@ -12,7 +12,7 @@ os.makedirs(TMP + "/_gen")
 for f in os.listdir(SRC):
     if f.endswith((".h", ".hpp", ".hip")):
         shutil.copy(os.path.join(SRC, f), TMP)
-shutil.copy(os.path.join(SRC, "_gen", "k_12_4_10.hip"), TMP + "/_gen")
+shutil.copy(os.path.join(SRC, "_gen", "u_12_4_10.hip"), TMP + "/_gen")
 p = TMP + "/admm_kernel.hip.h"
 s = open(p).read()
 def rep(a, b):
@@ -35,8 +35,8 @@ rep("                double4 rr = make_double4(ps, pi, ds, di);",
     "                double4 rr = make_double4((double)(clk_pro - clk_entry), (double)(c1 - c0), (double)(c2 - c1), (double)(c3 - c2));")
 open(p, "w").write(s)
 flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-but-set-variable -Wno-unused-variable".split()
-subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", TMP + "/_gen/k_12_4_10.hip", "-o", TMP + "/k_clk.o"])
-objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != "k_12_4_10.o" and "_chk" not in f]
+subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", TMP + "/_gen/u_12_4_10.hip", "-o", TMP + "/k_clk.o"])
+objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != "u_12_4_10.o" and "_chk" not in f]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-Wl,-Bsymbolic", "-o",
                        os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_clk.so"), *objs, TMP + "/k_clk.o", "-ldl"])
 print("built libtinympc_amd_clk.so")

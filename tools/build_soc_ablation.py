@@ -16,15 +16,15 @@ def build(tag, patches):
     for f in os.listdir(SRC):
         if f.endswith((".h", ".hpp", ".hip")):
             shutil.copy(os.path.join(SRC, f), tmp)
-    shutil.copy(os.path.join(SRC, "_gen", "k_6_3_10.hip"), tmp + "/_gen")
+    shutil.copy(os.path.join(SRC, "_gen", "u_6_3_10.hip"), tmp + "/_gen")
     p = tmp + "/admm_kernel.hip.h"
     s = open(p).read()
     for a, b in patches:
         assert a in s, a
         s = s.replace(a, b)
     open(p, "w").write(s)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-c", tmp + "/_gen/k_6_3_10.hip", "-o", tmp + "/k.o"])
-    objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != "k_6_3_10.o" and "_chk" not in f]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-c", tmp + "/_gen/u_6_3_10.hip", "-o", tmp + "/k.o"])
+    objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != "u_6_3_10.o" and "_chk" not in f]
     out = os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_%s.so" % tag)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-Wl,-Bsymbolic", "-o", out, *objs, tmp + "/k.o", "-ldl"])
     print("built", out)

@@ -30,19 +30,19 @@ SOCCLK = [
      "            const double ps = rp, pi = rd, ds = rc_, di = rt_;\n"),
 ]
 VARIANTS = {
-    "prim0": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=0"], []),
-    "ref0": ("k_12_4_10", ["-DTINYMPC_REF_LOAD=0"], []),
-    "prim1": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=1"], []),
-    "prim2": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=2"], []),
-    "prim3": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
-    "prim4": ("k_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
-    "socclk": ("k_6_3_10", [], SOCCLK),
+    "prim0": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=0"], []),
+    "ref0": ("u_12_4_10", ["-DTINYMPC_REF_LOAD=0"], []),
+    "prim1": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=1"], []),
+    "prim2": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=2"], []),
+    "prim3": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
+    "prim4": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
+    "socclk": ("u_6_3_10", [], SOCCLK),
     # timing-only ablations of the cone kernel (results are WRONG by construction)
-    "abl_fwd_nogc": ("k_6_3_10", [], [("gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC];", "gr[(i + 2) % 3] = 0.0;"),
+    "abl_fwd_nogc": ("u_6_3_10", [], [("gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC];", "gr[(i + 2) % 3] = 0.0;"),
                                      ("                        gr[0] = sC[cw + PL_GC];\n                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];\n",
                                       "                        gr[0] = 0.0; gr[1] = 0.0;\n")]),
-    "abl_bwd_now": ("k_6_3_10", [], [("if (i >= 2) wr[(i - 2) % 3] = sC[cw + (i - 2) * SLOT_D];", "if (i >= 2) wr[(i - 2) % 3] = 0.0;")]),
-    "abl_nopass": ("k_6_3_10", [], [("                            if (p > 0 && p >= soc_passes) break;            // wave-uniform\n", "                            break;\n")]),
+    "abl_bwd_now": ("u_6_3_10", [], [("if (i >= 2) wr[(i - 2) % 3] = sC[cw + (i - 2) * SLOT_D];", "if (i >= 2) wr[(i - 2) % 3] = 0.0;")]),
+    "abl_nopass": ("u_6_3_10", [], [("                            if (p > 0 && p >= soc_passes) break;            // wave-uniform\n", "                            break;\n")]),
 }
 
 

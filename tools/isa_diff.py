@@ -20,7 +20,7 @@ HEADERS = ("admm_kernel.hip.h", "kernel_entry.hpp", "tile_kernel.hip.h")
 def assemble(srcdir, dims, out):
     gen = os.path.join(srcdir, "_gen")
     os.makedirs(gen, exist_ok=True)
-    name = "k_%d_%d_%d" % dims
+    name = "u_%d_%d_%d" % dims
     with open(os.path.join(gen, name + ".hip"), "w") as f:
         f.write("#define TINYMPC_FUSED_NX %d\n#define TINYMPC_FUSED_NU %d\n" % dims[:2])      # as csrc/Makefile writes the unit
         f.write('#include "../kernel_entry.hpp"\n')

@@ -29,7 +29,7 @@ def usage(src):
 
 
 def main():
-    srcs = sorted(glob.glob(os.path.join(GEN, "k_*.hip")) + glob.glob(os.path.join(GEN, "t_*.hip")))
+    srcs = sorted(glob.glob(os.path.join(GEN, "u_*.hip")))
     if not srcs:
         sys.exit("build the library first (tinympc_amd/csrc/_gen is empty)")
     with concurrent.futures.ThreadPoolExecutor(8) as ex:
