@@ -81,5 +81,6 @@ def run_cases_hip(suite, replicate=1, debug=False, options=None):
     out["sol_x"], out["sol_u"] = out["vnew"], out["znew"]          # solution = slack (admm.cpp:436-437)
     out["batch_ret"] = ret
     out["tile_form"] = s.get_option("last_tile_form") if s.kernel_path() == "tile" else -1     # (W, R, LM) of the tile_dims.txt entry that ran
+    out["half_rows"] = s.get_option("last_half_rows")         # 1: the one-row kernel's HALF form (two instances per DPP row) ran
     s.close()
     return out

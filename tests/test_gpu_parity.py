@@ -157,6 +157,70 @@ def test_half_row_form_matches_oracle(dims, dyn):
     assert_match(run_cases_hip(warm, options=opts), sc.run_cases(OracleSolver, warm), RTOL, f"half rows warm {dims}")
 
 
+@pytest.mark.parametrize("dims", [(4, 2, 10), (4, 4, 10), (2, 2, 3), (4, 2, 30)])
+def test_one_row_kernel_half_rows_match_the_oracle_and_the_full_row_form(dims):
+    """Round 4: shapes with nx+nu <= 8 run TWO instances per DPP row on the one-row kernel itself (HALF: eight per wave, every column
+    of a mat-vec a pair of bank-masked FMAs inside the fused step blocks).  Ragged batch (37 = 4 full waves + 5), cold, warm and
+    out-of-iterations solves against the oracle, and bit for bit against the one-instance-per-row form (option half_rows = 0)."""
+    suite = sc.sweep_suite(*dims, B=37, max_iter=300)
+    base = {"no_tile": 1, "repack_after": 0}
+    ref = sc.run_cases(OracleSolver, suite)
+    half = run_cases_hip(suite, options=dict(base, half_rows=1))
+    full = run_cases_hip(suite, options=dict(base, half_rows=0))
+    assert half["half_rows"] == 1 and full["half_rows"] == 0
+    assert_match(half, ref, RTOL, f"one-row half rows {dims}")
+    for k in ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z", "primal_residual_state", "dual_residual_input"):
+        assert np.array_equal(half[k], full[k]), (k, dims)
+    warm = dict(problem=suite["problem"], config=dict(suite["config"], max_iter=6), cases=dict(suite["cases"]))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        warm["cases"][k] = ref[k]
+    warm["cases"]["x0"] = suite["cases"]["x0"] * 0.7
+    wref = sc.run_cases(OracleSolver, warm)
+    whalf = run_cases_hip(warm, options=dict(base, half_rows=1))
+    assert whalf["half_rows"] == 1
+    assert_match(whalf, wref, RTOL, f"one-row half rows, warm {dims}")
+
+
+@pytest.mark.parametrize("dims", [(4, 2, 10), (4, 4, 10)])
+def test_one_row_kernel_half_rows_in_fused_steps_and_split_solves(dims):
+    """The HALF form under the launch modes the one-row kernel has: T closed-loop MPC steps fused into one launch against T launches,
+    and a split solve (repack_after = K: the open instances re-packed EIGHT per wave) against the plain one -- all bit for bit."""
+    T = 5
+    suite = sc.sweep_suite(*dims, B=43, max_iter=40)
+
+    def run(fused, half, repack=0):
+        s = make_batch(suite)
+        for k, v in (("no_tile", 1), ("repack_after", repack), ("half_rows", half), ("advance_x0", 1)):
+            s.set_option(k, v)
+        s.set_x0(suite["cases"]["x0"]); s.set("Xref", suite["cases"]["Xref"]); s.set("Uref", suite["cases"]["Uref"])
+        if fused:
+            s.set_option("steps_per_launch", T)
+            s.solve_async()
+        else:
+            for _ in range(T):
+                s.solve_async()
+        out = {k: s.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "x0")}
+        out["iter"] = np.asarray(s.status()["iter"])
+        out["acc"] = np.asarray(s.reduce_stats()[7:9])
+        assert s.get_option("last_half_rows") == half
+        s.close()
+        return out
+    a = run(False, 0)
+    assert a["acc"][0] > 0
+    for other in (run(False, 1), run(True, 1), run(True, 0)):
+        for k in a:
+            assert np.array_equal(a[k], other[k]), (k, dims)
+    # one cold solve, split at K = 8 (stages 8, 16, 32, 40), against the plain launch
+    def cold(half, repack):
+        o = run_cases_hip(dict(suite, config=dict(suite["config"], max_iter=120)), options={"no_tile": 1, "repack_after": repack, "half_rows": half})
+        assert o["half_rows"] == half
+        return o
+    p0, p1, s1 = cold(0, 0), cold(1, 0), cold(1, 8)
+    assert len(np.unique(p0["iter"])) > 3 and p0["iter"].max() > 16
+    for k in ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z"):
+        assert np.array_equal(p0[k], p1[k]) and np.array_equal(p0[k], s1[k]), (k, dims)
+
+
 @pytest.mark.parametrize("dims,lm,other", [((12, 2, 50), 22, 0), ((4, 2, 50), 23, 99), ((12, 4, 50), 23, 0), ((20, 4, 30), 20, 12), ((20, 8, 50), 23, 14), ((20, 8, 50), 54, 14), ((4, 4, 50), 54, 99), ((8, 2, 50), 54, 0)])
 @pytest.mark.parametrize("dyn", [0, 1])
 def test_tile_forms_that_keep_v_in_its_record_match_the_oracle(dims, lm, other, dyn):

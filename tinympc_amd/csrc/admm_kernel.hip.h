@@ -295,6 +295,47 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
 }
 
 
+// HALF rows: lanes 0-7 and 8-15 of a DPP row carry two different instances.  `row_newbcast:k` broadcasts ONE lane to the whole row, so
+// a column of the mat-vec takes two instructions, each writing one half only (bank_mask: write-enable per bank of 4 lanes; honoured by
+// the DP-ALU DPP form at no cost, tools/ubench/ubench_dpp_bankmask.hip): lanes 0-7 get lane k, lanes 8-15 get lane 8+k.  Per instance
+// that is the same number of FMA issue slots as a full row gives -- the gain is everywhere else: every lane-local instruction (the
+// slot update is 13 of the 25 instructions per slot at (4,2)) now serves twice the instances, and so does every register.
+// HARDWARE NOTE (measured, tools/ubench/ubench_dpp_bankmask2.hip; not in the LLVM hazard tables): a bank-masked DPP instruction
+// writes its DISABLED lanes back with the value of vdst it read at operand fetch ("old"), and that read is NOT interlocked against a
+// VALU write of vdst in the instruction before -- `fmac bank_mask:0x3` directly followed by `fmac bank_mask:0xc` on the same
+// accumulator loses the first one's result (the second writes the stale lanes 0-7 back).  One wait state in between is enough.
+// So a chain runs all its low-half FMAs (their enabled lanes accumulate through the interlocked src2 path; the disabled lanes keep
+// being re-written with a value that does not change), then `s_nop 0`, then all its high-half FMAs.
+#define THL_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:%2+" #k " row_mask:0xf bank_mask:0x3\n\t"
+#define THH_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:8+%2+" #k " row_mask:0xf bank_mask:0xc\n\t"
+#define THL1 THL_(3, 0)
+#define THL2 THL1 THL_(4, 1)
+#define THL3 THL2 THL_(5, 2)
+#define THL4 THL3 THL_(6, 3)
+#define THL5 THL4 THL_(7, 4)
+#define THL6 THL5 THL_(8, 5)
+#define THL7 THL6 THL_(9, 6)
+#define THL8 THL7 THL_(10, 7)
+#define THH1 THH_(3, 0)
+#define THH2 THH1 THH_(4, 1)
+#define THH3 THH2 THH_(5, 2)
+#define THH4 THH3 THH_(6, 3)
+#define THH5 THH4 THH_(7, 4)
+#define THH6 THH5 THH_(8, 5)
+#define THH7 THH6 THH_(9, 6)
+#define THH8 THH7 THH_(10, 7)
+#define RINGH_CASE(K)                                                                       \
+    if constexpr (NCOL == K) {                                                              \
+        asm("s_nop 1\n\t" THL##K "s_nop 0\n\t" THH##K : "+&v"(a0) : "v"(src), "i"(COL0), TM##K);   \
+    }
+// a0 += sum_k bcast_half(src, COL0+k) * m[k]   (each half of the row reads its OWN lanes COL0+k)
+template <int COL0, int NCOL>
+__device__ __forceinline__ void ring1_half(double& a0, double src, const double* m) {
+    static_assert(NCOL >= 1 && COL0 + NCOL <= 8, "one half row");
+    RINGH_CASE(1) RINGH_CASE(2) RINGH_CASE(3) RINGH_CASE(4) RINGH_CASE(5) RINGH_CASE(6) RINGH_CASE(7) RINGH_CASE(8)
+}
+
+
 // ---- fused sweep steps (single-chain mode, box-only variants) --------------------------------------------------------------
 // The leading `s_nop 1` of a DPP block only waits out the two wait states a DPP read needs after a VALU write of its source.
 // Here the lane-local instructions a sweep step needs anyway stand in front of the DPP chain INSIDE the same asm statement --
@@ -431,13 +472,109 @@ __device__ __forceinline__ double ring_short(double init, double src, const doub
             : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t)                               \
             : [xi] "v"(xi), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                  \
     }
+// ---- the same fused steps for HALF rows (nx+nu <= 8: two instances per DPP row, see ring1_half): every column is a pair of
+// bank-masked FMAs -- all low halves, ONE wait state (a bank-masked DPP op re-writes its disabled lanes with the vdst it read
+// without interlock), all high halves.  In the forward step the wait state between the two halves of the first chain is the
+// step's own v_min.
+#define HAL1 "v_fmac_f64_dpp %[acc], %[sa], %[a0] row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL2 HAL1 "v_fmac_f64_dpp %[acc], %[sa], %[a1] row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL3 HAL2 "v_fmac_f64_dpp %[acc], %[sa], %[a2] row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL4 HAL3 "v_fmac_f64_dpp %[acc], %[sa], %[a3] row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL5 HAL4 "v_fmac_f64_dpp %[acc], %[sa], %[a4] row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL6 HAL5 "v_fmac_f64_dpp %[acc], %[sa], %[a5] row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL7 HAL6 "v_fmac_f64_dpp %[acc], %[sa], %[a6] row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t"
+#define HAL8 HAL7 "v_fmac_f64_dpp %[acc], %[sa], %[a7] row_newbcast:7 row_mask:0xf bank_mask:0x3\n\t"
+#define HAH1 "v_fmac_f64_dpp %[acc], %[sa], %[a0] row_newbcast:8+0 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH2 HAH1 "v_fmac_f64_dpp %[acc], %[sa], %[a1] row_newbcast:8+1 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH3 HAH2 "v_fmac_f64_dpp %[acc], %[sa], %[a2] row_newbcast:8+2 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH4 HAH3 "v_fmac_f64_dpp %[acc], %[sa], %[a3] row_newbcast:8+3 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH5 HAH4 "v_fmac_f64_dpp %[acc], %[sa], %[a4] row_newbcast:8+4 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH6 HAH5 "v_fmac_f64_dpp %[acc], %[sa], %[a5] row_newbcast:8+5 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH7 HAH6 "v_fmac_f64_dpp %[acc], %[sa], %[a6] row_newbcast:8+6 row_mask:0xf bank_mask:0xc\n\t"
+#define HAH8 HAH7 "v_fmac_f64_dpp %[acc], %[sa], %[a7] row_newbcast:8+7 row_mask:0xf bank_mask:0xc\n\t"
+#define HBL1 "v_fmac_f64_dpp %[acc], %[sb], %[b0] row_newbcast:%[c0]+0 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL2 HBL1 "v_fmac_f64_dpp %[acc], %[sb], %[b1] row_newbcast:%[c0]+1 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL3 HBL2 "v_fmac_f64_dpp %[acc], %[sb], %[b2] row_newbcast:%[c0]+2 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL4 HBL3 "v_fmac_f64_dpp %[acc], %[sb], %[b3] row_newbcast:%[c0]+3 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL5 HBL4 "v_fmac_f64_dpp %[acc], %[sb], %[b4] row_newbcast:%[c0]+4 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL6 HBL5 "v_fmac_f64_dpp %[acc], %[sb], %[b5] row_newbcast:%[c0]+5 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL7 HBL6 "v_fmac_f64_dpp %[acc], %[sb], %[b6] row_newbcast:%[c0]+6 row_mask:0xf bank_mask:0x3\n\t"
+#define HBL8 HBL7 "v_fmac_f64_dpp %[acc], %[sb], %[b7] row_newbcast:%[c0]+7 row_mask:0xf bank_mask:0x3\n\t"
+#define HBH1 "v_fmac_f64_dpp %[acc], %[sb], %[b0] row_newbcast:8+%[c0]+0 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH2 HBH1 "v_fmac_f64_dpp %[acc], %[sb], %[b1] row_newbcast:8+%[c0]+1 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH3 HBH2 "v_fmac_f64_dpp %[acc], %[sb], %[b2] row_newbcast:8+%[c0]+2 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH4 HBH3 "v_fmac_f64_dpp %[acc], %[sb], %[b3] row_newbcast:8+%[c0]+3 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH5 HBH4 "v_fmac_f64_dpp %[acc], %[sb], %[b4] row_newbcast:8+%[c0]+4 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH6 HBH5 "v_fmac_f64_dpp %[acc], %[sb], %[b5] row_newbcast:8+%[c0]+5 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH7 HBH6 "v_fmac_f64_dpp %[acc], %[sb], %[b6] row_newbcast:8+%[c0]+6 row_mask:0xf bank_mask:0xc\n\t"
+#define HBH8 HBH7 "v_fmac_f64_dpp %[acc], %[sb], %[b7] row_newbcast:8+%[c0]+7 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAL1 "v_fmac_f64_dpp %[t], %[xi], %[a0] row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL2 HFAL1 "v_fmac_f64_dpp %[t], %[xi], %[a1] row_newbcast:1 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL3 HFAL2 "v_fmac_f64_dpp %[t], %[xi], %[a2] row_newbcast:2 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL4 HFAL3 "v_fmac_f64_dpp %[t], %[xi], %[a3] row_newbcast:3 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL5 HFAL4 "v_fmac_f64_dpp %[t], %[xi], %[a4] row_newbcast:4 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL6 HFAL5 "v_fmac_f64_dpp %[t], %[xi], %[a5] row_newbcast:5 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL7 HFAL6 "v_fmac_f64_dpp %[t], %[xi], %[a6] row_newbcast:6 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAL8 HFAL7 "v_fmac_f64_dpp %[t], %[xi], %[a7] row_newbcast:7 row_mask:0xf bank_mask:0x3\n\t"
+#define HFAH1 "v_fmac_f64_dpp %[t], %[xi], %[a0] row_newbcast:8+0 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH2 HFAH1 "v_fmac_f64_dpp %[t], %[xi], %[a1] row_newbcast:8+1 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH3 HFAH2 "v_fmac_f64_dpp %[t], %[xi], %[a2] row_newbcast:8+2 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH4 HFAH3 "v_fmac_f64_dpp %[t], %[xi], %[a3] row_newbcast:8+3 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH5 HFAH4 "v_fmac_f64_dpp %[t], %[xi], %[a4] row_newbcast:8+4 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH6 HFAH5 "v_fmac_f64_dpp %[t], %[xi], %[a5] row_newbcast:8+5 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH7 HFAH6 "v_fmac_f64_dpp %[t], %[xi], %[a6] row_newbcast:8+6 row_mask:0xf bank_mask:0xc\n\t"
+#define HFAH8 HFAH7 "v_fmac_f64_dpp %[t], %[xi], %[a7] row_newbcast:8+7 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBL1 "v_fmac_f64_dpp %[xn], %[t], %[b0] row_newbcast:%[c0]+0 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL2 HFBL1 "v_fmac_f64_dpp %[xn], %[t], %[b1] row_newbcast:%[c0]+1 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL3 HFBL2 "v_fmac_f64_dpp %[xn], %[t], %[b2] row_newbcast:%[c0]+2 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL4 HFBL3 "v_fmac_f64_dpp %[xn], %[t], %[b3] row_newbcast:%[c0]+3 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL5 HFBL4 "v_fmac_f64_dpp %[xn], %[t], %[b4] row_newbcast:%[c0]+4 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL6 HFBL5 "v_fmac_f64_dpp %[xn], %[t], %[b5] row_newbcast:%[c0]+5 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL7 HFBL6 "v_fmac_f64_dpp %[xn], %[t], %[b6] row_newbcast:%[c0]+6 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBL8 HFBL7 "v_fmac_f64_dpp %[xn], %[t], %[b7] row_newbcast:%[c0]+7 row_mask:0xf bank_mask:0x3\n\t"
+#define HFBH1 "v_fmac_f64_dpp %[xn], %[t], %[b0] row_newbcast:8+%[c0]+0 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH2 HFBH1 "v_fmac_f64_dpp %[xn], %[t], %[b1] row_newbcast:8+%[c0]+1 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH3 HFBH2 "v_fmac_f64_dpp %[xn], %[t], %[b2] row_newbcast:8+%[c0]+2 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH4 HFBH3 "v_fmac_f64_dpp %[xn], %[t], %[b3] row_newbcast:8+%[c0]+3 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH5 HFBH4 "v_fmac_f64_dpp %[xn], %[t], %[b4] row_newbcast:8+%[c0]+4 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH6 HFBH5 "v_fmac_f64_dpp %[xn], %[t], %[b5] row_newbcast:8+%[c0]+5 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH7 HFBH6 "v_fmac_f64_dpp %[xn], %[t], %[b6] row_newbcast:8+%[c0]+6 row_mask:0xf bank_mask:0xc\n\t"
+#define HFBH8 HFBH7 "v_fmac_f64_dpp %[xn], %[t], %[b7] row_newbcast:8+%[c0]+7 row_mask:0xf bank_mask:0xc\n\t"
+#define FUSED_HBWD_CASE(NA_, NB_) FUSED_HBWD_CASE_(NA_, NB_)
+#define FUSED_HBWD_CASE_(NA_, NB_)                                                                                      \
+    if constexpr (NA == NA_ && NB == NB_) {                                                                             \
+        asm("v_add_f64 %[tmp], %[vn], -%[g]\n\t"                                                                        \
+            "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
+            "v_fma_f64 %[acc], %[qlo], %[smask], %[cb]\n\t"                                                             \
+            "s_nop 0\n\t" HAL##NA_ HBL##NB_ "s_nop 0\n\t" HAH##NA_ HBH##NB_                                             \
+            : [qlo] "=&v"(qlo), [acc] "=&v"(acc), [tmp] "=&v"(tmp)                                                      \
+            : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
+              [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                                         \
+    }
+#define FUSED_HFWD_CASE(NA_, NB_) FUSED_HFWD_CASE_(NA_, NB_)
+#define FUSED_HFWD_CASE_(NA_, NB_)                                                                                      \
+    if constexpr (NA == NA_ && NB == NB_) {                                                                             \
+        asm("v_add_f64 %[tt], %[xi], %[g]\n\t"                                                                          \
+            "v_max_f64 %[vm], %[lo], %[tt]\n\t" HFAL##NA_                                                               \
+            "v_min_f64 %[vn], %[hi], %[vm]\n\t" HFAH##NA_                                                               \
+            "v_mov_b64 %[xn], %[t]\n\t"                                                                                 \
+            "s_nop 0\n\t" HFBL##NB_ "s_nop 0\n\t" HFBH##NB_                                                             \
+            : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t)                               \
+            : [xi] "v"(xi), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                  \
+    }
 // One (nx, nu) pair per translation unit: the Makefile (compiled-in shapes) and jit.hip (run-time instantiated ones) define
 // TINYMPC_FUSED_NX / _NU as plain numbers in front of this header, so that exactly one pair of asm statements is spelled out.
 #if defined(TINYMPC_FUSED_NX) && defined(TINYMPC_FUSED_NU)
 #define FUSED_SHAPES(CASE) CASE(TINYMPC_FUSED_NX, TINYMPC_FUSED_NU)
 constexpr bool fused_shape(int na, int nb) { return na == TINYMPC_FUSED_NX && nb == TINYMPC_FUSED_NU; }
+#if TINYMPC_FUSED_NX + TINYMPC_FUSED_NU <= 8
+#define FUSED_HALF_SHAPES(CASE) CASE(TINYMPC_FUSED_NX, TINYMPC_FUSED_NU)
+#else
+#define FUSED_HALF_SHAPES(CASE)
+#endif
 #else
 #define FUSED_SHAPES(CASE)
+#define FUSED_HALF_SHAPES(CASE)
 constexpr bool fused_shape(int, int) { return false; }
 #endif
 // backward step: qlo = fma(-rho, vn - g, qx); acc = fma(qlo, smask, cb) + sum_k bcast(sa, k) ma[k] + sum_k bcast(sb, NA + k) mb_[k]
@@ -454,6 +591,21 @@ __device__ __forceinline__ void fused_backward_step_soc(double& qlo, double& acc
     double tmp;
     FUSED_SHAPES(FUSED_BWD_SOC_CASE)
     (void)tmp;
+}
+// the half-row forms of the two (NA + NB <= 8)
+template <int NA, int NB>
+__device__ __forceinline__ void fused_backward_step_half(double& qlo, double& acc, double vn, double g, double qx, double rho, double smask, double cb,
+                                                         double sa, double sb, const double* ma, const double* mb_) {
+    double tmp;
+    FUSED_HALF_SHAPES(FUSED_HBWD_CASE)
+    (void)tmp;
+}
+template <int NA, int NB>
+__device__ __forceinline__ void fused_forward_step_half(double& tt, double& vn, double& t, double& xn, double xi, double g, double lo, double hi,
+                                                        const double* ma, const double* mb_) {
+    double vm;
+    FUSED_HALF_SHAPES(FUSED_HFWD_CASE)
+    (void)vm;
 }
 // forward step: tt = xi + g; vn = min(hi, max(lo, tt)); t += sum_k bcast(xi, k) ma[k]; xn = t + sum_k bcast(t, NA + k) mb_[k]
 template <int NA, int NB>
@@ -526,6 +678,12 @@ __device__ __forceinline__ void store_primal(double* p, double v) {
 __device__ __forceinline__ double grp_max16(double v) {
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 16));
+    return v;
+}
+template <int W>
+__device__ __forceinline__ double grp_maxw(double v) {                 // max over the W (8 | 16) lanes of an instance
+#pragma unroll
+    for (int off = W / 2; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, W));
     return v;
 }
 
@@ -626,7 +784,9 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc, bool lin = fa
 // ADAPT: adaptive rho (admm.cpp:397-423): per-instance rho / Kinf / Pinf, re-estimated every 5th iteration
 // UB: the box is the same at every knot (the usual case: constant state / input limits): the two bounds of a lane live in
 // registers instead of being read from LDS slot by slot -- 18 LDS reads and as many waits less per iteration at N = 10
-template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false>
+// HALF: nx+nu <= 8 -- TWO instances per DPP row (lanes 0-7 | 8-15), eight per wave: every lane-local instruction and every register
+// serves twice the instances; a mat-vec column is a pair of bank-masked FMAs (fused_*_step_half).  Plain box variants only.
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false, bool HALF = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(solve_kernel_waves_per_simd(NX + NU, N, SOC, LIN != 0, ADAPT), solve_kernel_waves_per_simd(NX + NU, N, SOC, LIN != 0, ADAPT))))
 void admm_solve_kernel(const SolveArgs P) {
@@ -634,9 +794,13 @@ void admm_solve_kernel(const SolveArgs P) {
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
     constexpr bool FUSED = MODE == 2 && LIN == 0 && fused_shape(NX, NU);              // fused_backward_step(_soc) / fused_forward_step
+    static_assert(!HALF || (NZ <= 8 && FUSED && !SOC && !DBG && !HET && !ADAPT), "half rows: nx+nu <= 8, the plain box kernel on its fused step blocks");
+    constexpr int RL = HALF ? 8 : 16;                                  // lanes of one instance
+    constexpr int IPW = 64 / RL;                                       // instances per wave
+    constexpr unsigned long long RMASK = HALF ? 0xFFull : 0xFFFFull;
     const int lane = threadIdx.x & 63;
-    const int j = lane & 15;
-    const int grp = lane >> 4;
+    const int j = lane & (RL - 1);
+    const int grp = lane / RL;
     const bool is_state = j < NX;
     const bool is_input = (j >= NX) && (j < NZ);
 
@@ -751,14 +915,14 @@ void admm_solve_kernel(const SolveArgs P) {
     // UB: slot 1 speaks for every slot (slot 0 of an input lane is the neutral dummy: its box stays (-inf, +inf))
     const double lo_u = sLo[16 + j], hi_u = sHi[16 + j], lo_u0 = sLo[j], hi_u0 = sHi[j];
     const int ninst = P.index ? *P.count : P.batch;
-    const int ntiles = (ninst + 3) >> 2;
+    const int ntiles = (ninst + IPW - 1) / IPW;
     const bool resumed = P.index != nullptr;
     // Tiles of 4 instances: one per wave (grid = tiles), or -- a follow-up stage of a split solve, fewer waves than tiles -- the wave
     // takes its next tile off the stage's counter the moment it is free (its tiles differ in depth: a fixed stride would make the
     // stage wait for the slot that drew the deepest ones)
     for (int tile = blockIdx.x; tile < ntiles;
          tile = P.work_counter ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(P.work_counter, 1) : 0) + (int)gridDim.x : tile + (int)gridDim.x) {
-        const int slot = (P.reverse ? ntiles - 1 - tile : tile) * 4 + grp;
+        const int slot = (P.reverse ? ntiles - 1 - tile : tile) * IPW + grp;
         if (slot < ninst) {
             const int b = resumed ? P.index[slot] : slot;
             const double* het = nullptr;
@@ -837,7 +1001,9 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k)
                     pt[k] = ADAPT ? sP[grp * NX * NX + k + NX * (is_state ? j : 0)] : (HET ? het[TAB_PT + k * 16 + j] : sPt[k * 16 + j]);
-                const double xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
+                double xp = 0.0;
+                if constexpr (HALF) ring1_half<0, NX>(xp, ref_last, pt);
+                else xp = ring_sum<MODE, 0, NX>(0.0, ref_last, pt);
                 qx_last_plain = QX[N - 1];                   // q[:,N-1] uses -Xref*Q, p[:,N-1] the terminal term
                 QX[N - 1] = is_state ? -xp : QX[N - 1];
             };
@@ -964,6 +1130,7 @@ void admm_solve_kernel(const SolveArgs P) {
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
                             if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % 3], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                            else if constexpr (HALF) fused_backward_step_half<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             else fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             pcur = res;                                                 // p_i | d_i
                             Dn[i] = fma(res, nim, cf);
@@ -1052,7 +1219,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
                             double tt, vn, xn, t = Dn[i];
                             const double xi = X[i];
-                            fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
+                            if constexpr (HALF) fused_forward_step_half<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
+                            else fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
                             X[i + 1] = xn;
                             pmax = resid_max<(N > 12)>(pmax, xi - vn);
                             dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
@@ -1078,7 +1246,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             rd = dmax * rho;
                             const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
                             const unsigned long long bal = __ballot(ok);
-                            conv = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
+                            conv = ((bal >> (grp * RL)) & RMASK) == RMASK;
                         }
                     };
                     if constexpr (SOC) {
@@ -1262,8 +1430,8 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
             }
             if (P.x0_next && acc_iter > 0 && is_state) P.x0_next[(size_t)b * NX + j] = X[1];     // x1 = A x0 + B u0 + f (needs a forward pass)
-            const double ps = grp_max16(is_state ? rp : 0.0), pi = grp_max16(is_input ? rp : 0.0);
-            const double ds = grp_max16(is_state ? rd : 0.0), di = grp_max16(is_input ? rd : 0.0);
+            const double ps = grp_maxw<RL>(is_state ? rp : 0.0), pi = grp_maxw<RL>(is_input ? rp : 0.0);
+            const double ds = grp_maxw<RL>(is_state ? rd : 0.0), di = grp_maxw<RL>(is_input ? rd : 0.0);
             if (P.next_index) {
                 const bool open = j == 0 && !solved;
                 const unsigned long long m = __ballot(open);

@@ -1020,6 +1020,18 @@ int launch_solve(TinyBatch* b) {
         else if (jk.lin && !jk.het && !jk.dbg && jk.kmax == LIN_KMAX) k = b->kernel->klin[jk.soc][jk.lin];
         else if (jk.het && !jk.lin && !jk.dbg) k = b->kernel->khet[jk.soc];
     }
+    // HALF rows (nx+nu <= 8): the plain box launch of a compiled-in shape takes the form that puts two instances into a DPP row --
+    // eight per wave (option "half_rows": -1 / 1 on where the form exists, 0 off).  Bit-identical to the one-row form.
+    int ipw = 4;
+    if (k && b->kernel && b->half_rows != 0 && (k == b->kernel->kub || k == b->kernel->k[0][0][2])) {
+        SolveKernel kh = b->kernel->khalf[k == b->kernel->kub ? 1 : 0];
+        if (kh) { k = kh; ipw = 8; }
+    }
+    b->last_half = ipw == 8;
+    if (ipw == 8) {
+        grid = (b->batch + 7) / 8;
+        if (b->grid_waves_per_cu > 0) grid = (int)std::min<long>(grid, (long)b->num_cus * b->grid_waves_per_cu);
+    }
     hipFunction_t jit_fn = nullptr;
     if (!k) {
         std::string why;
@@ -1813,6 +1825,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "reset_duals")) b->reset_duals = value != 0;
     else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
+    else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
     else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
@@ -1926,6 +1939,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
+    if (!strcmp(name, "last_half_rows")) return b->last_half ? 1 : 0;       // the last one-row launch took the HALF form (two instances per DPP row)
     if (!strcmp(name, "last_tile_form")) return b->last_tile_form;          // W * 1e6 + R * 1e3 + LM of the tile_dims.txt entry the last tile launch took (-1: run-time instantiated)
     if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form
     if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;

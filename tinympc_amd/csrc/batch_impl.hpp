@@ -114,6 +114,8 @@ struct TinyBatch {
     bool tile_bounds_uniform = false;              // build_tile_tables_w: the same for the tile kernel's UB form
     bool xref_shared = true, uref_shared = true;   // the Xref / Uref records of all instances are identical (broadcast, or still zero)
     bool share_ref = true;                         // option "share_ref": let launches exploit that
+    int half_rows = -1;                  // option "half_rows": the one-row kernel's HALF form (nx+nu <= 8, eight instances per wave) where it exists; 0 = off
+    bool last_half = false;              // the last one-row launch took it
     int launch_order = 1;                // option "launch_order": 1 = successive plain launches of the one-row kernel walk the batch in alternating directions
     bool order_flip = false;
     int store_primal = 1;                // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)

@@ -12,7 +12,13 @@ struct KernelEntry {
     SolveKernel kadapt[2];    // [dbg]: adaptive rho (dpp_mode 2, no cone)
     SolveKernel kub;          // knot-invariant box in registers (plain variant, dpp_mode 2)
     SolveKernel kubsoc;       // the same for the cone variant (its slack lives in LDS since round 4: the two bound registers fit)
+    SolveKernel khalf[2];     // [UB]: HALF rows -- nx+nu <= 8, two instances per DPP row, eight per wave (plain box variant; else nullptr)
 };
+template <int NX, int NU, int NN, bool UB>
+constexpr SolveKernel half_kernel_or_null() {
+    if constexpr (NX + NU <= 8 && fused_shape(NX, NU)) return admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, LIN_KMAX, false, UB, true>;
+    else return nullptr;
+}
 struct TileEntry {
     int nx, nu, N, W, R;
     int lm;                   // which arrays leave the register file (tile_kernel.hip.h TILE_LM_*); 99: the largest set that fits the wave's LDS share
@@ -37,7 +43,8 @@ struct TileEntry {
       { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, true>, \
         tinympc_amd::admm_solve_kernel<NX, NU, NN, false, true, 2, 0, false, tinympc_amd::LIN_KMAX, true> },  \
       tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>,         \
-      tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true> }
+      tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>,          \
+      { tinympc_amd::half_kernel_or_null<NX, NU, NN, false>(), tinympc_amd::half_kernel_or_null<NX, NU, NN, true>() } }
 // the LEAN set of a shape that only the sweep of BASELINE configs[4] asks for: the box kernel in its two bound forms; its cone /
 // half-space / per-instance-data / adaptive / debug / dpp-mode variants are instantiated at run time on first use (jit.hip) --
 // compiled in, every one of them cost build time and library size for launches nobody has measured
@@ -46,4 +53,5 @@ struct TileEntry {
                     { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } } },                       \
       { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } },                     \
       { nullptr, nullptr }, { nullptr, nullptr },                                                             \
-      tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>, nullptr }
+      tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>, nullptr,  \
+      { tinympc_amd::half_kernel_or_null<NX, NU, NN, false>(), tinympc_amd::half_kernel_or_null<NX, NU, NN, true>() } }

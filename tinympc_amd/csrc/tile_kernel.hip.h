@@ -29,46 +29,7 @@ struct TileTab {
     static constexpr int doubles(int N, int kmax = LIN_KMAX) { return tlin_offset(N, kmax) + 3 * N * kmax * LW; }
 };
 
-// HALF rows: lanes 0-7 and 8-15 of a DPP row carry two different instances.  `row_newbcast:k` broadcasts ONE lane to the whole row, so
-// a column of the mat-vec takes two instructions, each writing one half only (bank_mask: write-enable per bank of 4 lanes; honoured by
-// the DP-ALU DPP form at no cost, tools/ubench/ubench_dpp_bankmask.hip): lanes 0-7 get lane k, lanes 8-15 get lane 8+k.  Per instance
-// that is the same number of FMA issue slots as a full row gives -- the gain is everywhere else: every lane-local instruction (the
-// slot update is 13 of the 25 instructions per slot at (4,2)) now serves twice the instances, and so does every register.
-// HARDWARE NOTE (measured, tools/ubench/ubench_dpp_bankmask2.hip; not in the LLVM hazard tables): a bank-masked DPP instruction
-// writes its DISABLED lanes back with the value of vdst it read at operand fetch ("old"), and that read is NOT interlocked against a
-// VALU write of vdst in the instruction before -- `fmac bank_mask:0x3` directly followed by `fmac bank_mask:0xc` on the same
-// accumulator loses the first one's result (the second writes the stale lanes 0-7 back).  One wait state in between is enough.
-// So a chain runs all its low-half FMAs (their enabled lanes accumulate through the interlocked src2 path; the disabled lanes keep
-// being re-written with a value that does not change), then `s_nop 0`, then all its high-half FMAs.
-#define THL_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:%2+" #k " row_mask:0xf bank_mask:0x3\n\t"
-#define THH_(mi, k) "v_fmac_f64_dpp %0, %1, %" #mi " row_newbcast:8+%2+" #k " row_mask:0xf bank_mask:0xc\n\t"
-#define THL1 THL_(3, 0)
-#define THL2 THL1 THL_(4, 1)
-#define THL3 THL2 THL_(5, 2)
-#define THL4 THL3 THL_(6, 3)
-#define THL5 THL4 THL_(7, 4)
-#define THL6 THL5 THL_(8, 5)
-#define THL7 THL6 THL_(9, 6)
-#define THL8 THL7 THL_(10, 7)
-#define THH1 THH_(3, 0)
-#define THH2 THH1 THH_(4, 1)
-#define THH3 THH2 THH_(5, 2)
-#define THH4 THH3 THH_(6, 3)
-#define THH5 THH4 THH_(7, 4)
-#define THH6 THH5 THH_(8, 5)
-#define THH7 THH6 THH_(9, 6)
-#define THH8 THH7 THH_(10, 7)
-#define RINGH_CASE(K)                                                                       \
-    if constexpr (NCOL == K) {                                                              \
-        asm("s_nop 1\n\t" THL##K "s_nop 0\n\t" THH##K : "+&v"(a0) : "v"(src), "i"(COL0), TM##K);   \
-    }
-// a0 += sum_k bcast_half(src, COL0+k) * m[k]   (each half of the row reads its OWN lanes COL0+k)
-template <int COL0, int NCOL>
-__device__ __forceinline__ void ring1_half(double& a0, double src, const double* m) {
-    static_assert(NCOL >= 1 && COL0 + NCOL <= 8, "one half row");
-    RINGH_CASE(1) RINGH_CASE(2) RINGH_CASE(3) RINGH_CASE(4) RINGH_CASE(5) RINGH_CASE(6) RINGH_CASE(7) RINGH_CASE(8)
-}
-
+// (the half-row FMA chains -- THL / THH, ring1_half -- live in admm_kernel.hip.h: the one-row kernel's HALF variant shares them)
 // (a, b) = (values of the even DPP row, values of the odd DPP row) of each 32-lane half, visible in both rows
 __device__ __forceinline__ void swap16(double v, double& a, double& b) {
     const int lo = __double2loint(v), hi = __double2hiint(v);

@@ -37,6 +37,12 @@ VARIANTS = {
     "prim3": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
     "prim4": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
     "socclk": ("u_6_3_10", [], SOCCLK),
+    # (20,8,50) tile forms that stream v|z to its record (LM bit 4): the per-iteration store removed (timing only, WRONG results) /
+    # issued nontemporal (results unchanged)
+    "vpg_nostore": ("u_20_8_50", [], [("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                        } else dmax", "} else dmax"),
+                                      ("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                            } else dmax", "} else dmax")]),
+    "vpg_nt": ("u_20_8_50", [], [("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                        } else dmax", "__builtin_nontemporal_store(VN[l], (l == 0 ? vpp0 : vpp) + l * NZ);\n                        } else dmax"),
+                                 ("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                            } else dmax", "__builtin_nontemporal_store(VN[l], (l == 0 ? vpp0 : vpp) + l * NZ);\n                            } else dmax")]),
     # timing-only ablations of the cone kernel (results are WRONG by construction)
     "abl_fwd_nogc": ("u_6_3_10", [], [("gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC];", "gr[(i + 2) % 3] = 0.0;"),
                                      ("                        gr[0] = sC[cw + PL_GC];\n                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];\n",
@@ -55,12 +61,14 @@ def build(tag):
         if f.endswith((".h", ".hpp", ".hip")):
             shutil.copy(os.path.join(SRC, f), tmp)
     shutil.copy(os.path.join(SRC, "_gen", unit + ".hip"), tmp + "/_gen")
-    p = tmp + "/admm_kernel.hip.h"
-    s = open(p).read()
-    for a, b in patches:
-        assert a in s, a
-        s = s.replace(a, b, 1)
-    open(p, "w").write(s)
+    for hdr in ("admm_kernel.hip.h", "tile_kernel.hip.h"):
+        p = tmp + "/" + hdr
+        s = open(p).read()
+        for a, b in patches:
+            if a in s:
+                s = s.replace(a, b)
+        open(p, "w").write(s)
+    assert all(any(a in open(os.path.join(SRC, h)).read() for h in ("admm_kernel.hip.h", "tile_kernel.hip.h")) for a, _ in patches), "a patch no longer applies"
     subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *defs, "-c", tmp + "/_gen/" + unit + ".hip", "-o", tmp + "/k.o"])
     objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != unit + ".o" and "_chk" not in f]
     out = os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_%s.so" % tag)
