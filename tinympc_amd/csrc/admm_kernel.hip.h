@@ -540,16 +540,20 @@ __device__ __forceinline__ void ring1_half(double& a0, double src, const double*
 #define HFBH6 HFBH5 "v_fmac_f64_dpp %[xn], %[t], %[b5] row_newbcast:8+%[c0]+5 row_mask:0xf bank_mask:0xc\n\t"
 #define HFBH7 HFBH6 "v_fmac_f64_dpp %[xn], %[t], %[b6] row_newbcast:8+%[c0]+6 row_mask:0xf bank_mask:0xc\n\t"
 #define HFBH8 HFBH7 "v_fmac_f64_dpp %[xn], %[t], %[b7] row_newbcast:8+%[c0]+7 row_mask:0xf bank_mask:0xc\n\t"
+// Every wait state such a chain needs is a lane-local instruction the iteration needs anyway (no s_nop): behind the write of the
+// accumulator stands the forward constant of the step BEFORE (Dn = fma(p | d, nim, cf) of the source the chain is about to broadcast),
+// between the two halves the `vn - g` of the NEXT step; in the forward step `g <- (x + g) - vnew` and the primal residual term
+// `x - vnew`.  Same instructions, same operands as the one-instance-per-row form: bit-identical results.
 #define FUSED_HBWD_CASE(NA_, NB_) FUSED_HBWD_CASE_(NA_, NB_)
 #define FUSED_HBWD_CASE_(NA_, NB_)                                                                                      \
     if constexpr (NA == NA_ && NB == NB_) {                                                                             \
-        asm("v_add_f64 %[tmp], %[vn], -%[g]\n\t"                                                                        \
-            "v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
+        asm("v_fma_f64 %[qlo], -%[rho], %[tmp], %[qx]\n\t"                                                              \
             "v_fma_f64 %[acc], %[qlo], %[smask], %[cb]\n\t"                                                             \
-            "s_nop 0\n\t" HAL##NA_ HBL##NB_ "s_nop 0\n\t" HAH##NA_ HBH##NB_                                             \
-            : [qlo] "=&v"(qlo), [acc] "=&v"(acc), [tmp] "=&v"(tmp)                                                      \
-            : [vn] "v"(vn), [g] "v"(g), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), [sa] "v"(sa),    \
-              [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                                                         \
+            "v_fma_f64 %[dnp], %[sa], %[nim], %[cf]\n\t" HAL##NA_ HBL##NB_                                              \
+            "v_add_f64 %[tmpn], %[vnn], -%[gn]\n\t" HAH##NA_ HBH##NB_                                                   \
+            : [qlo] "=&v"(qlo), [acc] "=&v"(acc), [dnp] "=&v"(dnp), [tmpn] "=&v"(tmpn)                                  \
+            : [tmp] "v"(tmp), [vnn] "v"(vnn), [gn] "v"(gn), [qx] "v"(qx), [rho] "v"(rho), [smask] "v"(smask), [cb] "v"(cb), \
+              [nim] "v"(nim), [cf] "v"(cf), [sa] "v"(sa), [sb] "v"(sb), [c0] "i"(NA_), FMA##NA_, FMB##NB_);             \
     }
 #define FUSED_HFWD_CASE(NA_, NB_) FUSED_HFWD_CASE_(NA_, NB_)
 #define FUSED_HFWD_CASE_(NA_, NB_)                                                                                      \
@@ -558,8 +562,9 @@ __device__ __forceinline__ void ring1_half(double& a0, double src, const double*
             "v_max_f64 %[vm], %[lo], %[tt]\n\t" HFAL##NA_                                                               \
             "v_min_f64 %[vn], %[hi], %[vm]\n\t" HFAH##NA_                                                               \
             "v_mov_b64 %[xn], %[t]\n\t"                                                                                 \
-            "s_nop 0\n\t" HFBL##NB_ "s_nop 0\n\t" HFBH##NB_                                                             \
-            : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t)                               \
+            "v_add_f64 %[gnew], %[tt], -%[vn]\n\t" HFBL##NB_                                                            \
+            "v_add_f64 %[dpr], %[xi], -%[vn]\n\t" HFBH##NB_                                                             \
+            : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t), [gnew] "=&v"(gnew), [dpr] "=&v"(dpr) \
             : [xi] "v"(xi), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                  \
     }
 // One (nx, nu) pair per translation unit: the Makefile (compiled-in shapes) and jit.hip (run-time instantiated ones) define
@@ -592,17 +597,17 @@ __device__ __forceinline__ void fused_backward_step_soc(double& qlo, double& acc
     FUSED_SHAPES(FUSED_BWD_SOC_CASE)
     (void)tmp;
 }
-// the half-row forms of the two (NA + NB <= 8)
+// the half-row forms of the two (NA + NB <= 8).  backward: qlo = fma(-rho, tmp, qx) with tmp = vn - g handed in (formed by the step before);
+// dnp = fma(sa, nim, cf); tmpn = vnn - gn for the next step.  forward: additionally gnew = tt - vn, dpr = xi - vn
 template <int NA, int NB>
-__device__ __forceinline__ void fused_backward_step_half(double& qlo, double& acc, double vn, double g, double qx, double rho, double smask, double cb,
-                                                         double sa, double sb, const double* ma, const double* mb_) {
-    double tmp;
+__device__ __forceinline__ void fused_backward_step_half(double& qlo, double& acc, double& dnp, double& tmpn, double tmp, double vnn, double gn, double qx,
+                                                         double rho, double smask, double cb, double nim, double cf, double sa, double sb,
+                                                         const double* ma, const double* mb_) {
     FUSED_HALF_SHAPES(FUSED_HBWD_CASE)
-    (void)tmp;
 }
 template <int NA, int NB>
-__device__ __forceinline__ void fused_forward_step_half(double& tt, double& vn, double& t, double& xn, double xi, double g, double lo, double hi,
-                                                        const double* ma, const double* mb_) {
+__device__ __forceinline__ void fused_forward_step_half(double& tt, double& vn, double& t, double& xn, double& gnew, double& dpr, double xi, double g,
+                                                        double lo, double hi, const double* ma, const double* mb_) {
     double vm;
     FUSED_HALF_SHAPES(FUSED_HFWD_CASE)
     (void)vm;
@@ -1121,8 +1126,23 @@ void admm_solve_kernel(const SolveArgs P) {
                     }
                     double pcur = qhi;                         // p_{N-1} on state lanes
                     // ---- backward_pass_grad, admm.cpp:13-20
+                    if constexpr (HALF) {                       // (the wait states of the half-row chains carry the neighbouring steps' lane-local work)
+                        double tmpv = VN[N - 2] - G[N - 2];
 #pragma unroll
-                    for (int i = N - 2; i >= 0; --i) {
+                        for (int i = N - 2; i >= 0; --i) {
+                            double qlo, res, dnp, tmpn;
+                            constexpr int dummy = 0;
+                            const int in = i > 0 ? i - 1 : dummy;
+                            fused_backward_step_half<NX, NU>(qlo, res, dnp, tmpn, tmpv, VN[in], G[in], QX[i], rho, smask, cb, nim, cf, pcur, qhi, mb, mb + NX);
+                            if (i + 1 <= N - 2) Dn[i + 1] = dnp;                        // fma(p_{i+1} | d_{i+1}, nim, cf)
+                            tmpv = tmpn;
+                            pcur = res;                                                 // p_i | d_i
+                            qhi = qlo;
+                        }
+                        Dn[0] = fma(pcur, nim, cf);
+                    }
+#pragma unroll
+                    for (int i = N - 2; i >= 0 && !HALF; --i) {
                         if constexpr (SOC) {
                             if (i >= 2) wr[(i - 2) % 3] = sC[cw + (i - 2) * SLOT_D];      // (slot i + 1's register is free by now)
                             __builtin_amdgcn_sched_barrier(0);
@@ -1130,7 +1150,6 @@ void admm_solve_kernel(const SolveArgs P) {
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
                             if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % 3], rho, smask, cb, pcur, qhi, mb, mb + NX);
-                            else if constexpr (HALF) fused_backward_step_half<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             else fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             pcur = res;                                                 // p_i | d_i
                             Dn[i] = fma(res, nim, cf);
@@ -1219,8 +1238,18 @@ void admm_solve_kernel(const SolveArgs P) {
                         if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
                             double tt, vn, xn, t = Dn[i];
                             const double xi = X[i];
-                            if constexpr (HALF) fused_forward_step_half<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
-                            else fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
+                            if constexpr (HALF) {
+                                double gnew, dpr;
+                                fused_forward_step_half<NX, NU>(tt, vn, t, xn, gnew, dpr, xi, G[i], lo_c, hi_c, mf1, mf2);
+                                X[i + 1] = xn;
+                                pmax = vmax_abs64(pmax, dpr);              // (one v_max with |.|: an asm output would be canonicalised in front of fmax)
+                                dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
+                                G[i] = gnew;
+                                VN[i] = vn;
+                                lo_c = lo_n; hi_c = hi_n;
+                                continue;
+                            }
+                            fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
                             X[i + 1] = xn;
                             pmax = resid_max<(N > 12)>(pmax, xi - vn);
                             dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
