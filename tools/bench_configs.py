@@ -107,7 +107,7 @@ def config3(B=262144, device=0):
     assert st2[0] == st[0] and st2[1] == st[1], "the split solve must reproduce the plain one"
     settled = auto[6:]
     e = _entry("config3", "quadrotor_tracking (12,4,10) x %d, per-instance random Xref/Uref, one cold solve (BASELINE configs[2])" % B,
-               settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(),
+               settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solves_launched=(3 + 17) * B,
                launch_form="the library's default dispatch (automatic split solve, clock-checked), repetitions 7-17 of 17",
                plain_launch_ms=float(np.median(plain)), plain_launch_ms_min=float(np.min(plain)),
                automatic_split_k=s.get_option("auto_split_k"), automatic_split_growth=s.get_option("auto_split_growth"),
@@ -158,6 +158,7 @@ def config4(B=65536, device=0, en_state_soc=0, en_input_soc=1, name="config4"):
     e = _entry(name, "rocket_landing (6,3,10) x %d, %s, %d-step closed loop fused into one launch (BASELINE configs[3])" % (B, cones, steps),
                ms, B * steps, st[7], nx, nu, N, s.algorithmic_bytes() + 8 * 3 * nu * (N - 1), s.kernel_path(),
                solved_fraction=st[8] / (B * steps), mpc_steps_per_launch=steps, en_state_soc=en_state_soc, en_input_soc=en_input_soc,
+               solves_launched=6 * B * steps,
                note="flops_per_iter counts the box iteration only (the cone projection's sqrt / divisions are extra work, not extra credit); "
                     "bytes: bytes_warm + the cone slack records, once per LAUNCH (S = %d)" % S)
     e["hbm"]["gbs"] /= steps                           # the records move once per launch, not once per fused step
@@ -198,7 +199,7 @@ def sweep_cell(nx, nu, N, B=131072, device=0):
     st = s.reduce_stats()
     name = "sweep_%d_%d_%d" % (nx, nu, N)
     e = _entry(name, "random sweep cell (nx=%d, nu=%d, N=%d) x %d, one cold solve, max_iter 500 (BASELINE configs[4])" % (nx, nu, N, B),
-               settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B,
+               settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B, solves_launched=len(ms) * B,
                automatic_split_k=s.get_option("auto_split_k"), tile_alt_verdict=s.get_option("tile_alt_verdict"))
     idx = _sample_idx(B)
     stt = s.status()
@@ -210,7 +211,7 @@ def sweep_cell(nx, nu, N, B=131072, device=0):
     return e, spec
 
 
-def run_all(device=0, budget_s=45.0, log=None, spec_out=None):
+def run_all(device=0, budget_s=45.0, log=None, spec_out=None, only=None):
     """-> {"config3": ..., "config4": ..., "sweep_4_2_10": ...}; an entry that fails is reported as {"error": ...}, entries that
     would start after the budget is spent as {"skipped": ...} (the bench line must appear whatever happens here).  spec_out: where
     the samples for oracle/config_check.py are pickled."""
@@ -221,6 +222,8 @@ def run_all(device=0, budget_s=45.0, log=None, spec_out=None):
             ("config4_both_cones", lambda: config4(device=device, en_state_soc=1, en_input_soc=1, name="config4_both_cones"))]
     jobs += [("sweep_%d_%d_%d" % c, (lambda c=c: sweep_cell(*c, device=device))) for c in SWEEP_CELLS]
     for name, fn in jobs:
+        if only and name not in only:
+            continue
         if time.perf_counter() - t0 > budget_s:
             out[name] = {"skipped": "time budget of %.0f s spent" % budget_s}
             continue
@@ -240,4 +243,5 @@ def run_all(device=0, budget_s=45.0, log=None, spec_out=None):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run_all(log=lambda m: print(m, file=sys.stderr)), indent=1))
+    # python tools/bench_configs.py [entry ...]   (under rocprofv3 --pmc for tools/configs_traffic.py: one entry per run)
+    print("@@CFG@@" + json.dumps(run_all(log=lambda m: print(m, file=sys.stderr), only=sys.argv[1:] or None, budget_s=600.0)))

@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def find(stage, pattern):
@@ -34,7 +34,10 @@ copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", 
           ("configs", "configs_3_4.json", "configs_3_4.json"), ("sweep", "sweep_config5.json", "sweep_config5.json"),
           ("sweep", "sweep_config5.md", "sweep_config5.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt"),
           ("adaptive", "adaptive_bench_run.txt", "adaptive_bench_run.txt"),
-          ("counters", "kernel_counters.md", "kernel_counters_table.md")]      # (rNN_kernel_counters.md = this table + its reading)
+          ("counters", "kernel_counters.md", "kernel_counters_table.md"),      # (rNN_kernel_counters.md = this table + its reading)
+          ("probes", "warm_order.md", "warm_launch_order.md"), ("probes", "warm_order_batches.md", "warm_launch_order_batches.md"),
+          ("probes", "soc_iter_cost.txt", "soc_iter_cost.txt"), ("probes", "half_rows_bench.md", "half_rows_bench.md"),
+          ("cfgtraffic", "configs_traffic.json", "configs_traffic.json")]
 for stage, name, dst in copies:
     src = os.path.join(OUT, stage, name)
     if os.path.exists(src):
@@ -85,5 +88,12 @@ for mode, key, what in (("step", "per_step_launch", "one launch per MPC step, th
                 "fuses.  Below 1.0: the hover references are one shared record (share_ref) and a solve that converges at its first "
                 "check does not store v|z again"}
 if traffic:
-    json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+    tp = os.path.join(DST, "traffic.json")
+    try:
+        old = json.load(open(tp))
+    except Exception:                                    # noqa: BLE001
+        old = {}
+    if "configs" in old:                                 # (written by tools/configs_traffic.py)
+        traffic["configs"] = old["configs"]
+    json.dump(traffic, open(tp, "w"), indent=1)
 print("collected into", DST, "traffic keys:", list(traffic))

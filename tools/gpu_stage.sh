@@ -10,6 +10,8 @@
 #   sweep        tools/sweep_bench.py (config 5)
 #   adaptive     the adaptive-rho parity tests + a timing of the adaptive kernel variant
 #   counters     rocprofv3 SQ / HBM counters of the sweep and cone kernels -> kernel_counters.md
+#   cfgtraffic   FETCH_SIZE / WRITE_SIZE per solve of every `configs` entry of the bench line -> profiles/traffic.json[configs]
+#   probes       warm-regime launch order table, cone iteration cost, half-row forms (round 4)
 #   exp          whatever tools/gpu_experiment.sh holds (kernel experiments of the moment)
 set +e
 export TMPDIR=/tmp
@@ -63,6 +65,20 @@ for stage in "$@"; do
     bench3)
       # round 3: the driver's command (plain process, defaults of the new line: regimes, configs, CPU baseline last)
       timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; echo "rc=$?"; tail -c 600 $O/bench_driver_flags.json; echo; tail -5 $O/bench_driver_flags.err ;;
+    cfgtraffic)
+      # HBM-side bytes per solve of every `configs` entry: FETCH_SIZE / WRITE_SIZE passes (kernel trace only) of one entry per run
+      cd /tmp
+      for e in ${CFG_ENTRIES:-config3 config4 config4_state_cone config4_both_cones sweep_4_2_10 sweep_12_4_30 sweep_4_2_50 sweep_12_8_30 sweep_20_8_10 sweep_20_8_50}; do
+        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/${e}_fetch -o c -- python $R/tools/bench_configs.py $e > $R/$O/${e}_fetch.json 2> $R/$O/${e}_fetch.err
+        timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/${e}_write -o c -- python $R/tools/bench_configs.py $e > $R/$O/${e}_write.json 2> $R/$O/${e}_write.err
+      done
+      cd $R; python tools/configs_traffic.py $O > $O/configs_traffic.json 2> $O/configs_traffic.err; tail -c 400 $O/configs_traffic.json ;;
+    probes)
+      # round 4: warm-regime launch order / store policy table, cone iteration cost, half-row forms
+      timeout 600 python tools/warm_order_probe.py > $O/warm_order.md 2>&1; tail -20 $O/warm_order.md
+      BATCHES=16384,32768,65536,131072 QUICK=1 timeout 600 python tools/warm_order_probe.py > $O/warm_order_batches.md 2>&1
+      timeout 300 python tools/soc_iter_cost.py > $O/soc_iter_cost.txt 2>&1; cat $O/soc_iter_cost.txt
+      timeout 600 python tools/half_rows_bench.py > $O/half_rows_bench.md 2>&1; cat $O/half_rows_bench.md ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
