@@ -542,8 +542,8 @@ __device__ __forceinline__ void ring1_half(double& a0, double src, const double*
 #define HFBH8 HFBH7 "v_fmac_f64_dpp %[xn], %[t], %[b7] row_newbcast:8+%[c0]+7 row_mask:0xf bank_mask:0xc\n\t"
 // Every wait state such a chain needs is a lane-local instruction the iteration needs anyway (no s_nop): behind the write of the
 // accumulator stands the forward constant of the step BEFORE (Dn = fma(p | d, nim, cf) of the source the chain is about to broadcast),
-// between the two halves the `vn - g` of the NEXT step; in the forward step `g <- (x + g) - vnew` and the primal residual term
-// `x - vnew`.  Same instructions, same operands as the one-instance-per-row form: bit-identical results.
+// between the two halves the `vn - g` of the NEXT step; in the forward step `g <- (x + g) - vnew` (the residual terms are NOT pulled in:
+// they are only formed when the termination test can pass).  Same instructions, same operands as the one-instance-per-row form: bit-identical results.
 #define FUSED_HBWD_CASE(NA_, NB_) FUSED_HBWD_CASE_(NA_, NB_)
 #define FUSED_HBWD_CASE_(NA_, NB_)                                                                                      \
     if constexpr (NA == NA_ && NB == NB_) {                                                                             \
@@ -563,8 +563,8 @@ __device__ __forceinline__ void ring1_half(double& a0, double src, const double*
             "v_min_f64 %[vn], %[hi], %[vm]\n\t" HFAH##NA_                                                               \
             "v_mov_b64 %[xn], %[t]\n\t"                                                                                 \
             "v_add_f64 %[gnew], %[tt], -%[vn]\n\t" HFBL##NB_                                                            \
-            "v_add_f64 %[dpr], %[xi], -%[vn]\n\t" HFBH##NB_                                                             \
-            : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t), [gnew] "=&v"(gnew), [dpr] "=&v"(dpr) \
+            "s_nop 0\n\t" HFBH##NB_                                                                                     \
+            : [tt] "=&v"(tt), [vm] "=&v"(vm), [vn] "=&v"(vn), [xn] "=&v"(xn), [t] "+&v"(t), [gnew] "=&v"(gnew)           \
             : [xi] "v"(xi), [g] "v"(g), [lo] "v"(lo), [hi] "v"(hi), [c0] "i"(NA_), FMA##NA_, FMB##NB_);                  \
     }
 // One (nx, nu) pair per translation unit: the Makefile (compiled-in shapes) and jit.hip (run-time instantiated ones) define
@@ -598,7 +598,7 @@ __device__ __forceinline__ void fused_backward_step_soc(double& qlo, double& acc
     (void)tmp;
 }
 // the half-row forms of the two (NA + NB <= 8).  backward: qlo = fma(-rho, tmp, qx) with tmp = vn - g handed in (formed by the step before);
-// dnp = fma(sa, nim, cf); tmpn = vnn - gn for the next step.  forward: additionally gnew = tt - vn, dpr = xi - vn
+// dnp = fma(sa, nim, cf); tmpn = vnn - gn for the next step.  forward: additionally gnew = tt - vn
 template <int NA, int NB>
 __device__ __forceinline__ void fused_backward_step_half(double& qlo, double& acc, double& dnp, double& tmpn, double tmp, double vnn, double gn, double qx,
                                                          double rho, double smask, double cb, double nim, double cf, double sa, double sb,
@@ -606,7 +606,7 @@ __device__ __forceinline__ void fused_backward_step_half(double& qlo, double& ac
     FUSED_HALF_SHAPES(FUSED_HBWD_CASE)
 }
 template <int NA, int NB>
-__device__ __forceinline__ void fused_forward_step_half(double& tt, double& vn, double& t, double& xn, double& gnew, double& dpr, double xi, double g,
+__device__ __forceinline__ void fused_forward_step_half(double& tt, double& vn, double& t, double& xn, double& gnew, double xi, double g,
                                                         double lo, double hi, const double* ma, const double* mb_) {
     double vm;
     FUSED_HALF_SHAPES(FUSED_HFWD_CASE)
@@ -1239,10 +1239,10 @@ void admm_solve_kernel(const SolveArgs P) {
                             double tt, vn, xn, t = Dn[i];
                             const double xi = X[i];
                             if constexpr (HALF) {
-                                double gnew, dpr;
-                                fused_forward_step_half<NX, NU>(tt, vn, t, xn, gnew, dpr, xi, G[i], lo_c, hi_c, mf1, mf2);
+                                double gnew;
+                                fused_forward_step_half<NX, NU>(tt, vn, t, xn, gnew, xi, G[i], lo_c, hi_c, mf1, mf2);
                                 X[i + 1] = xn;
-                                pmax = vmax_abs64(pmax, dpr);              // (one v_max with |.|: an asm output would be canonicalised in front of fmax)
+                                pmax = resid_max<(N > 12)>(pmax, xi - vn);
                                 dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
                                 G[i] = gnew;
                                 VN[i] = vn;
@@ -1267,15 +1267,31 @@ void admm_solve_kernel(const SolveArgs P) {
                     slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % 3 : 0]);
                     // ---- termination_condition, admm.cpp:310-328 (the box residuals: the cone slacks do not enter them)
                     bool conv = false;
+                    // The 2N subtractions and maxima behind the four residuals (a tenth of the quadrotor iteration) are only formed when the
+                    // test can pass: a row converges only if EVERY entry of its residuals is below the tolerance, so two probe slots decide
+                    // first -- slot 1 (x_1 | u_0: where the constraints bite) and the last one.  An entry there at or above its tolerance and
+                    // the test is lost whatever the other slots hold (max >= that entry; `x rho` is monotone for rho > 0; a NaN entry is
+                    // ignored by the maxima, so it does not count against the probe either).  The probe is skipped -- the full test runs --
+                    // on the last test of the launch's iteration budget: the residuals it leaves are the ones the solve reports (:314-317).
                     auto termination = [&]() {
                         if (countdown > 0 && --countdown == 0) {
                             countdown = P.check_termination;
                             checked = 1;
-                            rp = pmax;
-                            rd = dmax * rho;
-                            const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
-                            const unsigned long long bal = __ballot(ok);
-                            conv = ((bal >> (grp * RL)) & RMASK) == RMASK;
+                            constexpr int PS0 = N >= 2 ? 1 : 0, PS1 = N - 1;
+                            auto lost = [&](const int s) {
+                                return (fabs(X[s] - VN[s]) >= P.tol_pri) || (fabs(VP[s] - VN[s]) * rho >= P.tol_dua);
+                            };
+                            const bool maybe = !(rho > 0.0) || !(lost(PS0) || lost(PS1));
+                            const unsigned long long balp = __ballot(maybe);
+                            const bool row_maybe = ((balp >> (grp * RL)) & RMASK) == RMASK;
+                            const bool last_test = (P.max_iter - 1 - it) < P.check_termination;
+                            if (last_test || __ballot(row_maybe) != 0ull) {
+                                rp = pmax;
+                                rd = dmax * rho;
+                                const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
+                                const unsigned long long bal = __ballot(ok);
+                                conv = ((bal >> (grp * RL)) & RMASK) == RMASK;
+                            }
                         }
                     };
                     if constexpr (SOC) {

@@ -31,11 +31,12 @@ for f in sorted(glob.glob(os.path.join(d, "*_fetch.json"))):
                     t += float(r["Counter_Value"])
         tot[kind] = t * 1024.0
     n = e.get("solves_launched") or e["solves"]
+    n = n / e.get("mpc_steps_per_launch", 1)             # a fused episode moves its records once per LAUNCH: count instance-launches
     hbm = (2 * tot["fetch"] + tot["write"]) / n
-    out[name] = {"hbm_bytes_per_solve": hbm, "fetch_bytes_per_solve_x2": 2 * tot["fetch"] / n, "write_bytes_per_solve": tot["write"] / n,
+    out[name] = {"hbm_bytes_per_instance_launch": hbm, "fetch_bytes_x2": 2 * tot["fetch"] / n, "write_bytes": tot["write"] / n,
                  "algorithmic_bytes_per_solve": e["hbm"]["algorithmic_bytes_per_solve"], "ratio_traffic_over_algorithmic": hbm / e["hbm"]["algorithmic_bytes_per_solve"],
-                 "solves_in_the_profiled_run": n, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE around `python tools/bench_configs.py %s` (tools/gpu_stage.sh cfgtraffic)" % name,
-                 "note": "per cold solve (config 4: per MPC step of the fused 90-step episode -- the records move once per launch); L2-fabric-side counters: Infinity-Cache hits included"}
+                 "instance_launches_in_the_profiled_run": n, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE around `python tools/bench_configs.py %s` (tools/gpu_stage.sh cfgtraffic)" % name,
+                 "note": "per instance and launch (one cold solve; config 4: one fused 90-step episode -- the records move once per launch); L2-fabric-side counters: Infinity-Cache hits included"}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
 t.setdefault("configs", {}).update(out)
