@@ -1278,14 +1278,18 @@ void admm_solve_kernel(const SolveArgs P) {
                             countdown = P.check_termination;
                             checked = 1;
                             constexpr int PS0 = N >= 2 ? 1 : 0, PS1 = N - 1;
-                            auto lost = [&](const int s) {
-                                return (fabs(X[s] - VN[s]) >= P.tol_pri) || (fabs(VP[s] - VN[s]) * rho >= P.tol_dua);
+                            auto lost = [&](const int s) {              // (`|`, not `||`: four compares and three s_or, no EXEC-mask regions)
+                                return (fabs(X[s] - VN[s]) >= P.tol_pri) | (fabs(VP[s] - VN[s]) * rho >= P.tol_dua);
                             };
-                            const bool maybe = !(rho > 0.0) || !(lost(PS0) || lost(PS1));
-                            const unsigned long long balp = __ballot(maybe);
-                            const bool row_maybe = ((balp >> (grp * RL)) & RMASK) == RMASK;
+                            const bool maybe = !(rho > 0.0) | !(lost(PS0) | lost(PS1));
+                            // any row all of whose lanes say maybe?  (scalar: AND-fold the ballot over each row's RL bits; rows that have
+                            // left the loop are masked off and vote 0)
+                            unsigned long long fold = __ballot(maybe);
+                            fold &= fold >> 1; fold &= fold >> 2; fold &= fold >> 4;
+                            if constexpr (!HALF) fold &= fold >> 8;
+                            const bool any_row = (fold & (HALF ? 0x0101010101010101ull : 0x0001000100010001ull)) != 0ull;
                             const bool last_test = (P.max_iter - 1 - it) < P.check_termination;
-                            if (last_test || __ballot(row_maybe) != 0ull) {
+                            if (last_test || any_row) {
                                 rp = pmax;
                                 rd = dmax * rho;
                                 const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
