@@ -370,6 +370,37 @@ def test_non_finite_instance_stays_in_its_row(options):
     assert np.isnan(dirty["x"][1]).any() and np.isnan(dirty["x"][4]).any()
 
 
+@pytest.mark.parametrize("dims", [(4, 2, 50), (12, 2, 50)])
+def test_a_diverged_instance_does_not_reach_the_others_through_the_shared_pad(dims):
+    """on the tile forms that stream v|z to its record, the lanes WITHOUT a row (and the input lanes' dummy slot 0) of every
+    instance point at one pad behind the records.  A diverged instance leaves non-finite values there; healthy instances -- in the same
+    launch and in the NEXT one on the same batch -- must keep their iteration counts (check_termination = 1: their first test would
+    otherwise see an infinite dual residual) and their results, bit for bit."""
+    suite = sc.sweep_suite(*dims, B=13, max_iter=60)
+    s = make_batch(suite)
+    assert s.kernel_path() == "tile"
+
+    def solve(x0):
+        s.reset()
+        s.set("Xref", suite["cases"]["Xref"]); s.set("Uref", suite["cases"]["Uref"]); s.set_x0(x0)
+        s.solve()
+        out = {k: s.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z")}
+        out["iter"] = np.asarray(s.status()["iter"]).copy()
+        return out
+    clean = solve(suite["cases"]["x0"])
+    assert s.get_option("last_tile_form") % 1000 >= 16            # a form with v|z in its record (LM bit 4)
+    bad = suite["cases"]["x0"].copy()
+    bad[3, 0] = np.nan
+    bad[8, 1] = np.inf
+    dirty = solve(bad)
+    after = solve(suite["cases"]["x0"])                            # the pad now holds what the diverged instances left
+    s.close()
+    healthy = [i for i in range(13) if i not in (3, 8)]
+    for k in clean:
+        assert np.array_equal(dirty[k][healthy], clean[k][healthy]), (k, "same launch")
+        assert np.array_equal(after[k], clean[k]), (k, "next launch")
+
+
 def test_hover_closed_loop_full_batch():
     """BASELINE config 2 at full size: 65 536 identical quadrotor-hover instances, 100 closed-loop MPC
     steps on device (advance_x0).  Properties: every instance reproduces the reference's golden

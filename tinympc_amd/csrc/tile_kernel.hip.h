@@ -367,13 +367,13 @@ void admm_tile_kernel(const SolveArgs P) {
                     if (iter == 0) {                                   // a solve's first iteration: v|z of the solve before, from its record, into
                         __builtin_amdgcn_s_waitcnt(0);                 // the vnew|znew registers (dead behind the backward sweep)
 #pragma unroll
-                        for (int l = 0; l < L; ++l) {
-                            // lanes without a row (and the input lanes' dummy slot 0) point at the pad behind the records, which EVERY
-                            // instance's such lanes stream into: whatever it holds -- the non-finite leftovers of a diverged instance
-                            // included -- is not taken (once per solve: the select costs nothing in the iteration)
-                            const double vz = (l == 0 ? vpp0 : vpp)[l * NZ];
-                            VN[l] = (jj >= NZ || (l == 0 && hrow == 0 && is_input)) ? 0.0 : vz;
-                        }
+                        for (int l = 0; l < L; ++l) VN[l] = (l == 0 ? vpp0 : vpp)[l * NZ];
+                        // The pad behind the records is shared by EVERY instance's lanes without a row and by the input lanes' dummy slot 0:
+                        // a diverged instance can leave non-finite values there.  The dummy slot of a real lane does not take them (one
+                        // select per solve); the lanes without a row may -- nothing of theirs reaches a row lane (the chains broadcast lanes
+                        // < nx+nu only) and they do not vote in the termination test (below).  (a select on all L slots here
+                        // cost these 512-register forms 50-80 B/lane of scratch and (12,2,50) 23 %.)
+                        if (hrow == 0 && is_input) VN[0] = 0.0;
                     }
                 }
                 // ---- forward_pass (admm.cpp:25-32) + slot updates, first row first
@@ -529,7 +529,7 @@ void admm_tile_kernel(const SolveArgs P) {
                     checked = 1;
                     rp = pmax;
                     rd = dmax * rho;
-                    const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
+                    const bool ok = ((rp < P.tol_pri) && (rd < P.tol_dua)) || jj >= NZ;        // (lanes without a row: their residuals are all zeros, or pad leftovers)
                     const unsigned long long bal = __ballot(ok);
                     conv = (bal & inst_mask) == inst_mask;
                 }
