@@ -811,8 +811,8 @@ void admm_solve_kernel(const SolveArgs P) {
 
     // per-wave LDS copies of the tables that are read with a dynamic index or only once per solve
     __shared__ double sPt[NX * 16];
-    __shared__ double sLo[N * 16];
-    __shared__ double sHi[N * 16];
+    __shared__ double sLo[UB ? 1 : N * 16];                    // (UB: the two bounds of a lane live in registers, read from the table once)
+    __shared__ double sHi[UB ? 1 : N * 16];
     __shared__ double sLin[LS ? 3 * KMAX * 16 : 1];
     __shared__ double sTLin[LT ? 3 * N * KMAX * 16 : 1];
     // SOC: the cone slack lives in LDS, not in registers.  Per row and slot three planes of CS cells (lane j: cell j; the lanes beyond
@@ -846,8 +846,10 @@ void admm_solve_kernel(const SolveArgs P) {
     if constexpr (LT) for (int e = lane; e < 3 * N * KMAX * 16; e += 64) sTLin[e] = P.tab[TAB_BOUNDS + 2 * N * 16 + 3 * KMAX * 16 + e];
     for (int e = lane; e < NX * 16; e += 64) sPt[e] = P.tab[TAB_PT + e];
     for (int e = lane; e < N * 16; e += 64) {
-        sLo[e] = P.tab[TAB_BOUNDS + e];
-        sHi[e] = P.tab[TAB_BOUNDS + N * 16 + e];
+        if constexpr (!UB) {
+            sLo[e] = P.tab[TAB_BOUNDS + e];
+            sHi[e] = P.tab[TAB_BOUNDS + N * 16 + e];
+        }
     }
     // this lane's matrix rows
     double mb[NZ], mf1[NX], mf2[NU];
@@ -918,7 +920,8 @@ void admm_solve_kernel(const SolveArgs P) {
     __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
 
     // UB: slot 1 speaks for every slot (slot 0 of an input lane is the neutral dummy: its box stays (-inf, +inf))
-    const double lo_u = sLo[16 + j], hi_u = sHi[16 + j], lo_u0 = sLo[j], hi_u0 = sHi[j];
+    const double lo_u = P.tab[TAB_BOUNDS + (N > 1 ? 16 : 0) + j], hi_u = P.tab[TAB_BOUNDS + N * 16 + (N > 1 ? 16 : 0) + j];
+    const double lo_u0 = P.tab[TAB_BOUNDS + j], hi_u0 = P.tab[TAB_BOUNDS + N * 16 + j];
     const int ninst = P.index ? *P.count : P.batch;
     const int ntiles = (ninst + IPW - 1) / IPW;
     const bool resumed = P.index != nullptr;
@@ -1223,8 +1226,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     // Software pipeline: the box bounds of slot i+1 are read from LDS one whole step before
                     // they are used (sched_barrier pins the reads above the step), and slot i's update is
                     // scheduled together with the FMA chain of step i -- both only need x_i.
-                    double lo_c = sLo[j], hi_c = sHi[j];
-                    if constexpr (UB) { lo_c = lo_u0; hi_c = hi_u0; }
+                    double lo_c = UB ? lo_u0 : sLo[j], hi_c = UB ? hi_u0 : sHi[j];
                     double gr[SOC ? 3 : 1];                     // SOC: gc of slot i, read from its plane two steps ahead
                     if constexpr (SOC) {
                         gr[0] = sC[cw + PL_GC];

@@ -1,4 +1,11 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $O/pytest.txt 2>&1; grep -n "passed\|failed\|Error" $O/pytest.txt | tail -5
-timeout 600 python tools/sweep_bench.py --reps 8 --cells "12,2,50;20,4,50;12,8,50;20,8,50;4,8,50" > $O/sweep_cells.md 2>&1; grep "^| [0-9]" $O/sweep_cells.md
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_variants.py tests/test_gpu_repack.py tests/test_gpu_phases.py -m gpu -q -x > $O/pytest.txt 2>&1; grep -n "passed\|failed\|Error" $O/pytest.txt | tail -5
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-configs --min-seconds 2 > $O/b.json 2>$O/b.err
+python - <<'PY'
+import json, os
+d = json.load(open(os.environ["O"] + "/b.json"))
+print("value %.4g roofline %.3f" % (d["value"], d["roofline"]["frac"]))
+for k, v in d["regimes"].items():
+    if isinstance(v, dict) and "hbm_frac" in v: print(k, "ms %.4f min %.4f hbm_frac %.3f" % (v["ms_per_launch"], v["ms_per_launch_min"], v["hbm_frac"]))
+PY

@@ -17,6 +17,10 @@ for B in [int(b) for b in os.environ.get("BATCHES", "65536").split(",")]:
     s.set_bound_constraints(np.full((nx, 1), h["x_min"]), np.full((nx, 1), h["x_max"]), np.full((nu, 1), h["u_min"]), np.full((nu, 1), h["u_max"]))
     s.update_settings(max_iter=h["max_iter"])
     s.set_option("advance_x0", 1)
+    if os.environ.get("TORCH_STREAM"):                   # as bench.py runs it: the solver on a torch-created stream
+        import torch
+        _stream = torch.cuda.Stream(device=0)
+        s.set_stream(_stream.cuda_stream)
     xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
     x0 = np.array(h["x0"], dtype=np.float64)
     bw = s.algorithmic_bytes()
