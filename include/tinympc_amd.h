@@ -224,6 +224,12 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * Ignored while a cone / half-space family is enabled, whose slack the next solve initialises from x|u).
  * "share_ref" (default 1: when Xref and Uref were set with TINY_BROADCAST -- or never -- every instance reads ONE reference
  * record instead of its own copy; 0 switches that off).
+ * "launch_order" (default 1: successive plain launches of the register kernel walk the batch in ALTERNATING directions, so that a
+ * warm launch begins with the records its predecessor touched last -- the ones the 256 MiB Infinity Cache in front of HBM still
+ * holds; 0: always ascending; 2: always descending.  Instances are independent: no result depends on it.  With the same aim the box
+ * variants store work->x|u -- written once per launch, never read back by a kernel -- with nontemporal stores).
+ * "half_rows" (default -1 / 1: shapes with nx + nu <= 8 run TWO instances per 16-lane row, eight per wavefront, where that form is
+ * compiled in -- bit-identical to the one-instance-per-row form; 0: off; read-back "last_half_rows").
  * A solve that converges at its first termination check never stores v|z: the reference returns before v = vnew. */
 int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 /* derived state: "auto_split_k" (the K the automatic split solve derived from the last iteration histogram; 0 = plain launch),
