@@ -827,6 +827,11 @@ void admm_solve_kernel(const SolveArgs P) {
     // vcnew = x + gc bit for bit, so gc = 0 and W = x + gc -- what the forward sweep leaves there.  A slot is 3 CS doubles, an ODD
     // number: the item gathers of a pass (stride = one slot) fall into distinct LDS banks.  + a dummy slot whose item (0, 0, 1)
     // the lanes without an item project (onto itself): no EXEC-mask region around the gather / scatter of a pass.
+    // SPD: how many sweep steps ahead of its use a cell is read (the ring of SPD + 1 registers per plane)
+#ifndef TINYMPC_SOC_PD
+#define TINYMPC_SOC_PD 2
+#endif
+    constexpr int SPD = TINYMPC_SOC_PD, SPR = SPD + 1;
     constexpr int CS = SOC ? ((NZ + 1) | 1) : 1;
     constexpr int SLOT_D = 3 * CS;
     constexpr int PL_GC = CS, PL_VC = 2 * CS;
@@ -1102,11 +1107,10 @@ void admm_solve_kernel(const SolveArgs P) {
                 int countdown = P.check_termination;
                 // SOC: vcnew - gc of slot i comes out of the W plane two sweep steps before its use (a ring of three registers); the
                 // first two of a sweep are read at the end of the iteration before
-                double wr[SOC ? 3 : 1];
+                double wr[SOC ? SPR : 1];
                 if constexpr (SOC) {
-                    wr[(N - 1) % 3] = sC[cw + (N - 1) * SLOT_D];
-                    if constexpr (N >= 2) wr[(N - 2) % 3] = sC[cw + (N - 2) * SLOT_D];
-                    if constexpr (N >= 3) wr[(N - 3) % 3] = sC[cw + (N - 3) * SLOT_D];
+#pragma unroll
+                    for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
                 }
                 for (int it = iter0; it < P.max_iter; ++it) {
                     // ---- update_linear_cost (lane-local) fused into the backward sweep.
@@ -1114,13 +1118,13 @@ void admm_solve_kernel(const SolveArgs P) {
                     double qhi;
                     {
                         double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293 | :280
-                        if constexpr (SOC) t = fma(-rho, wr[(N - 1) % 3], t);       // :295 | :282
+                        if constexpr (SOC) t = fma(-rho, wr[(N - 1) % SPR], t);     // :295 | :282
                         if constexpr (LS) t = fma(-rho, VL[N - 1] - GL[N - 1], t);  // :298 | :285
                         if constexpr (LT) t = fma(-rho, VT[N - 1] - GT[N - 1], t);  // :301 | :288
                         qhi = t;
                         if constexpr (DBG) {
                             double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
-                            if constexpr (SOC) ql = fma(-rho, wr[(N - 1) % 3], ql);         // :269
+                            if constexpr (SOC) ql = fma(-rho, wr[(N - 1) % SPR], ql);       // :269
                             if constexpr (LS) ql = fma(-rho, VL[N - 1] - GL[N - 1], ql);    // :272
                             if constexpr (LT) ql = fma(-rho, VT[N - 1] - GT[N - 1], ql);    // :275
                             Qd[N - 1] = is_state ? ql : t;
@@ -1147,12 +1151,12 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                     for (int i = N - 2; i >= 0 && !HALF; --i) {
                         if constexpr (SOC) {
-                            if (i >= 2) wr[(i - 2) % 3] = sC[cw + (i - 2) * SLOT_D];      // (slot i + 1's register is free by now)
+                            if (i >= SPD) wr[(i - SPD) % SPR] = sC[cw + (i - SPD) * SLOT_D];      // (slot i + 1's register is free by now)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
-                            if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % 3], rho, smask, cb, pcur, qhi, mb, mb + NX);
+                            if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % SPR], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             else fused_backward_step<NX, NU>(qlo, res, VN[i], G[i], QX[i], rho, smask, cb, pcur, qhi, mb, mb + NX);
                             pcur = res;                                                 // p_i | d_i
                             Dn[i] = fma(res, nim, cf);
@@ -1161,7 +1165,7 @@ void admm_solve_kernel(const SolveArgs P) {
                             continue;
                         }
                         double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
-                        if constexpr (SOC) qlo = fma(-rho, wr[i % 3], qlo);         // :269 | :282
+                        if constexpr (SOC) qlo = fma(-rho, wr[i % SPR], qlo);       // :269 | :282
                         if constexpr (LS) qlo = fma(-rho, VL[i] - GL[i], qlo);      // :272 | :285
                         if constexpr (LT) qlo = fma(-rho, VT[i] - GT[i], qlo);      // :275 | :288
                         // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
@@ -1227,15 +1231,15 @@ void admm_solve_kernel(const SolveArgs P) {
                     // they are used (sched_barrier pins the reads above the step), and slot i's update is
                     // scheduled together with the FMA chain of step i -- both only need x_i.
                     double lo_c = UB ? lo_u0 : sLo[j], hi_c = UB ? hi_u0 : sHi[j];
-                    double gr[SOC ? 3 : 1];                     // SOC: gc of slot i, read from its plane two steps ahead
+                    double gr[SOC ? SPR : 1];                   // SOC: gc of slot i, read from its plane SPD steps ahead
                     if constexpr (SOC) {
-                        gr[0] = sC[cw + PL_GC];
-                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];
+#pragma unroll
+                        for (int d = 0; d < SPD && d < N; ++d) gr[d % SPR] = sC[cw + d * SLOT_D + PL_GC];
                     } else gr[0] = 0.0;
 #pragma unroll
                     for (int i = 0; i < N - 1; ++i) {
                         const double lo_n = UB ? lo_u : sLo[(i + 1) * 16 + j], hi_n = UB ? hi_u : sHi[(i + 1) * 16 + j];
-                        if constexpr (SOC) { if (i + 2 < N) gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC]; }
+                        if constexpr (SOC) { if (i + SPD < N) gr[(i + SPD) % SPR] = sC[cw + (i + SPD) * SLOT_D + PL_GC]; }
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
                             double tt, vn, xn, t = Dn[i];
@@ -1257,16 +1261,16 @@ void admm_solve_kernel(const SolveArgs P) {
                             dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
                             G[i] = tt - vn;
                             VN[i] = vn;
-                            if constexpr (SOC) sC[cw + i * SLOT_D] = fma(xi, socmask, gr[i % 3]);     // x + gc -> cone step (below); see slot_update
+                            if constexpr (SOC) sC[cw + i * SLOT_D] = fma(xi, socmask, gr[i % SPR]);   // x + gc -> cone step (below); see slot_update
                             lo_c = lo_n; hi_c = hi_n;
                             continue;
                         }
                         const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
                         X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)
-                        slot_update(i, lo_c, hi_c, gr[SOC ? i % 3 : 0]);
+                        slot_update(i, lo_c, hi_c, gr[SOC ? i % SPR : 0]);
                         lo_c = lo_n; hi_c = hi_n;
                     }
-                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % 3 : 0]);
+                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % SPR : 0]);
                     // ---- termination_condition, admm.cpp:310-328 (the box residuals: the cone slacks do not enter them)
                     bool conv = false;
                     // The 2N subtractions and maxima behind the four residuals (a tenth of the quadrotor iteration) are only formed when the
@@ -1332,9 +1336,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         // the next backward sweep's first three terms, on their way while this iteration closes
-                        wr[(N - 1) % 3] = sC[cw + (N - 1) * SLOT_D];
-                        if constexpr (N >= 2) wr[(N - 2) % 3] = sC[cw + (N - 2) * SLOT_D];
-                        if constexpr (N >= 3) wr[(N - 3) % 3] = sC[cw + (N - 3) * SLOT_D];
+#pragma unroll
+                        for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
                     }
                     iter += 1;                                                      // :394
                     if constexpr (ADAPT) {

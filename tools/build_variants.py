@@ -37,6 +37,7 @@ VARIANTS = {
     "prim3": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
     "prim4": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
     "socclk": ("u_6_3_10", [], SOCCLK),
+    "socpd3": ("u_6_3_10", ["-DTINYMPC_SOC_PD=3"], []),     # LDS prefetch distance of the cone slack cells (default 2): measured equal
     # (20,8,50) tile forms that stream v|z to its record (LM bit 4): the per-iteration store removed (timing only, WRONG results) /
     # issued nontemporal (results unchanged)
     "vpg_nostore": ("u_20_8_50", [], [("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                        } else dmax", "} else dmax"),
