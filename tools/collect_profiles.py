@@ -31,7 +31,7 @@ def pmc_per_launch(dirname, counter, kernel="admm_solve_kernel"):
 copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", "smoke.txt"),
           ("bench", "bench_driver_flags.json", "bench_driver_flags.json"), ("bench", "bench_default.json", "bench_default.json"),
           ("bench", "bench_per_step.json", "bench_per_step.json"), ("bench", "bench_torchrun1.json", "bench_torchrun1.json"),
-          ("configs", "configs_3_4.json", "configs_3_4.json"), ("sweep", "sweep_config5.json", "sweep_config5.json"),
+          ("sweep", "sweep_config5.json", "sweep_config5.json"),
           ("sweep", "sweep_config5.md", "sweep_config5.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt"),
           ("adaptive", "adaptive_bench_run.txt", "adaptive_bench_run.txt"),
           ("counters", "kernel_counters.md", "kernel_counters_table.md"),      # (rNN_kernel_counters.md = this table + its reading)
