@@ -32,7 +32,7 @@ copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", 
           ("bench", "bench_driver_flags.json", "bench_driver_flags.json"), ("bench", "bench_default.json", "bench_default.json"),
           ("bench", "bench_per_step.json", "bench_per_step.json"), ("bench", "bench_torchrun1.json", "bench_torchrun1.json"),
           ("sweep", "sweep_config5.json", "sweep_config5.json"),
-          ("sweep", "sweep_config5.md", "sweep_config5.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt"),
+          ("sweep", "sweep_config5.md", "sweep_config5.md"), ("sweep", "sweep_parity.md", "sweep_parity.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt"),
           ("adaptive", "adaptive_bench_run.txt", "adaptive_bench_run.txt"),
           ("counters", "kernel_counters.md", "kernel_counters_table.md"),      # (rNN_kernel_counters.md = this table + its reading)
           ("probes", "warm_order.md", "warm_launch_order.md"), ("probes", "warm_order_batches.md", "warm_launch_order_batches.md"),

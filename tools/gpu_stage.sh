@@ -47,7 +47,7 @@ for stage in "$@"; do
     configs)
       timeout 900 python tools/config_bench.py $O/configs_3_4.json > $O/configs.out 2> $O/configs.err; tail -c 800 $O/configs.out ;;
     sweep)
-      timeout 900 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md ;;
+      timeout 1500 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json --parity $O/sweep_parity.md > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md; tail -3 $O/sweep_parity.md ;;
     adaptive)
       timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt
       timeout 300 python tools/adaptive_bench.py > $O/adaptive_bench_run.txt 2>&1; tail -2 $O/adaptive_bench_run.txt ;;

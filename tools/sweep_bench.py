@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_amd as tm  # noqa: E402
 from tinympc_amd.distributed import shard_indices  # noqa: E402
 
+PARITY = None                                         # --parity: list of samples (one per cell)
 RANK = int(os.environ.get("RANK", "0"))
 LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
 WORLD = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +103,14 @@ def run_cell(nx, nu, N, B, reps):
     iters, solved = st[0], st[1]
     alg = s.algorithmic_bytes()
     auto_k, auto_pm = s.get_option("auto_split_k"), s.get_option("auto_split_permille")
-    hv, hc = np.unique(s.status()["iter"], return_counts=True)
+    stt = s.status()
+    hv, hc = np.unique(stt["iter"], return_counts=True)
+    if PARITY is not None:                            # --parity: a sample of THIS batch for oracle/config_check.py (run after the GPU work)
+        idx = np.unique(np.linspace(0, B - 1, 256).astype(np.int64))
+        it = np.where(stt["solved"][idx] != 0, stt["iter"][idx], -stt["iter"][idx])
+        PARITY.append(dict(name="sweep_%d_%d_%d" % (nx, nu, N), kind="single", problem={k: v for k, v in prob.items()},
+                           cfg_kw=dict(max_iter=500, u_min=np.full((nu, 1), -0.5), u_max=np.full((nu, 1), 0.5)),
+                           x0=x0[idx], Xref=xr[idx], Uref=np.zeros((nu, N - 1)), gpu_iter=it.astype(np.int32), gpu_u0=s.get("u")[idx][:, :, 0]))
     s.close()
     fl = tm.flops_per_iter(nx, nu, N)
     t = best * 1e-3
@@ -119,7 +127,12 @@ def main():
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--cells", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--parity", default="", help="(1 GPU) also check 256 instances of every cell's batch against the oracle, iteration counts "
+                                                 "and u[:,0] (oracle/config_check.py, processes of its own AFTER the GPU work); markdown table to this file")
     args = ap.parse_args()
+    global PARITY
+    if args.parity and WORLD == 1:
+        PARITY = []
     global _dist, LOCAL_RANK
     if WORLD > 1 or os.environ.get("TINYMPC_FORCE_DIST"):
         from tinympc_amd.distributed import init_process_group
@@ -137,6 +150,32 @@ def main():
               f"{r['iters_per_solve']:.1f} | {r['solved_fraction']:.3f} | {r['fp64_frac']:.3f} | {r['hbm_frac']:.4f} |", flush=True)
     if args.out and RANK == 0:
         json.dump(rows, open(args.out, "w"), indent=1)
+    if PARITY:
+        import pickle, subprocess, tempfile
+        spec = os.path.join(tempfile.mkdtemp(prefix="tinympc_sweep_"), "samples.pkl")
+        pickle.dump(PARITY, open(spec, "wb"))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ("import sys, json; sys.path.insert(0, %r); import config_check; print('@@CHK@@' + json.dumps(config_check.run(%r, seconds=0.05)))"
+                % (os.path.join(root, "oracle"), spec))
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
+        chk = [json.loads(ln[7:]) for ln in p.stdout.splitlines() if ln.startswith("@@CHK@@")]
+        with open(args.parity, "w") as f:
+            f.write("Every cell of the config-5 sweep at its FULL batch (%d instances, one cold solve): 256 instances evenly spaced through the batch, solved again by\n"
+                    "the oracle (oracle/liboracle.so) -- iteration counts and solved flags must be equal, u[:,0] relative to the solve's largest entry.\n\n" % args.batch)
+            f.write("| cell | kernel | instances | iteration sum GPU | oracle | count mismatches | max rel err u0 |\n|---|---|---|---|---|---|---|\n")
+            bad = 0
+            for r in rows:
+                name = "sweep_%d_%d_%d" % (r["nx"], r["nu"], r["N"])
+                ps = chk[0][name]["parity_sample"] if chk and name in chk[0] else None
+                if ps is None:
+                    f.write("| (%d,%d,%d) | %s | checker failed: %s |\n" % (r["nx"], r["nu"], r["N"], r["kernel"], (p.stderr or "")[-200:].replace("\n", " ")))
+                    bad += 1
+                    continue
+                bad += ps["iteration_count_mismatches"]
+                f.write("| (%d,%d,%d) | %s | %d | %d | %d | %d | %.1e |\n" % (r["nx"], r["nu"], r["N"], r["kernel"], ps["instances"], ps["iter_sum_gpu"],
+                                                                             ps["iter_sum_oracle"], ps["iteration_count_mismatches"], ps["max_rel_err_u0"]))
+            f.write("\ntotal iteration-count mismatches: %d\n" % bad)
+        say("parity table ->", args.parity)
     if _dist is not None:
         _dist.destroy_process_group()
 
