@@ -1285,9 +1285,9 @@ void admm_solve_kernel(const SolveArgs P) {
                             checked = 1;
                             constexpr int PS0 = N >= 2 ? 1 : 0, PS1 = N - 1;
                             auto lost = [&](const int s) {              // (`|`, not `||`: four compares and three s_or, no EXEC-mask regions)
-                                return (fabs(X[s] - VN[s]) >= P.tol_pri) | (fabs(VP[s] - VN[s]) * rho >= P.tol_dua);
+                                return (int)(fabs(X[s] - VN[s]) >= P.tol_pri) | (int)(fabs(VP[s] - VN[s]) * rho >= P.tol_dua);
                             };
-                            const bool maybe = !(rho > 0.0) | !(lost(PS0) | lost(PS1));
+                            const bool maybe = ((int)!(rho > 0.0) | (int)!(lost(PS0) | lost(PS1))) != 0;
                             // any row all of whose lanes say maybe?  (scalar: AND-fold the ballot over each row's RL bits; rows that have
                             // left the loop are masked off and vote 0)
                             unsigned long long fold = __ballot(maybe);
