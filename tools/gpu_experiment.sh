@@ -1,4 +1,11 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 900 python tools/tile_variants_bench.py > $O/tile_variants_bench.md 2>$O/tile_variants.err; cat $O/tile_variants_bench.md; tail -3 $O/tile_variants.err
-timeout 1500 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json --parity $O/sweep_parity.md > $O/sweep_config5.md 2> $O/sweep.err; tail -5 $O/sweep_config5.md; cat $O/sweep_parity.md | tail -42
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_variants.py tests/test_gpu_repack.py tests/test_gpu_phases.py -m gpu -q -x > $O/pytest.txt 2>&1; grep -n "passed\|failed\|Error" $O/pytest.txt | tail -5
+CHECK=1 timeout 300 python tools/soc_iter_cost.py --one input
+timeout 300 python tools/bench_configs.py config4 config4_both_cones 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('@@CFG@@'):
+        d = json.loads(ln[7:])
+        for k, e in d.items(): print(k, round(e['ms'], 3), round(e['roofline']['frac'], 3))
+"
