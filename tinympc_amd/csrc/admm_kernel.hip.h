@@ -1313,10 +1313,6 @@ void admm_solve_kernel(const SolveArgs P) {
                         __builtin_amdgcn_wave_barrier();
                         double n0 = sC[item_at[0]], n1 = sC[item_at[0] + 1], n2 = sC[item_at[0] + 2];
                         termination();
-                        if (!conv) {                            // v = vnew, z = znew (:445-446) here: ten copies in the shadow of the gather
-#pragma unroll
-                            for (int s = 0; s < N; ++s) VP[s] = VN[s];
-                        }
 #pragma unroll
                         for (int p = 0; p < SOC_PASSES; ++p) {
                             if (p > 0 && p >= soc_passes) break;            // wave-uniform
@@ -1427,10 +1423,8 @@ void admm_solve_kernel(const SolveArgs P) {
                     }
                     if constexpr (!SOC) termination();                             // (after the adaptation: it may have moved rho)
                     if (conv) { solved = 1; break; }                                // :431-441 (returns before v = vnew)
-                    if constexpr (!SOC) {
 #pragma unroll
-                        for (int s = 0; s < N; ++s) VP[s] = VN[s];                  // :445-446 (SOC: done inside the cone step)
-                    }
+                    for (int s = 0; s < N; ++s) VP[s] = VN[s];                      // :445-446
                     vp_touched = true;
                 }
                 acc_iter += (unsigned)(iter - iter0);
