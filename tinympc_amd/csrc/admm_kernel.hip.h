@@ -723,6 +723,18 @@ __device__ __forceinline__ double soc_component(double s0, double s1, double s2,
 
 // The same projection for a whole 3-cone held by ONE lane (s0, s1, s2) -> (r0, r1, r2): the transposed form of the cone step
 // (one lane per (cone, knot) pair) pays the square root and the two divisions once per iteration instead of once per knot.
+// soc_all_inside: EVERY cone of the wave is inside with a margin that the float rounding of the norm cannot bridge (see soc_component):
+// every projection of the pass is then the identity (:49) -- the common case of a constraint that is not active -- and the cone step
+// neither takes a square root nor rewrites what the forward sweep left.  `&` on purpose: three compares and two s_and, no EXEC regions.
+__device__ __forceinline__ bool soc_all_inside(double s0, double s1, double s2, float mu) {
+#pragma clang fp contract(off)
+    const double u0 = s2 * (double)mu;                                  // :40
+    const double q0 = s0 * s0, q1 = s1 * s1;
+    const double q = q0 + q1;
+    // (u0 < 1e300: a non-finite last component takes the exact path, where gc = (x + gc) - vcnew becomes the NaN the reference gets)
+    const bool sure_inside = (u0 > 1e-30) & (u0 < 1e300) & (q <= (u0 * u0) * (1.0 - 0x1p-20)) & (q < 1e70);
+    return __builtin_amdgcn_ballot_w64(!sure_inside) == 0ull;
+}
 // rmu_exact: every mu of the wave is a power of two and rmu = 1 / mu exactly (wave-uniform) -- then a * rmu IS a / mu, rounded once
 // like the division (2^k scalings are exact, overflow and gradual underflow included), without the ten instructions of one.
 __device__ __forceinline__ void soc_project3(double s0, double s1, double s2, float mu, float rmu, bool rmu_exact, double& r0, double& r1, double& r2) {
@@ -730,10 +742,6 @@ __device__ __forceinline__ void soc_project3(double s0, double s1, double s2, fl
     const double u0 = s2 * (double)mu;                                  // :40
     const double q0 = s0 * s0, q1 = s1 * s1;
     const double q = q0 + q1;
-    r0 = s0; r1 = s1; r2 = s2;
-    // see soc_component; `&` on purpose: three compares and two s_and instead of nested EXEC-mask regions
-    const bool sure_inside = (u0 > 1e-30) & (q <= (u0 * u0) * (1.0 - 0x1p-20)) & (q < 1e70);
-    if (__builtin_amdgcn_ballot_w64(!sure_inside) == 0ull) return;
     const float a = (float)sqrt(q);                                     // :42
     const double ad = (double)a;
     const bool below = ad <= -u0, inside = ad <= u0;                    // :46 | :49
@@ -1108,6 +1116,9 @@ void admm_solve_kernel(const SolveArgs P) {
                 // SOC: vcnew - gc of slot i comes out of the W plane two sweep steps before its use (a ring of three registers); the
                 // first two of a sweep are read at the end of the iteration before
                 double wr[SOC ? SPR : 1];
+                bool gcz[SOC_PASSES];                          // SOC: the GC cells of pass p's items are known to be zero (rows only LEAVE a solve)
+#pragma unroll
+                for (int p = 0; p < SOC_PASSES; ++p) gcz[p] = false;
                 if constexpr (SOC) {
 #pragma unroll
                     for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
@@ -1312,20 +1323,38 @@ void admm_solve_kernel(const SolveArgs P) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         double n0 = sC[item_at[0]], n1 = sC[item_at[0] + 1], n2 = sC[item_at[0] + 2];
+                        // the next backward sweep's first terms: on their way together with the gather.  They stay valid unless a pass
+                        // below takes its exact path and rewrites W cells (then they are read again)
+#pragma unroll
+                        for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
                         termination();
+                        bool any_exact = false;
 #pragma unroll
                         for (int p = 0; p < SOC_PASSES; ++p) {
                             if (p > 0 && p >= soc_passes) break;            // wave-uniform
                             const int at = item_at[p];
                             if (p > 0) { n0 = sC[at]; n1 = sC[at + 1]; n2 = sC[at + 2]; }
                             const double s0 = n0, s1 = n1, s2 = n2;
-                            double r0, r1, r2;
-                            soc_project3(s0, s1, s2, item_mu[p], item_rmu[p], mu_pow2, r0, r1, r2);
-                            // the item's three cells of every plane (the dummy item: (0, 0, 1) onto itself, from every lane that has none)
-                            const double g0 = s0 - r0, g1 = s1 - r1, g2 = s2 - r2;      // :229 / :234  (gc + x) - vcnew
-                            sC[at + PL_VC] = r0; sC[at + PL_VC + 1] = r1; sC[at + PL_VC + 2] = r2;
-                            sC[at + PL_GC] = g0; sC[at + PL_GC + 1] = g1; sC[at + PL_GC + 2] = g2;
-                            sC[at] = r0 - g0; sC[at + 1] = r1 - g1; sC[at + 2] = r2 - g2;   // vcnew - gc: the next backward sweep's term
+                            if (soc_all_inside(s0, s1, s2, item_mu[p])) {
+                                // no cone of the wave is active: vcnew = x + gc bit for bit, so gc = (x + gc) - vcnew = 0 and
+                                // vcnew - gc = x + gc -- what the forward sweep left in the W plane.  VC takes its copy (for the
+                                // write-back); the GC cells are zeroed once, then known to be zero (gcz: of the rows still iterating)
+                                sC[at + PL_VC] = s0; sC[at + PL_VC + 1] = s1; sC[at + PL_VC + 2] = s2;
+                                if (!gcz[p]) {
+                                    sC[at + PL_GC] = 0.0; sC[at + PL_GC + 1] = 0.0; sC[at + PL_GC + 2] = 0.0;
+                                    gcz[p] = true;
+                                }
+                            } else {
+                                double r0, r1, r2;
+                                soc_project3(s0, s1, s2, item_mu[p], item_rmu[p], mu_pow2, r0, r1, r2);
+                                // the item's three cells of every plane (the dummy item: (0, 0, 1) onto itself, from every lane that has none)
+                                const double g0 = s0 - r0, g1 = s1 - r1, g2 = s2 - r2;      // :229 / :234  (gc + x) - vcnew
+                                sC[at + PL_VC] = r0; sC[at + PL_VC + 1] = r1; sC[at + PL_VC + 2] = r2;
+                                sC[at + PL_GC] = g0; sC[at + PL_GC + 1] = g1; sC[at + PL_GC + 2] = g2;
+                                sC[at] = r0 - g0; sC[at + 1] = r1 - g1; sC[at + 2] = r2 - g2;   // vcnew - gc: the next backward sweep's term
+                                gcz[p] = false;
+                                any_exact = true;
+                            }
                         }
                         // a cell outside every item: gc = (x + gc) - vcnew = 0 from the solve's first iteration on (whatever the warm start
                         // held there); once per solve, wave-uniform (the rows of a wave open their solves together)
@@ -1335,9 +1364,10 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        // the next backward sweep's first three terms, on their way while this iteration closes
+                        if (any_exact) {
 #pragma unroll
-                        for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
+                            for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
+                        }
                     }
                     iter += 1;                                                      // :394
                     if constexpr (ADAPT) {
