@@ -5,7 +5,9 @@ patched COPY of admm_kernel.hip.h (nothing in csrc/ is modified); run a tool aga
   prim0..prim4  (12,4,10): the x|u store plain / nontemporal (the default) / sc1 / sc0 sc1 / sc0 sc1 nt (TINYMPC_PRIM_STORE)
   ref0          (12,4,10): per-instance Xref|Uref records read with plain loads (TINYMPC_REF_LOAD=0; the default is nontemporal)
   socclk        (6,3,10): s_memtime phase clocks of the cone kernel's iteration (backward, forward, cone step, tail) in the four
-                residual outputs (shader cycles summed over the iterations of a solve)"""
+                residual outputs (shader cycles summed over the iterations of a solve; s_memtime answers on the counter LDS reads
+                use, so every clock read also waits for the prefetches in flight: phases come out longer than they run)
+  idm           (6,3,10): the identity-mode stretch experiment, see profiles/r04_negative_results.md"""
 import os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tinympc_amd", "csrc")
@@ -26,7 +28,38 @@ SOCCLK = [
     ("                acc_iter += (unsigned)(iter - iter0);\n",
      "                acc_iter += (unsigned)(iter - iter0);\n                rp = (double)clkB; rd = (double)clkF; rc_ = (double)clkC; rt_ = (double)clkT;\n"),
     ("            double rp = 0.0, rd = 0.0;\n", "            double rp = 0.0, rd = 0.0, rc_ = 0.0, rt_ = 0.0;\n"),
-    ("            const double ps = grp_max16(is_state ? rp : 0.0), pi = grp_max16(is_input ? rp : 0.0);\n            const double ds = grp_max16(is_state ? rd : 0.0), di = grp_max16(is_input ? rd : 0.0);\n",
+    ("            const double ps = grp_maxw<RL>(is_state ? rp : 0.0), pi = grp_maxw<RL>(is_input ? rp : 0.0);\n            const double ds = grp_maxw<RL>(is_state ? rd : 0.0), di = grp_maxw<RL>(is_input ? rd : 0.0);\n",
+     "            const double ps = rp, pi = rd, ds = rc_, di = rt_;\n"),
+]
+# socclk + a count of the passes that took their exact path, added to the "tail" clock in units of 1e6
+SOCCLK_CNT = SOCCLK + [("                                gcz[p] = false;\n                                any_exact = true;\n",
+                        "                                gcz[p] = false;\n                                any_exact = true;\n                                clkT += 1000000;\n")]
+# which lanes fail the all-inside test (the ballot of the last pass, in the "tail" slot; the "cone" slot: u0 and q of lane 0)
+SOCCLK_MASK = SOCCLK + [("                            if (soc_all_inside(s0, s1, s2, item_mu[p])) {\n",
+                         "                            { const double u0_ = s2 * (double)item_mu[p]; const double q_ = s0 * s0 + s1 * s1;\n"
+                         "                              const bool si_ = (u0_ > 1e-30) & (u0_ < 1e300) & (q_ <= (u0_ * u0_) * (1.0 - 0x1p-20)) & (q_ < 1e70);\n"
+                         "                              dbgmask = (long long)__builtin_amdgcn_ballot_w64(!si_); dbgu0 = u0_; dbgq = q_; }\n"
+                         "                            if (soc_all_inside(s0, s1, s2, item_mu[p])) {\n"),
+                        ("                long long clkB = 0, clkF = 0, clkC = 0, clkT = 0;\n", "                long long clkB = 0, clkF = 0, clkC = 0, clkT = 0, dbgmask = 0; double dbgu0 = 0, dbgq = 0;\n"),
+                        ("rp = (double)clkB; rd = (double)clkF; rc_ = (double)clkC; rt_ = (double)clkT;", "rp = dbgu0 * (double)(iter - iter0); rd = dbgq * (double)(iter - iter0); rc_ = (double)clkC; rt_ = (double)dbgmask * (double)(iter - iter0);")]
+
+# the cone kernel's two iteration modes: shader cycles and iteration counts of the general / the identity-mode iterations of a solve
+# (in the four residual outputs: cycles general, cycles identity, iterations general, iterations identity)
+SOCMODE = [
+    ("                    if (!(SOC && redo)) {\n",
+     "                    const long long tg0 = clock64();\n                    if (!(SOC && redo)) {\n"),
+    ("                    vp_touched = true;\n                    ++it;\n",
+     "                    vp_touched = true;\n                    ++it;\n                    clkG += clock64() - tg0; nG += 1;\n"),
+    ("                            while (it < P.max_iter) {\n                                backward_sweep(bool_c<true>{});\n",
+     "                            while (it < P.max_iter) {\n                                const long long ti0 = clock64();\n                                backward_sweep(bool_c<true>{});\n"),
+    ("                                for (int s = 0; s < N; ++s) VP[s] = VN[s];\n                                ++it;\n",
+     "                                for (int s = 0; s < N; ++s) VP[s] = VN[s];\n                                ++it;\n                                clkI += clock64() - ti0; nI += 1;\n"),
+    ("                int it = iter0;\n", "                int it = iter0;\n                long long clkG = 0, clkI = 0, nG = 0, nI = 0;\n"),
+    ("                                    redo = true;\n", "                                    redo = true; nG += 1000;\n"),
+    ("                acc_iter += (unsigned)(iter - iter0);\n",
+     "                acc_iter += (unsigned)(iter - iter0);\n                rp = (double)clkG; rd = (double)clkI; rc_ = (double)nG; rt_ = (double)nI;\n"),
+    ("            double rp = 0.0, rd = 0.0;\n", "            double rp = 0.0, rd = 0.0, rc_ = 0.0, rt_ = 0.0;\n"),
+    ("            const double ps = grp_maxw<RL>(is_state ? rp : 0.0), pi = grp_maxw<RL>(is_input ? rp : 0.0);\n            const double ds = grp_maxw<RL>(is_state ? rd : 0.0), di = grp_maxw<RL>(is_input ? rd : 0.0);\n",
      "            const double ps = rp, pi = rd, ds = rc_, di = rt_;\n"),
 ]
 VARIANTS = {
@@ -37,6 +70,13 @@ VARIANTS = {
     "prim3": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=3"], []),
     "prim4": ("u_12_4_10", ["-DTINYMPC_PRIM_STORE=4"], []),
     "socclk": ("u_6_3_10", [], SOCCLK),
+    "socclkcnt": ("u_6_3_10", [], SOCCLK_CNT),
+    "socmask": ("u_6_3_10", [], SOCCLK_MASK),
+    # the abandoned identity-mode stretch of the cone kernel (tools/experiments/idm_mode.diff, profiles/r04_negative_results.md):
+    # on / compiled out / with its mode counters
+    "idm": ("u_6_3_10", [], [], "idm_mode.diff"),
+    "idm0": ("u_6_3_10", ["-DTINYMPC_SOC_IDM=0"], [], "idm_mode.diff"),
+    "idm_socmode": ("u_6_3_10", [], SOCMODE, "idm_mode.diff"),
     "socpd3": ("u_6_3_10", ["-DTINYMPC_SOC_PD=3"], []),     # LDS prefetch distance of the cone slack cells (default 2): measured equal
     # (20,8,50) tile forms that stream v|z to its record (LM bit 4): the per-iteration store removed (timing only, WRONG results) /
     # issued nontemporal (results unchanged)
@@ -54,7 +94,7 @@ VARIANTS = {
 
 
 def build(tag):
-    unit, defs, patches = VARIANTS[tag]
+    unit, defs, patches, *diff = VARIANTS[tag]
     tmp = "/tmp/variant_" + tag
     shutil.rmtree(tmp, ignore_errors=True)
     os.makedirs(tmp + "/_gen")
@@ -62,14 +102,18 @@ def build(tag):
         if f.endswith((".h", ".hpp", ".hip")):
             shutil.copy(os.path.join(SRC, f), tmp)
     shutil.copy(os.path.join(SRC, "_gen", unit + ".hip"), tmp + "/_gen")
+    for d in diff:                                      # a source diff kept under tools/experiments/ goes on first
+        subprocess.check_call(["patch", "-s", tmp + "/admm_kernel.hip.h", os.path.join(ROOT, "tools", "experiments", d)])
+    applied = [False] * len(patches)
     for hdr in ("admm_kernel.hip.h", "tile_kernel.hip.h"):
         p = tmp + "/" + hdr
         s = open(p).read()
-        for a, b in patches:
+        for i, (a, b) in enumerate(patches):             # in order: a later patch may anchor on what an earlier one put in
             if a in s:
                 s = s.replace(a, b)
+                applied[i] = True
         open(p, "w").write(s)
-    assert all(any(a in open(os.path.join(SRC, h)).read() for h in ("admm_kernel.hip.h", "tile_kernel.hip.h")) for a, _ in patches), "a patch no longer applies"
+    assert all(applied), "a patch no longer applies: %r" % [patches[i][0][:60] for i, ok in enumerate(applied) if not ok]
     subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *defs, "-c", tmp + "/_gen/" + unit + ".hip", "-o", tmp + "/k.o"])
     objs = [os.path.join(SRC, "_gen", f) for f in os.listdir(SRC + "/_gen") if f.endswith(".o") and f != unit + ".o" and "_chk" not in f]
     out = os.path.join(ROOT, "tinympc_amd", "libtinympc_amd_%s.so" % tag)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Cost of one ADMM iteration of the (6,3,10) rocket kernel without and with cone projections: 65 536 instances, 100 iterations
-each (check_termination = 0 unless CHECK=1: no early exit), one launch per setting.
+each (check_termination = 0 unless CHECK=1: no early exit), one launch per setting.  No references are set: the cones are ACTIVE (every
+projection pass on its exact path); the `warm` figure repeats the launch from the state it left, where no cone is active any more --
+the regime of BASELINE's config 4 (identity fast path of the cone step).
 
     python tools/soc_iter_cost.py                 SIMD cycles per wave-iteration (kernel time x 2.4 GHz), box / input / state / both
     python tools/soc_iter_cost.py --one input     ONE setting, two launches: the command to put under rocprofv3 --pmc (SQ counter passes)
@@ -32,6 +34,10 @@ for name, ss, si in SETTINGS:
         s.reset(); s.set_x0(x0); s.set_option("timing", 1); s.solve_async(); best = min(best, float(s.timing_ms()[0]))
     line = (f"{name:11s}: {best:.3f} ms per 100 iterations = {B * 100 / best * 1e3:.3e} ADMM it/s, "
             f"{best * 1e-3 / 100 / (B / 4 / 1024) * 2.4e9:.0f} SIMD cycles per wave-iteration")
+    # the same 100 iterations again WITHOUT a reset: the warm state of the solve before, no cone active any more -- every pass takes
+    # its identity path (what the closed loop of config 4 sees after its first solves)
+    s.set_option("timing", 1); s.solve_async(); warm = float(s.timing_ms()[0])
+    line += f" | warm (no cone active): {warm:.3f} ms, {warm * 1e-3 / 100 / (B / 4 / 1024) * 2.4e9:.0f} cycles"
     if clocks:
         st = s.status()
         it = np.maximum(st["iter"], 1)
