@@ -1190,13 +1190,19 @@ void admm_solve_kernel(const SolveArgs P) {
                     // (admm.cpp:81-135, 219-235, 314-317) of slot i+1 issued right behind the step that produced it:
                     // the lane-local element-wise work (and its LDS bound reads) fills the dependency stalls of
                     // the next step's FMA chain instead of forming a separate, latency-exposed phase.
+                    // The 2N subtractions and maxima behind the residuals: short horizons form them inside the termination test, from the
+                    // registers, only when the probe lets the test run (said here, not left to the compiler's sinking); long ones keep
+                    // the running maxima of the forward sweep
+                    constexpr bool LAZY_RES = N <= 12;
                     double pmax = 0.0, dmax = 0.0;
                     auto slot_update = [&](const int s, const double lo, const double hi, const double gcv) {
                         const double xi = X[s];
                         const double t = xi + G[s];                                 // :85 / :88
                         const double vn = vmin64(hi, vmax64(lo, t));                // :91-98
-                        pmax = resid_max<(N > 12)>(pmax, xi - vn);
-                        dmax = resid_max<(N > 12)>(dmax, VP[s] - vn);
+                        if constexpr (!LAZY_RES) {
+                            pmax = resid_max<true>(pmax, xi - vn);
+                            dmax = resid_max<true>(dmax, VP[s] - vn);
+                        }
                         G[s] = t - vn;                      // :222 / :225  g + x - vnew; (g + x) == t bit-for-bit
                         VN[s] = vn;
                         if constexpr (SOC) {
@@ -1259,8 +1265,10 @@ void admm_solve_kernel(const SolveArgs P) {
                                 double gnew;
                                 fused_forward_step_half<NX, NU>(tt, vn, t, xn, gnew, xi, G[i], lo_c, hi_c, mf1, mf2);
                                 X[i + 1] = xn;
-                                pmax = resid_max<(N > 12)>(pmax, xi - vn);
-                                dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
+                                if constexpr (!LAZY_RES) {
+                                    pmax = resid_max<true>(pmax, xi - vn);
+                                    dmax = resid_max<true>(dmax, VP[i] - vn);
+                                }
                                 G[i] = gnew;
                                 VN[i] = vn;
                                 lo_c = lo_n; hi_c = hi_n;
@@ -1268,8 +1276,10 @@ void admm_solve_kernel(const SolveArgs P) {
                             }
                             fused_forward_step<NX, NU>(tt, vn, t, xn, xi, G[i], lo_c, hi_c, mf1, mf2);
                             X[i + 1] = xn;
-                            pmax = resid_max<(N > 12)>(pmax, xi - vn);
-                            dmax = resid_max<(N > 12)>(dmax, VP[i] - vn);
+                            if constexpr (!LAZY_RES) {
+                                pmax = resid_max<true>(pmax, xi - vn);
+                                dmax = resid_max<true>(dmax, VP[i] - vn);
+                            }
                             G[i] = tt - vn;
                             VN[i] = vn;
                             if constexpr (SOC) sC[cw + i * SLOT_D] = fma(xi, socmask, gr[i % SPR]);   // x + gc -> cone step (below); see slot_update
@@ -1307,6 +1317,13 @@ void admm_solve_kernel(const SolveArgs P) {
                             const bool any_row = (fold & (HALF ? 0x0101010101010101ull : 0x0001000100010001ull)) != 0ull;
                             const bool last_test = (P.max_iter - 1 - it) < P.check_termination;
                             if (last_test || any_row) {
+                                if constexpr (LAZY_RES) {
+#pragma unroll
+                                    for (int s = 0; s < N; ++s) {
+                                        pmax = resid_max<false>(pmax, X[s] - VN[s]);
+                                        dmax = resid_max<false>(dmax, VP[s] - VN[s]);
+                                    }
+                                }
                                 rp = pmax;
                                 rd = dmax * rho;
                                 const bool ok = (rp < P.tol_pri) && (rd < P.tol_dua);
