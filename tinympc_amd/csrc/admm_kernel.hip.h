@@ -151,6 +151,11 @@ struct SolveArgs {
     // Infinity Cache in front of HBM still holds (a batch whose records exceed it would otherwise stream through it without a hit).
     // Instances are independent: the order changes nothing in the results.
     int reverse;
+    // one-row kernel, plain launches: slot s of the grid solves instance perm[s] (null: instance s).  A fused closed-loop launch that
+    // is cut into stretches of MPC steps (batch_api.hip "step_regroup") hands every stretch the instances ordered by the iteration
+    // count of their last solve: the four rows of a wave run in lock step, so a wave costs what its slowest row costs, and rows
+    // that took alike counts at the last step take alike counts at the next ones.  Same reason as above: nothing in the results.
+    const int* perm;
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -945,7 +950,7 @@ void admm_solve_kernel(const SolveArgs P) {
          tile = P.work_counter ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(P.work_counter, 1) : 0) + (int)gridDim.x : tile + (int)gridDim.x) {
         const int slot = (P.reverse ? ntiles - 1 - tile : tile) * IPW + grp;
         if (slot < ninst) {
-            const int b = resumed ? P.index[slot] : slot;
+            const int b = resumed ? P.index[slot] : (P.perm ? P.perm[slot] : slot);
             const double* het = nullptr;
             if constexpr (HET) {                               // this instance's own cache (A, B, Q, R, rho differ per instance)
                 het = P.het_tabs + (size_t)b * TAB_BOUNDS;
@@ -1476,9 +1481,10 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
                 acc_iter += (unsigned)(iter - iter0);
                 acc_solved += (unsigned)solved;
+                // (the logs of a single-step launch: a stretch of a fused launch that batch_api.hip cut up, "step_regroup")
+                if (P.iter_log && j == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
+                if (P.u0_log && is_input) P.u0_log[((size_t)step * P.batch + b) * NU + (j - NX)] = X[1];
                 if (nsteps > 1) {
-                    if (P.iter_log && j == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
-                    if (P.u0_log && is_input) P.u0_log[((size_t)step * P.batch + b) * NU + (j - NX)] = X[1];
                     // plant step x0 <- A x0 + B u_0 + f (== forward_pass x_1).  Input lanes hold u_0 in slot 1: their
                     // slot 0 is the neutral dummy and must stay 0, or its "slack" would enter the dual residual
                     x0v = is_state ? X[1] : 0.0;

@@ -915,6 +915,128 @@ static int enqueue_iteration_histogram(TinyBatch* b) {
     return TINY_OK;
 }
 
+// ---- step_regroup: counting sort of the instances by the iteration count of their last solve, largest first (the longest waves
+// of a stretch start first, the short ones fill its tail), and the estimate that switches it on
+enum { RG_BINS = 1024 };
+__device__ __forceinline__ int regroup_key(const int4 st) {
+    const int it = st.x < 0 ? -st.x : st.x;
+    return it < RG_BINS - 1 ? it : RG_BINS - 1;
+}
+__global__ __launch_bounds__(256) void regroup_hist_kernel(const int4* status, int batch, unsigned* bins) {
+    __shared__ unsigned h[RG_BINS];
+    for (int i = threadIdx.x; i < RG_BINS; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += gridDim.x * blockDim.x) atomicAdd(&h[regroup_key(status[b])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RG_BINS; i += blockDim.x)
+        if (h[i]) atomicAdd(&bins[i], h[i]);
+}
+// bins[k] <- instances with a key above k (one block of RG_BINS threads): where the first instance of key k goes
+__global__ __launch_bounds__(RG_BINS) void regroup_scan_kernel(unsigned* bins) {
+    __shared__ unsigned s[RG_BINS];
+    const int t = threadIdx.x;
+    const unsigned own = bins[RG_BINS - 1 - t];
+    s[t] = own;
+    __syncthreads();
+    for (int d = 1; d < RG_BINS; d <<= 1) {
+        const unsigned v = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    bins[RG_BINS - 1 - t] = s[t] - own;
+}
+// (a block ranks its 1024 instances in LDS and asks the device-wide counters once per key it holds: the counts of a batch sit in a
+// handful of bins, one atomic per instance on those few addresses would serialise the whole pass)
+__global__ __launch_bounds__(256) void regroup_scatter_kernel(const int4* status, int batch, unsigned* bins, int* perm) {
+    __shared__ unsigned base[RG_BINS], rank[RG_BINS];
+    for (int c0 = blockIdx.x * 1024; c0 < batch; c0 += gridDim.x * 1024) {
+        for (int i = threadIdx.x; i < RG_BINS; i += 256) { base[i] = 0u; rank[i] = 0u; }
+        __syncthreads();
+        int key[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = c0 + e * 256 + threadIdx.x;
+            key[e] = b < batch ? regroup_key(status[b]) : -1;
+            if (key[e] >= 0) atomicAdd(&base[key[e]], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < RG_BINS; i += 256)
+            if (base[i]) base[i] = atomicAdd(&bins[i], base[i]);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (key[e] >= 0) perm[base[key[e]] + atomicAdd(&rank[key[e]], 1u)] = c0 + e * 256 + threadIdx.x;
+        __syncthreads();
+    }
+}
+// what lock step costs a batch whose waves take the instances four by four in their natural order, by the iteration totals each
+// instance has accumulated (d_accum): out[0] += rows x the largest total of every group of four, out[1] += the totals
+__global__ __launch_bounds__(256) void lockstep_estimate_kernel(const uint2* accum, int batch, unsigned long long* out) {
+    unsigned long long m = 0ull, t = 0ull;
+    const int groups = (batch + 3) / 4;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
+        unsigned mx = 0u; int rows = 0;
+        for (int r = 0; r < 4 && 4 * g + r < batch; ++r) {
+            const unsigned v = accum[4 * g + r].x;
+            mx = v > mx ? v : mx; t += v; ++rows;
+        }
+        m += (unsigned long long)mx * rows;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { m += __shfl_xor(m, off); t += __shfl_xor(t, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], m); atomicAdd(&out[1], t); }
+}
+static int ensure_regroup_buffers(TinyBatch* b) {
+    if (!b->d_perm) HIP_TRY(b, hipMalloc(&b->d_perm, (size_t)b->batch * sizeof(int)));
+    if (!b->d_rg_bins) HIP_TRY(b, hipMalloc(&b->d_rg_bins, RG_BINS * sizeof(unsigned)));
+    return TINY_OK;
+}
+// d_perm <- the instances ordered by the iteration count d_status holds for them, largest first (enqueued on the batch's stream)
+static int enqueue_regroup_sort(TinyBatch* b) {
+    HIP_TRY(b, hipMemsetAsync(b->d_rg_bins, 0, RG_BINS * sizeof(unsigned), b->stream));
+    const int blocks = std::max(1, std::min(256, (b->batch + 1023) / 1024));
+    hipLaunchKernelGGL(regroup_hist_kernel, dim3(blocks), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_rg_bins);
+    hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(RG_BINS), 0, b->stream, b->d_rg_bins);
+    hipLaunchKernelGGL(regroup_scatter_kernel, dim3(blocks), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_rg_bins, b->d_perm);
+    HIP_TRY(b, hipGetLastError());
+    return TINY_OK;
+}
+static int enqueue_lockstep_estimate(TinyBatch* b) {
+    if (!b->d_ls) {
+        HIP_TRY(b, hipMalloc(&b->d_ls, 2 * sizeof(unsigned long long)));
+        HIP_TRY(b, hipHostMalloc(reinterpret_cast<void**>(&b->h_ls), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIP_TRY(b, hipEventCreateWithFlags(&b->ls_ev, hipEventDisableTiming));
+    }
+    HIP_TRY(b, hipMemsetAsync(b->d_ls, 0, 2 * sizeof(unsigned long long), b->stream));
+    hipLaunchKernelGGL(lockstep_estimate_kernel, dim3(64), dim3(256), 0, b->stream, b->d_accum, b->batch, b->d_ls);
+    HIP_TRY(b, hipGetLastError());
+    HIP_TRY(b, hipMemcpyAsync(b->h_ls, b->d_ls, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(b, hipEventRecord(b->ls_ev, b->stream));
+    b->ls_pending = true;
+    return TINY_OK;
+}
+static void read_lockstep_estimate(TinyBatch* b) {
+    b->ls_pending = false;
+    b->lockstep_ratio = b->h_ls[1] > 0ull ? (double)b->h_ls[0] / (double)b->h_ls[1] : 1.0;
+    if (b->regroup_verdict == 0) b->regroup_verdict = b->lockstep_ratio >= 1.05 ? 1 : -1;
+}
+// stretches of a fused launch of `steps` MPC steps: K steps each; the first one a single step when nothing is known about the
+// instances yet (it is what tells them apart); a short remainder joins the stretch before it
+static std::vector<int> regroup_stretches(int steps, int K, bool know) {
+    std::vector<int> out;
+    int left = steps;
+    if (!know && left > 1) { out.push_back(1); left -= 1; }
+    while (left > 0) {
+        int n = std::min(K, left);
+        if (left - n > 0 && left - n < (K + 1) / 2) n = left;
+        out.push_back(n);
+        left -= n;
+    }
+    return out;
+}
+constexpr int REGROUP_AUTO_MIN_STEPS = 16, REGROUP_AUTO_MIN_BATCH = 4096;
+static int regroup_auto_k(int steps) { return std::max(8, (steps + 3) / 4); }
+
 // index lists + per-stage counters of the split solve: [stage] list lengths, [32 + stage] tile counters
 static int ensure_repack_buffers(TinyBatch* b) {
     if (b->d_repack_index && b->d_repack_count) return TINY_OK;
@@ -953,7 +1075,7 @@ int launch_solve(TinyBatch* b) {
     const bool soc = soc_active(b);
     SolveArgs a;
     a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0; a.work_counter = nullptr; a.reverse = 0;
-    a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr;
+    a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr; a.perm = nullptr;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
     a.status = b->d_status; a.resid = b->d_resid;
@@ -1188,8 +1310,43 @@ int launch_solve(TinyBatch* b) {
         // option "launch_order" = 1: successive plain launches walk the batch in alternating directions (SolveArgs::reverse)
         a.reverse = (b->launch_order == 2 || (b->launch_order == 1 && b->order_flip)) ? 1 : 0;
         b->order_flip = !b->order_flip;
-        if (int rc = launch(grid)) return rc;
+        // option "step_regroup": a fused closed-loop launch in stretches of K MPC steps, each over the instances ordered by the
+        // iteration count of their last solve (see batch_impl.hpp).  Every stretch is the launch a caller with steps_per_launch = K
+        // would have made: same results, bit for bit; a stretch that is not the last one keeps x|u to itself where nothing reads it.
+        const bool regroup_ok = steps > 1 && !b->one_shot;
+        if (b->ls_pending && hipEventQuery(b->ls_ev) == hipSuccess) read_lockstep_estimate(b);
+        const bool regroup_auto = b->step_regroup < 0 && regroup_ok && steps >= REGROUP_AUTO_MIN_STEPS && b->batch >= REGROUP_AUTO_MIN_BATCH;
+        if (regroup_auto && b->regroup_verdict != 0 && ++b->regroup_since >= 64) { b->regroup_since = 0; b->regroup_verdict = 0; }   // (batches drift: ask again)
+        const int rk = !regroup_ok ? 0 : (b->step_regroup > 0 ? b->step_regroup : ((regroup_auto && b->regroup_verdict == 1) ? regroup_auto_k(steps) : 0));
+        b->last_regroup_stretches = 1;
+        if (rk > 0 && rk < steps) {
+            if (int rc = ensure_regroup_buffers(b)) return rc;
+            const std::vector<int> stretches = regroup_stretches(steps, rk, b->status_valid);
+            const int mask_all = a.store_mask, cold0 = a.cold;
+            int* const ilog = a.iter_log; double* const ulog = a.u0_log;
+            const bool keep_primal = soc || jk.lin || b->debug;        // (the next stretch reads x|u back: admm.cpp:352-374)
+            int done = 0;
+            a.reverse = 0;
+            for (size_t c = 0; c < stretches.size(); ++c) {
+                const bool sorted = c > 0 || b->status_valid;
+                if (sorted) { if (int rc = enqueue_regroup_sort(b)) return rc; }
+                a.perm = sorted ? b->d_perm : nullptr;
+                a.steps = stretches[c];
+                a.traj_step0 = (int)b->traj_step + done;
+                a.iter_log = ilog ? ilog + (size_t)done * b->batch : nullptr;
+                a.u0_log = ulog ? ulog + (size_t)done * b->batch * b->nu : nullptr;
+                a.cold = c == 0 ? cold0 : 0;
+                a.store_mask = (c + 1 < stretches.size() && !keep_primal) ? (mask_all & ~(1 | 32)) : mask_all;
+                if (int rc = launch(grid)) return rc;
+                done += stretches[c];
+            }
+            b->last_regroup_stretches = (int)stretches.size();
+        } else {
+            if (int rc = launch(grid)) return rc;
+        }
+        if (regroup_auto && b->regroup_verdict == 0 && !b->ls_pending) { if (int rc = enqueue_lockstep_estimate(b)) return rc; }
     }
+    b->status_valid = true;
     if (timed) {
         HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream));
         b->timing_n++;
@@ -1412,13 +1569,15 @@ int tiny_batch_destroy(TinyBatch* b) {
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
                     b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count,
-                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter};
+                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter, b->d_perm, b->d_rg_bins, b->d_ls};
     for (void* p : bufs)
         if (p) hipFree(p);
     if (b->h_wire) hipHostFree(b->h_wire);
     if (b->d_hist) hipFree(b->d_hist);
     if (b->h_hist) hipHostFree(b->h_hist);
     if (b->hist_ev) hipEventDestroy(b->hist_ev);
+    if (b->h_ls) hipHostFree(b->h_ls);
+    if (b->ls_ev) hipEventDestroy(b->ls_ev);
     if (b->auto_ev0) hipEventDestroy(b->auto_ev0);
     if (b->auto_ev1) hipEventDestroy(b->auto_ev1);
     for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
@@ -1683,6 +1842,7 @@ int tiny_batch_reset(TinyBatch* b) {
     if (b->d_arho && !b->astate_fresh)               // adaptive rho: every instance's cache back to the one tiny_setup computed
         if (int rc = adaptive_fresh_state(b)) return rc;
     b->records_zero = true;                           // the next one-row launch need not READ what it knows to be zero (launch_solve)
+    b->status_valid = false;                          // (d_status: the last episode's counts say nothing about the next one's first step)
     return TINY_OK;
 }
 
@@ -1827,6 +1987,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
     else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
+    else if (!strcmp(name, "step_regroup")) { if (value < -1) return fail(b, TINY_ERR_ARG, "step_regroup: K > 0 (stretches of K MPC steps), 0 (never) or -1 (automatic)"); b->step_regroup = (int)value; b->regroup_verdict = 0; b->regroup_since = 0; b->ls_pending = false; }
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
@@ -1944,6 +2105,12 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form
     if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;
     if (!strcmp(name, "repack_after")) return b->repack_after;
+    if (!strcmp(name, "step_regroup")) return b->step_regroup;
+    if (!strcmp(name, "step_regroup_stretches")) return b->last_regroup_stretches;   // launches the last fused solve was cut into (1: not cut)
+    if (!strcmp(name, "step_regroup_verdict") || !strcmp(name, "lockstep_permille")) {
+        if (b->ls_pending && hipEventSynchronize(b->ls_ev) == hipSuccess) read_lockstep_estimate(b);      // (a diagnostic may wait; a solve never does)
+        return name[0] == 's' ? (long)b->regroup_verdict : (long)(b->lockstep_ratio * 1000.0 + 0.5);
+    }
     return fail(b, TINY_ERR_ARG, "unknown option %s", name);
 }
 

@@ -118,6 +118,21 @@ struct TinyBatch {
     bool last_half = false;              // the last one-row launch took it
     int launch_order = 1;                // option "launch_order": 1 = successive plain launches of the one-row kernel walk the batch in alternating directions
     bool order_flip = false;
+    // step_regroup (fused closed-loop launches of the one-row kernel): the launch is cut into stretches of K MPC steps and every
+    // stretch takes the instances ordered by the iteration count of their last solve (SolveArgs::perm; a counting sort on the
+    // device between the stretches) -- the four rows of a wave run in lock step, and what a row needed at its last step says what
+    // it will need at the next ones.  K > 0: stretches of K steps; 0: never; -1 (default): on when the iteration totals of the
+    // previous fused launch of this batch (d_accum, grouped four by four as the waves take them) say that lock step costs >= 5 %.
+    int step_regroup = -1;
+    int regroup_verdict = 0, regroup_since = 0;    // 0 open, 1 on, -1 off (the estimate of the last fused launch decided)
+    bool status_valid = false;                     // d_status holds this episode's last iteration counts (not after setup / reset)
+    int* d_perm = nullptr;
+    unsigned* d_rg_bins = nullptr;                 // 1024 bins of the counting sort
+    unsigned long long *d_ls = nullptr, *h_ls = nullptr;   // {4 x sum over waves of the largest total, sum of the totals}
+    hipEvent_t ls_ev = nullptr;
+    bool ls_pending = false;
+    double lockstep_ratio = 0.0;                   // the last estimate (1.0 = rows of a wave agree)
+    int last_regroup_stretches = 0;                // launches the last fused solve was cut into (1: not cut)
     int store_primal = 1;                // false: launches do not write x|u back (no consumer between closed-loop steps when the plant step runs on the device)
     bool records_zero = false, auto_cold = true; // every warm-start record is known to be zero (after tiny_batch_reset / setup): launches skip reading them
     int one_shot = 0;                    // 1: cold state assumed, x|u + vnew|znew written; 2: x|u only (bytes_cold of SURVEY.md 8(d))
