@@ -47,7 +47,8 @@ def rocket_batch(B, en_state_soc=0, en_input_soc=1, seed=5):
 FIELDS = ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc", "x0")
 
 
-def episode(s, steps, regroup, launches=1, fields=FIELDS):
+def episode(s, steps, regroup, launches=1, fields=FIELDS, streams=1):
+    s.set_option("step_regroup_streams", streams)
     s.set_option("steps_per_launch", steps)
     s.set_option("step_log", 1)
     s.set_option("step_regroup", regroup)
@@ -67,14 +68,19 @@ def episode(s, steps, regroup, launches=1, fields=FIELDS):
 
 @pytest.mark.parametrize("cones", [(0, 1), (1, 1)])
 @pytest.mark.parametrize("K", [1, 4, 7])
-def test_regrouped_stretches_equal_the_uncut_launch(cones, K):
+@pytest.mark.parametrize("streams", [1, 2])
+def test_regrouped_stretches_equal_the_uncut_launch(cones, K, streams):
+    """streams = 2: the two halves of the batch on two streams, the second one half a stretch out of step (K = 1: no room for that)"""
     B, steps = 203, 24                                         # ragged last wave; 7 does not divide 24 (a short remainder joins)
     a, sa = episode(rocket_batch(B, *cones), steps, 0, launches=2)
-    b, sb = episode(rocket_batch(B, *cones), steps, K, launches=2)
+    b, sb = episode(rocket_batch(B, *cones), steps, K, launches=2, streams=streams)
     assert sa == [1, 1]
     # first launch: nothing known yet -> a single step first, then stretches of K; second launch: sorted from its first step on
     n2 = len(range(0, steps, K)) if steps % K == 0 or steps % K >= (K + 1) // 2 else steps // K
-    assert sb[1] == n2 and sb[0] >= sb[1]
+    if streams == 1:
+        assert sb[1] == n2 and sb[0] >= sb[1]
+    else:
+        assert sb[1] >= 2 * n2
     assert len(np.unique(np.abs(a["it"][3]))) > 2            # the instances do differ (or the order would not matter)
     for k in a:
         assert np.array_equal(a[k], b[k]), k

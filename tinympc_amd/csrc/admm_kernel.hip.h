@@ -156,6 +156,7 @@ struct SolveArgs {
     // count of their last solve: the four rows of a wave run in lock step, so a wave costs what its slowest row costs, and rows
     // that took alike counts at the last step take alike counts at the next ones.  Same reason as above: nothing in the results.
     const int* perm;
+    int perm_count;           // slots of `perm` (a launch may take a part of the batch: batch_api.hip runs two halves on two streams)
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -940,7 +941,7 @@ void admm_solve_kernel(const SolveArgs P) {
     // UB: slot 1 speaks for every slot (slot 0 of an input lane is the neutral dummy: its box stays (-inf, +inf))
     const double lo_u = P.tab[TAB_BOUNDS + (N > 1 ? 16 : 0) + j], hi_u = P.tab[TAB_BOUNDS + N * 16 + (N > 1 ? 16 : 0) + j];
     const double lo_u0 = P.tab[TAB_BOUNDS + j], hi_u0 = P.tab[TAB_BOUNDS + N * 16 + j];
-    const int ninst = P.index ? *P.count : P.batch;
+    const int ninst = P.index ? *P.count : (P.perm ? P.perm_count : P.batch);
     const int ntiles = (ninst + IPW - 1) / IPW;
     const bool resumed = P.index != nullptr;
     // Tiles of 4 instances: one per wave (grid = tiles), or -- a follow-up stage of a split solve, fewer waves than tiles -- the wave

@@ -922,6 +922,7 @@ __device__ __forceinline__ int regroup_key(const int4 st) {
     const int it = st.x < 0 ? -st.x : st.x;
     return it < RG_BINS - 1 ? it : RG_BINS - 1;
 }
+// (status / perm: of the FIRST instance of the range; `first` = its number in the batch -- what perm holds)
 __global__ __launch_bounds__(256) void regroup_hist_kernel(const int4* status, int batch, unsigned* bins) {
     __shared__ unsigned h[RG_BINS];
     for (int i = threadIdx.x; i < RG_BINS; i += blockDim.x) h[i] = 0u;
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(RG_BINS) void regroup_scan_kernel(unsigned* bins) {
 }
 // (a block ranks its 1024 instances in LDS and asks the device-wide counters once per key it holds: the counts of a batch sit in a
 // handful of bins, one atomic per instance on those few addresses would serialise the whole pass)
-__global__ __launch_bounds__(256) void regroup_scatter_kernel(const int4* status, int batch, unsigned* bins, int* perm) {
+__global__ __launch_bounds__(256) void regroup_scatter_kernel(const int4* status, int batch, int first, unsigned* bins, int* perm) {
     __shared__ unsigned base[RG_BINS], rank[RG_BINS];
     for (int c0 = blockIdx.x * 1024; c0 < batch; c0 += gridDim.x * 1024) {
         for (int i = threadIdx.x; i < RG_BINS; i += 256) { base[i] = 0u; rank[i] = 0u; }
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(256) void regroup_scatter_kernel(const int4* status
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (key[e] >= 0) perm[base[key[e]] + atomicAdd(&rank[key[e]], 1u)] = c0 + e * 256 + threadIdx.x;
+            if (key[e] >= 0) perm[base[key[e]] + atomicAdd(&rank[key[e]], 1u)] = first + c0 + e * 256 + threadIdx.x;
         __syncthreads();
     }
 }
@@ -988,16 +989,23 @@ __global__ __launch_bounds__(256) void lockstep_estimate_kernel(const uint2* acc
 }
 static int ensure_regroup_buffers(TinyBatch* b) {
     if (!b->d_perm) HIP_TRY(b, hipMalloc(&b->d_perm, (size_t)b->batch * sizeof(int)));
-    if (!b->d_rg_bins) HIP_TRY(b, hipMalloc(&b->d_rg_bins, RG_BINS * sizeof(unsigned)));
+    if (!b->d_rg_bins) HIP_TRY(b, hipMalloc(&b->d_rg_bins, 2 * RG_BINS * sizeof(unsigned)));
+    if (b->regroup_streams == 2 && !b->stream2) {
+        HIP_TRY(b, hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIP_TRY(b, hipEventCreateWithFlags(&b->rg_fork, hipEventDisableTiming));
+        HIP_TRY(b, hipEventCreateWithFlags(&b->rg_join, hipEventDisableTiming));
+    }
     return TINY_OK;
 }
-// d_perm <- the instances ordered by the iteration count d_status holds for them, largest first (enqueued on the batch's stream)
-static int enqueue_regroup_sort(TinyBatch* b) {
-    HIP_TRY(b, hipMemsetAsync(b->d_rg_bins, 0, RG_BINS * sizeof(unsigned), b->stream));
-    const int blocks = std::max(1, std::min(256, (b->batch + 1023) / 1024));
-    hipLaunchKernelGGL(regroup_hist_kernel, dim3(blocks), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_rg_bins);
-    hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(RG_BINS), 0, b->stream, b->d_rg_bins);
-    hipLaunchKernelGGL(regroup_scatter_kernel, dim3(blocks), dim3(256), 0, b->stream, b->d_status, b->batch, b->d_rg_bins, b->d_perm);
+// d_perm[first ..) <- instances first .. first + count - 1 ordered by the iteration count d_status holds for them, largest first
+// (enqueued on `st`; `half` picks the set of counters)
+static int enqueue_regroup_sort(TinyBatch* b, hipStream_t st, int half, int first, int count) {
+    unsigned* bins = b->d_rg_bins + half * RG_BINS;
+    HIP_TRY(b, hipMemsetAsync(bins, 0, RG_BINS * sizeof(unsigned), st));
+    const int blocks = std::max(1, std::min(256, (count + 1023) / 1024));
+    hipLaunchKernelGGL(regroup_hist_kernel, dim3(blocks), dim3(256), 0, st, b->d_status + first, count, bins);
+    hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(RG_BINS), 0, st, bins);
+    hipLaunchKernelGGL(regroup_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->d_status + first, count, first, bins, b->d_perm + first);
     HIP_TRY(b, hipGetLastError());
     return TINY_OK;
 }
@@ -1020,12 +1028,11 @@ static void read_lockstep_estimate(TinyBatch* b) {
     b->lockstep_ratio = b->h_ls[1] > 0ull ? (double)b->h_ls[0] / (double)b->h_ls[1] : 1.0;
     if (b->regroup_verdict == 0) b->regroup_verdict = b->lockstep_ratio >= 1.05 ? 1 : -1;
 }
-// stretches of a fused launch of `steps` MPC steps: K steps each; the first one a single step when nothing is known about the
-// instances yet (it is what tells them apart); a short remainder joins the stretch before it
-static std::vector<int> regroup_stretches(int steps, int K, bool know) {
+// stretches of `steps` MPC steps: `lead` steps first (0: none), then K steps each; a short remainder joins the stretch before it
+static std::vector<int> regroup_stretches(int steps, int K, int lead) {
     std::vector<int> out;
     int left = steps;
-    if (!know && left > 1) { out.push_back(1); left -= 1; }
+    if (lead > 0 && left > lead) { out.push_back(lead); left -= lead; }
     while (left > 0) {
         int n = std::min(K, left);
         if (left - n > 0 && left - n < (K + 1) / 2) n = left;
@@ -1075,7 +1082,7 @@ int launch_solve(TinyBatch* b) {
     const bool soc = soc_active(b);
     SolveArgs a;
     a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0; a.work_counter = nullptr; a.reverse = 0;
-    a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr; a.perm = nullptr;
+    a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr; a.perm = nullptr; a.perm_count = 0;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
     a.status = b->d_status; a.resid = b->d_resid;
@@ -1266,12 +1273,13 @@ int launch_solve(TinyBatch* b) {
         if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
         HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
     }
-    auto launch = [&](const int g) -> int {
+    auto launch = [&](const int g, hipStream_t st = nullptr) -> int {
+        if (!st) st = b->stream;
         if (jit_fn) {
             void* params[] = {&a};
-            HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)g, 1, 1, 64, 1, 1, 0, b->stream, params, nullptr));
+            HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)g, 1, 1, 64, 1, 1, 0, st, params, nullptr));
         } else {
-            hipLaunchKernelGGL(k, dim3(g), dim3(64), 0, b->stream, a);
+            hipLaunchKernelGGL(k, dim3(g), dim3(64), 0, st, a);
             HIP_TRY(b, hipGetLastError());
         }
         return TINY_OK;
@@ -1321,26 +1329,58 @@ int launch_solve(TinyBatch* b) {
         b->last_regroup_stretches = 1;
         if (rk > 0 && rk < steps) {
             if (int rc = ensure_regroup_buffers(b)) return rc;
-            const std::vector<int> stretches = regroup_stretches(steps, rk, b->status_valid);
             const int mask_all = a.store_mask, cold0 = a.cold;
             int* const ilog = a.iter_log; double* const ulog = a.u0_log;
             const bool keep_primal = soc || jk.lin || b->debug;        // (the next stretch reads x|u back: admm.cpp:352-374)
-            int done = 0;
+            const int traj0 = (int)b->traj_step;
             a.reverse = 0;
-            for (size_t c = 0; c < stretches.size(); ++c) {
-                const bool sorted = c > 0 || b->status_valid;
-                if (sorted) { if (int rc = enqueue_regroup_sort(b)) return rc; }
-                a.perm = sorted ? b->d_perm : nullptr;
-                a.steps = stretches[c];
-                a.traj_step0 = (int)b->traj_step + done;
+            int launches = 0;
+            // one stretch: steps [done, done + n) of the instances `first` .. `first + count - 1`, on stream `st`
+            auto stretch = [&](hipStream_t st, const int half, const int first, const int count, const int done, const int n, const bool sorted) -> int {
+                if (sorted) { if (int rc = enqueue_regroup_sort(b, st, half, first, count)) return rc; }
+                a.perm = sorted ? b->d_perm + first : nullptr; a.perm_count = count;
+                a.steps = n;
+                a.traj_step0 = traj0 + done;
                 a.iter_log = ilog ? ilog + (size_t)done * b->batch : nullptr;
                 a.u0_log = ulog ? ulog + (size_t)done * b->batch * b->nu : nullptr;
-                a.cold = c == 0 ? cold0 : 0;
-                a.store_mask = (c + 1 < stretches.size() && !keep_primal) ? (mask_all & ~(1 | 32)) : mask_all;
-                if (int rc = launch(grid)) return rc;
-                done += stretches[c];
+                a.cold = launches == 0 ? cold0 : 0;
+                a.store_mask = (done + n < steps && !keep_primal) ? (mask_all & ~(1 | 32)) : mask_all;
+                ++launches;
+                int g = (count + ipw - 1) / ipw;
+                if (b->grid_waves_per_cu > 0) g = (int)std::min<long>(g, (long)b->num_cus * b->grid_waves_per_cu);
+                return launch(g, st);
+            };
+            int done0 = 0;
+            if (!b->status_valid) {                 // nothing is known about the instances yet: ONE step of all of them tells them apart
+                if (int rc = stretch(b->stream, 0, 0, b->batch, 0, 1, false)) return rc;
+                done0 = 1;
             }
-            b->last_regroup_stretches = (int)stretches.size();
+            const int half0 = ((b->batch / 2 + 7) / 8) * 8;
+            if (b->regroup_streams == 2 && b->stream2 && half0 < b->batch && (b->step_regroup > 0 || b->batch >= 2 * REGROUP_AUTO_MIN_BATCH) && steps - done0 > rk) {
+                // two halves on two streams, the second one half a stretch out of step with the first
+                const int first[2] = {0, half0}, count[2] = {half0, b->batch - half0};
+                const std::vector<int> sched[2] = {regroup_stretches(steps - done0, rk, 0), regroup_stretches(steps - done0, rk, (rk + 1) / 2)};
+                hipStream_t st[2] = {b->stream, b->stream2};
+                HIP_TRY(b, hipEventRecord(b->rg_fork, b->stream));
+                HIP_TRY(b, hipStreamWaitEvent(b->stream2, b->rg_fork, 0));
+                int done[2] = {done0, done0};
+                for (size_t c = 0; c < std::max(sched[0].size(), sched[1].size()); ++c)
+                    for (int h = 0; h < 2; ++h)
+                        if (c < sched[h].size()) {
+                            if (int rc = stretch(st[h], h, first[h], count[h], done[h], sched[h][c], true)) return rc;
+                            done[h] += sched[h][c];
+                        }
+                HIP_TRY(b, hipEventRecord(b->rg_join, b->stream2));
+                HIP_TRY(b, hipStreamWaitEvent(b->stream, b->rg_join, 0));
+            } else {
+                int done = done0;
+                for (const int n : regroup_stretches(steps - done0, rk, 0)) {
+                    if (int rc = stretch(b->stream, 0, 0, b->batch, done, n, true)) return rc;
+                    done += n;
+                }
+            }
+            a.perm = nullptr;
+            b->last_regroup_stretches = launches;
         } else {
             if (int rc = launch(grid)) return rc;
         }
@@ -1578,6 +1618,9 @@ int tiny_batch_destroy(TinyBatch* b) {
     if (b->hist_ev) hipEventDestroy(b->hist_ev);
     if (b->h_ls) hipHostFree(b->h_ls);
     if (b->ls_ev) hipEventDestroy(b->ls_ev);
+    if (b->rg_fork) hipEventDestroy(b->rg_fork);
+    if (b->rg_join) hipEventDestroy(b->rg_join);
+    if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); }
     if (b->auto_ev0) hipEventDestroy(b->auto_ev0);
     if (b->auto_ev1) hipEventDestroy(b->auto_ev1);
     for (hipEvent_t e : b->ev_start) hipEventDestroy(e);
@@ -1988,6 +2031,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
     else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
     else if (!strcmp(name, "step_regroup")) { if (value < -1) return fail(b, TINY_ERR_ARG, "step_regroup: K > 0 (stretches of K MPC steps), 0 (never) or -1 (automatic)"); b->step_regroup = (int)value; b->regroup_verdict = 0; b->regroup_since = 0; b->ls_pending = false; }
+    else if (!strcmp(name, "step_regroup_streams")) { if (value < 1 || value > 2) return fail(b, TINY_ERR_ARG, "step_regroup_streams: 1 or 2"); b->regroup_streams = (int)value; }
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }

@@ -127,6 +127,9 @@ struct TinyBatch {
     int regroup_verdict = 0, regroup_since = 0;    // 0 open, 1 on, -1 off (the estimate of the last fused launch decided)
     bool status_valid = false;                     // d_status holds this episode's last iteration counts (not after setup / reset)
     int* d_perm = nullptr;
+    int regroup_streams = 2;                       // option "step_regroup_streams": 2 = the batch in two halves on two streams, their stretches half a stretch apart
+    hipStream_t stream2 = nullptr;                 // (a half that drains at the end of a stretch leaves its CUs to the other half, which is in the middle of one)
+    hipEvent_t rg_fork = nullptr, rg_join = nullptr;
     unsigned* d_rg_bins = nullptr;                 // 1024 bins of the counting sort
     unsigned long long *d_ls = nullptr, *h_ls = nullptr;   // {4 x sum over waves of the largest total, sum of the totals}
     hipEvent_t ls_ev = nullptr;

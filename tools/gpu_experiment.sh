@@ -1,8 +1,9 @@
 #!/bin/bash
-# step_regroup: parity of the cut launches, K sweep on config 4, the automatic switch on the other cone settings
 O=$1; mkdir -p $O; export O
-timeout 600 python -m pytest tests/test_gpu_regroup.py tests/test_gpu_fused_variants.py -m gpu -x -q > $O/pytest_regroup.txt 2>&1; tail -5 $O/pytest_regroup.txt
-timeout 300 python tools/regroup_bench.py --cones input --ks 0,8,10,15,23,30,45,-1,0 > $O/regroup_input.md 2> $O/regroup_input.err; cat $O/regroup_input.md; tail -3 $O/regroup_input.err
-timeout 300 python tools/regroup_bench.py --cones state --ks 0,-1,23 --reps 3 > $O/regroup_state.md 2> $O/regroup_state.err; cat $O/regroup_state.md; tail -3 $O/regroup_state.err
-timeout 300 python tools/regroup_bench.py --cones both --ks 0,-1 --reps 3 > $O/regroup_both.md 2> $O/regroup_both.err; cat $O/regroup_both.md; tail -3 $O/regroup_both.err
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-regimes --min-seconds 2 > $O/bench_headline.json 2> $O/bench_headline.err; tail -c 700 $O/bench_headline.json
+timeout 800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_variants.py tests/test_gpu_repack.py tests/test_gpu_phases.py tests/test_gpu_regroup.py -m gpu -x -q --durations=12 > $O/pytest_subset.txt 2>&1; tail -22 $O/pytest_subset.txt
+timeout 300 python tools/bench_configs.py config4 > $O/config4.json 2> $O/config4.err; python -c "
+import json,sys
+d=json.loads(open('$O/config4.json').read().split('@@CFG@@')[1])
+e=d.get('config4',d)
+print({k:e.get(k) for k in ('ms','ms_min','ms_max','plain_launch_ms','iters_per_s','step_regroup')}, e.get('roofline',{}).get('frac'))
+"; tail -3 $O/config4.err

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--ks", default="0,10,15,23,30,45,-1,0")
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=2)
     a = ap.parse_args()
     ess, eis = {"input": (0, 1), "state": (1, 0), "both": (1, 1)}[a.cones]
     B = a.batch
@@ -38,6 +39,7 @@ def main():
     steps = m["NTOTAL"] - N
     s.set_option("advance_x0", 1)
     s.set_option("steps_per_launch", steps)
+    s.set_option("step_regroup_streams", a.streams)
 
     def episode():
         s.reset()
@@ -47,6 +49,7 @@ def main():
         s.set_option("timing", 1)
         s.solve_async()
         return float(np.sum(s.timing_ms()))
+    print("streams = %d" % a.streams)
     print("| cones | K | stretches | ms median | ms min | ADMM it/s | lock-step estimate |")
     print("|---|---|---|---|---|---|---|")
     ref = None
