@@ -237,3 +237,37 @@ def test_disk_cache_serves_a_second_process(tmp_path):
     finally:
         del os.environ["TINYMPC_AMD_JIT_CACHE"]
     assert hit and n > 1000
+
+
+@pytest.mark.parametrize("dims", [(20, 4, 10), (8, 3, 50)])
+def test_tile_cone_variant_fused_steps_equal_single_step_launches(dims):
+    """closed loop on the tile kernel's cone variant (the slack in LDS planes, transposed cone step): T fused MPC steps must leave
+    what T single-step launches leave, bit for bit -- the planes are re-initialised from x|u between the steps (admm.cpp:352-357)
+    inside the launch exactly as a new launch initialises them from the records"""
+    nx, nu, N = dims
+    prob = sc.sweep_suite(*dims, B=1)["problem"]
+    rng = np.random.default_rng(5)
+    cfg = sc.default_config(prob, max_iter=30, en_state_soc=1, en_input_soc=1, u_min=-0.5, u_max=0.5,
+                            state_cone=([2], [3], [0.6]), input_cone=([0], [3], [0.8]))
+    cases = sc.zero_cases(prob, 7)
+    cases["x0"] = rng.normal(0, 0.4, cases["x0"].shape)
+    cases["Xref"] = rng.normal(0, 0.2, cases["Xref"].shape)
+    suite = dict(problem=prob, config=cfg, cases=cases)
+    T, outs = 5, []
+    for fused in (0, 1):
+        s = make_batch(suite)
+        assert s.kernel_path() in ("tile", "tile-jit")
+        s.set_option("advance_x0", 1)
+        s.set_x0(cases["x0"]); s.set("Xref", cases["Xref"]); s.set("Uref", cases["Uref"])
+        if fused:
+            s.set_option("steps_per_launch", T)
+            s.solve_async()
+        else:
+            for _ in range(T):
+                s.solve_async()
+        outs.append({k: s.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "zcnew", "gc", "yc", "x0")})
+        outs[-1]["acc"] = s.reduce_stats()[7:9]
+        s.close()
+    assert outs[0]["acc"][0] > T
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

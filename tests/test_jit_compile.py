@@ -14,10 +14,10 @@ VARIANTS = [
     "tinympc_amd::admm_solve_kernel<5, 3, 7, false, false, 2, 0, false, 4>",       # an unseen shape
     "tinympc_amd::admm_solve_kernel<12, 4, 10, true, true, 2, 3, false, 4>",       # cone x debug x both half-space families
     "tinympc_amd::admm_solve_kernel<12, 4, 10, false, false, 2, 1, true, 8>",      # heterogeneous x half-spaces, 8 per knot
-    "tinympc_amd::admm_tile_kernel<20, 4, 10, 2, 1, true>",                         # cones on a wide shape
-    "tinympc_amd::admm_tile_kernel<6, 2, 60, 1, 2, false>",                         # a long horizon outside tile_dims.txt
-    "tinympc_amd::admm_tile_kernel<20, 4, 10, 2, 1, true, 3, 8>",                   # cones + both half-space families, 8 per knot, wide
-    "tinympc_amd::admm_tile_kernel<8, 2, 50, 1, 2, false, 1, 4>",                   # static half-spaces on a long horizon
+    "tinympc_amd::admm_tile_kernel<20, 4, 10, 2, 1, 3>",                            # cones on a wide shape
+    "tinympc_amd::admm_tile_kernel<6, 2, 60, 1, 2, 0>",                            # a long horizon outside tile_dims.txt
+    "tinympc_amd::admm_tile_kernel<20, 4, 10, 2, 1, 1, 3, 8>",                      # cones + both half-space families, 8 per knot, wide
+    "tinympc_amd::admm_tile_kernel<8, 2, 50, 1, 2, 0, 1, 4>",                      # static half-spaces on a long horizon
 ]
 
 CHILD = r'''

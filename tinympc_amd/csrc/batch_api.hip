@@ -449,6 +449,8 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
     hipFunction_t jit_fn = nullptr;
     bool jit_dyn = false;
     const bool soc = soc_active(b);
+    // which families' cone slack is on (the tile kernel's SOC template value): bit 0 inputs, bit 1 states
+    const int socm = ((b->set.en_input_soc && !b->Acu.empty()) ? 1 : 0) | ((b->set.en_state_soc && !b->Acx.empty()) ? 2 : 0);
     const int lv = tile_lin_variant(b);
     int vR = b->tile->R;                             // rows along the horizon of the form this launch takes
     if (b->tile_is_jit || soc || lv) {               // a tile shape outside tile_dims.txt, or a cone / half-space variant: instantiate it now (jit.hpp)
@@ -462,10 +464,10 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         jit_dyn = b->tile_is_jit && !soc && !lv && b->tile_dyn_opt != 0 && jipw >= 2 && b->grid_waves_per_cu <= 0 &&
                   (b->tile_dyn_opt > 0 || (long)((b->batch + jipw - 1) / jipw) >= 16L * b->num_cus);
         if (jit_dyn) {
-            jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, soc, lv, LIN_KMAX, &why, true);
+            jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, LIN_KMAX, &why, true);
             if (!jit_fn) { jit_dyn = false; why.clear(); }
         }
-        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, soc, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
+        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
         if (!jit_fn) {                               // the coverage kernel takes over
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }

@@ -225,11 +225,11 @@ hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
     return get(name, false, err);
 }
 
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, bool soc, int lin, int kmax, std::string* err, bool dyn) {
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn) {
     char name[256];
     // (dyn: the dynamic slot form -- persistent grid, slots draw instances from SolveArgs::work_counter; plain variants only)
-    if (dyn) snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %s, %d, %d, false, 0, true>", nx, nu, N, W, R, soc ? "true" : "false", lin, kmax);
-    else snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", nx, nu, N, W, R, soc ? "true" : "false", lin, kmax);
+    if (dyn) snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d, false, 0, true>", nx, nu, N, W, R, soc, lin, kmax);
+    else snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", nx, nu, N, W, R, soc, lin, kmax);
     return get(name, true, err);
 }
 

@@ -95,15 +95,21 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int 
             (lm == 0 || 8 * tile_lds_bytes(nx, nu, n, w, r, lm, true) <= 158 * 1024)) ? 2 : 1;
 }
 
-// SOC: second-order-cone slacks (admm.cpp:102-135, 228-235) -- two more L-long arrays; this variant is never compiled in,
-// it is instantiated at run time (jit.hpp) when a wide / long shape has a cone switched on.
+// SOC: second-order-cone slacks (admm.cpp:102-135, 228-235); bit 0: the input family's cone slack is on, bit 1: the state family's.
+// This variant is never compiled in, it is instantiated at run time (jit.hpp) when a wide / long shape has a cone switched on.
+// The slack lives in LDS planes and the cone step is TRANSPOSED, as in the one-row kernel (admm_kernel.hip.h): per instance and
+// global slot three planes of one cell per row of the families that are on -- W (x + gc between the forward sweep and the cone
+// step, then vcnew - gc: what the next backward sweep adds to the linear cost), GC (gc | yc), VC (vcnew | zcnew of the cells that
+// belong to an item) -- and lane t of an instance's lanes takes (cone, knot) item t of a pass: ONE inside test / square root /
+// division sequence per pass of LPI items instead of three shuffles and one per knot (round 4: the per-knot form ran at a
+// quarter of the box form's iteration rate, profiles/r04_tile_variants_bench.md).
 // LIN (bit 0 static, bit 1 time-varying half-spaces, admm.cpp:137-211) / KMAX as in admm_kernel.hip.h: two more L-long
 // arrays per family; a'z is the lane-local product summed over the tile's rows by the same FMA chain against ones.
 // UB: the box is the same at every knot -- a lane's two bounds (and the dummy slot's) live in registers, no LDS read per slot.
 // W = 1 shapes compiled with TINYMPC_FUSED_NX / _NU (csrc/Makefile) run the sweeps on the one-row kernel's fused step blocks
 // (fused_backward_step / fused_forward_step: the lane-local instructions of a step sit in front of its DPP chain, no s_nop)
 // and take that kernel's placement of the forward constant (d <- fma(res, nim, cf)).
-template <int NX, int NU, int N, int W, int R, bool SOC = false, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false>
+template <int NX, int NU, int N, int W, int R, int SOC = 0, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W))))
 void admm_tile_kernel(const SolveArgs P) {
@@ -161,12 +167,12 @@ void admm_tile_kernel(const SolveArgs P) {
     const double qr = P.tab[T::VEC + VEC_QR * LW + jj];
     const double smask = P.tab[T::VEC + VEC_SMASK * LW + jj];
     const double nim = P.tab[T::VEC + VEC_NIM * LW + jj];
-    double socmask = 0.0, cone_mu_d = 0.0;
+    double socmask = 0.0;
     int cone_base = -1;
+    auto g0_of = [](const int h) { return h * L; };
     if constexpr (SOC) {
         socmask = P.tab[T::VEC + VEC_SOCFLAG * LW + jj];               // 1.0 on the rows of a family whose cone slack is on
         cone_base = (int)P.tab[T::VEC + VEC_CONE_BASE * LW + jj];      // first ROW of this row's cone, or -1
-        cone_mu_d = P.tab[T::VEC + VEC_CONE_MU * LW + jj];
     }
     bool lin_lane = false, tlin_lane = false;
     if constexpr (LS) lin_lane = P.tab[T::VEC + VEC_LINFLAG * LW + jj] != 0.0;
@@ -175,11 +181,54 @@ void admm_tile_kernel(const SolveArgs P) {
 #pragma unroll
     for (int k = 0; k < (LIN ? NZ : 1); ++k) ones[k] = 1.0;
     const bool soc_lane = socmask != 0.0, proj_lane = soc_lane && cone_base >= 0;
-    const int cone_c = proj_lane ? jj - cone_base : 0;
-    const float cone_mu = (float)cone_mu_d;                            // admm.cpp:39 takes mu as float
-    // lane that holds knot-vector row r of THIS instance and horizon row (the cone may straddle the two W rows)
-    const int group_lane0 = ((lane >> 4) - wrow) * 16;     // (cone variants only: never with half rows)
-    auto lane_of_row = [&](const int r) { return group_lane0 + (r >> 4) * 16 + (r & 15); };
+    // ---- cone slack planes (see the header): CR cells per slot and plane, one per row of the families that are on; every other
+    // lane shares the pad cell CR (it only ever holds zeros); a slot is 3 CSR doubles, an ODD number: the item gathers of a pass
+    // (stride = one slot) fall into distinct LDS banks.  + a dummy slot whose item (0, 0, 1) the lanes without an item project
+    // (onto itself): no EXEC-mask region around the gather / scatter of a pass.
+    constexpr int CR = ((SOC & 2) ? NX : 0) + ((SOC & 1) ? NU : 0);
+    constexpr int CSR = SOC ? ((CR + 1) | 1) : 1, SLOT_C = 3 * CSR, PL_GC = CSR, PL_VC = 2 * CSR;
+    constexpr int C_ROW0 = (SOC == 1) ? NX : 0;                         // the row that owns cell 0
+    __shared__ double sC[SOC ? (IPW * N + 1) * SLOT_C : 1];
+    const int cell = (soc_lane && jj >= C_ROW0 && jj - C_ROW0 < CR) ? jj - C_ROW0 : CR;
+    const int cw0 = (inst * N + g0_of(hrow)) * SLOT_C + cell;           // W cell of this lane's first own slot (slot l: + l * SLOT_C)
+    // (cone, knot) items of an instance, dealt out to its LPI lanes 16 ... 64 per pass: item t = cone by cone (ascending first
+    // row), a state cone has N items (slots 0 .. N-1), an input cone N-1 (slots 1 .. N-1).  All instances of a wave share the layout.
+    constexpr int SOC_ITEMS = ((SOC & 2) ? (NX / 3) * N : 0) + ((SOC & 1) ? (NU / 3) * (N - 1) : 0);
+    constexpr int SOC_PASSES = SOC ? (SOC_ITEMS > 0 ? (SOC_ITEMS + LPI - 1) / LPI : 1) : 1;
+    int item_at[SOC_PASSES];
+    float item_mu[SOC_PASSES], item_rmu[SOC_PASSES];
+    bool mu_pow2 = true;
+    int soc_passes = 0;
+    if constexpr (SOC) {
+        if (lane < 3) {
+            sC[IPW * N * SLOT_C + lane] = lane == 2 ? 1.0 : 0.0;
+            sC[IPW * N * SLOT_C + PL_GC + lane] = 0.0;
+            sC[IPW * N * SLOT_C + PL_VC + lane] = lane == 2 ? 1.0 : 0.0;
+        }
+        // first rows of the cones: instance 0's first horizon row holds row jj in lane jj
+        const unsigned heads = (unsigned)(__builtin_amdgcn_ballot_w64(proj_lane && jj == cone_base && inst == 0 && hrow == 0) & 0xFFFFFFFFull);
+        int total = 0;
+        for (unsigned m = heads; m; m &= m - 1) total += (__builtin_ctz(m) < NX) ? N : N - 1;
+#pragma unroll
+        for (int p = 0; p < SOC_PASSES; ++p) {
+            int t = p * LPI + (lane - inst * LPI);
+            item_at[p] = IPW * N * SLOT_C; item_mu[p] = 1.0f;
+            if (p * LPI < total) soc_passes = p + 1;
+            for (unsigned m = heads; m; m &= m - 1) {
+                const int hb = __builtin_ctz(m);
+                const int cnt = hb < NX ? N : N - 1;
+                if (t >= 0 && t < cnt) {
+                    item_at[p] = (inst * N + t + (hb < NX ? 0 : 1)) * SLOT_C + (hb - C_ROW0);
+                    item_mu[p] = (float)P.tab[T::VEC + VEC_CONE_MU * LW + hb];
+                    t = -1;
+                } else if (t >= 0) t -= cnt;
+            }
+            item_rmu[p] = 1.0f / item_mu[p];
+            const unsigned mb_ = __float_as_uint(item_mu[p]);
+            const bool p2 = (mb_ & 0x807FFFFFu) == 0u && (mb_ >> 23) >= 127u - 60u && (mb_ >> 23) <= 127u + 60u;
+            if (__builtin_amdgcn_ballot_w64(!p2) != 0ull) mu_pow2 = false;
+        }
+    }
     const double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -191,7 +240,8 @@ void admm_tile_kernel(const SolveArgs P) {
     const int ntiles = (P.batch + IPW - 1) / IPW;
     // ---- the state of this lane's instance (one instance per SLOT of RPI rows; IPW slots per wave)
     double G[L], VN[L], VP[(VL_ || VG) ? 1 : L], QX[(QL || QR) ? 1 : L], Dn[DL ? 1 : L];
-    double VC[SOC ? L : 1], GC[SOC ? L : 1];
+    bool gcz[SOC_PASSES];                                              // SOC: the GC cells of this lane's item of pass p are known to be zero
+    bool gc_own_dirty = false;                                         // SOC: this lane's own GC cells outside every item may hold a loaded value
     double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
     double ref_last = 0.0, x0v = 0.0, x1v = 0.0, x0_last = 0.0, rp = 0.0, rd = 0.0;   // x1v: slot 1 (x_1 | u_0) of the last sweep; x0_last: the x0 the last solve started from
     int b = 0, iter = 0, solved = 0, checked = 0, countdown = 0, step = 0;
@@ -244,8 +294,11 @@ void admm_tile_kernel(const SolveArgs P) {
                 if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else if constexpr (!QR) QX[l] = -(r * qr);
                 if constexpr (DL) sD[l * SLOT + li] = 0.0; else Dn[l] = 0.0;
                 if constexpr (SOC) {
-                    VC[l] = (valid && soc_lane) ? P.prim[off] : 0.0;                    // vcnew = x, zcnew = u (admm.cpp:352-357)
-                    GC[l] = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                    const double vc0 = (valid && soc_lane) ? P.prim[off] : 0.0;         // vcnew = x, zcnew = u (admm.cpp:352-357)
+                    const double gc0 = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                    sC[cw0 + l * SLOT_C] = vc0 - gc0;
+                    sC[cw0 + l * SLOT_C + PL_GC] = gc0;
+                    sC[cw0 + l * SLOT_C + PL_VC] = vc0;
                 }
                 if constexpr (LS) { VL[l] = (valid && lin_lane) ? P.prim[off] : 0.0; GL[l] = (valid && lin_lane) ? P.ldual[off] : 0.0; }     // :361-365
                 if constexpr (LT) { VT[l] = (valid && tlin_lane) ? P.prim[off] : 0.0; GT[l] = (valid && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
@@ -273,6 +326,7 @@ void admm_tile_kernel(const SolveArgs P) {
             }
 
             have = true; step = 0; acc_iter = 0; acc_solved = 0; checked = 0; rp = 0.0; rd = 0.0; x1v = 0.0;
+            if constexpr (SOC) gc_own_dirty = true;
         }
         if (__ballot(have) == 0ull) break;
         bool start = fresh;                                             // a solve begins: this instance's first, or its next fused MPC step
@@ -281,11 +335,13 @@ void admm_tile_kernel(const SolveArgs P) {
                 iter = 0; solved = 0; countdown = P.check_termination;
                 x0_last = x0v;
                 if constexpr (SOC) {
-                    if (step > 0) {                                        // vcnew = x, zcnew = u of the previous solve
-#pragma unroll
-                        for (int l = 0; l < L; ++l) VC[l] = soc_lane ? sX[l * 64 + lane] : 0.0;
+                    if (hrow == 0 && is_state && soc_lane) {               // x[:,0] = x0
+                        sC[cw0] = x0v - sC[cw0 + PL_GC];
+                        sC[cw0 + PL_VC] = x0v;
                     }
-                    if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
+#pragma unroll
+                    for (int p = 0; p < SOC_PASSES; ++p) gcz[p] = false;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
                 if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
                     if (step > 0) {
@@ -326,8 +382,17 @@ void admm_tile_kernel(const SolveArgs P) {
 #pragma unroll
                             for (int d = 0; d < QD; ++d) rq[d] = (L - 1 - d == 0 ? rpp0 : rpp)[(L - 1 - d) * NZ];
                         }
+                        // SOC: vcnew - gc of slot l out of its W cell, two steps ahead of its use (one wave per SIMD: see QX above)
+                        double wa = 0.0, wb = 0.0;
+                        if constexpr (SOC) { wa = sC[cw0 + (L - 1) * SLOT_C]; wb = sC[cw0 + (L - 2) * SLOT_C]; }
 #pragma unroll
                         for (int l = L - 1; l >= 0; --l) {
+                            double wl = 0.0;
+                            if constexpr (SOC) {
+                                wl = wa; wa = wb;
+                                if (l >= 2) wb = sC[cw0 + (l - 2) * SLOT_C];
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                             double qxl;
                             if constexpr (QL) {
                                 qxl = qa; qa = qb;
@@ -340,7 +405,7 @@ void admm_tile_kernel(const SolveArgs P) {
                                 if (l == L - 1) qxl = (hrow == R - 1 && is_state) ? qx_term : qxl;
                             } else qxl = QX[l];
                             double qlo = fma(-rho, VN[l] - G[l], qxl);                  // admm.cpp:267 | :280 | :293
-                            if constexpr (SOC) qlo = fma(-rho, VC[l] - GC[l], qlo);     // :269 | :282 | :295
+                            if constexpr (SOC) qlo = fma(-rho, wl, qlo);                // :269 | :282 | :295
                             if constexpr (LS) qlo = fma(-rho, VL[l] - GL[l], qlo);      // :272 | :285 | :298
                             if constexpr (LT) qlo = fma(-rho, VT[l] - GT[l], qlo);      // :275 | :288 | :301
                             if (ph == R - 1 && l == L - 1) {
@@ -389,6 +454,8 @@ void admm_tile_kernel(const SolveArgs P) {
                         double da = 0.0, db = 0.0, va = 0.0, vb = 0.0;   // Dn / v|z in LDS: read two steps ahead (see the backward sweep)
                         if constexpr (DL) { da = sD[li]; db = sD[SLOT + li]; }
                         if constexpr (VL_) { va = sV[li]; vb = sV[SLOT + li]; }
+                        double ga = 0.0, gb = 0.0;                      // SOC: gc of slot l out of its GC cell, likewise
+                        if constexpr (SOC) { ga = sC[cw0 + PL_GC]; gb = sC[cw0 + SLOT_C + PL_GC]; }
 #pragma unroll
                         for (int l = 0; l < L; ++l) {
                             const int g = ph * L + l;
@@ -406,7 +473,12 @@ void admm_tile_kernel(const SolveArgs P) {
                             if constexpr (!UB) {
                                 lo_n = (l + 1 < L) ? sLo[(g + 1) * LW + jj] : 0.0; hi_n = (l + 1 < L) ? sHi[(g + 1) * LW + jj] : 0.0;
                             }
-                            if constexpr (!UB || DL || VL_) __builtin_amdgcn_sched_barrier(0);   // (pins the reads ABOVE this step: the compiler otherwise sinks them to their use)
+                            double gcl = 0.0;
+                            if constexpr (SOC) {
+                                gcl = ga; ga = gb;
+                                if (l + 2 < L) gb = sC[cw0 + (l + 2) * SLOT_C + PL_GC];
+                            }
+                            if constexpr (!UB || DL || VL_ || SOC != 0) __builtin_amdgcn_sched_barrier(0);   // (pins the reads ABOVE this step: the compiler otherwise sinks them to their use)
                             const double xi = xcur;
                             if constexpr (KEEPX) sX[l * 64 + lane] = xi;
                             if constexpr (DEFER) {                                       // the chains only; the slot update follows the sweep
@@ -460,16 +532,10 @@ void admm_tile_kernel(const SolveArgs P) {
                             } else dmax = vmax_abs64(dmax, VP[l] - vn);
                             G[l] = tt - vn;
                             VN[l] = vn;
-                            if constexpr (SOC) {
-                                const double tc = fma(xi, socmask, GC[l]);              // x + gc on the cone-slack rows, else 0
-                                const int base = proj_lane ? cone_base : jj;
-                                const double s0 = __shfl(tc, lane_of_row(base)), s1 = __shfl(tc, lane_of_row(base + 1)),
-                                             s2 = __shfl(tc, lane_of_row(base + 2));
-                                double vc = tc;
-                                if (proj_lane && (is_state || g >= 1)) vc = soc_component(s0, s1, s2, tc, cone_c, cone_mu);   // :112-135
-                                GC[l] = tc - vc;                                        // :229 / :234
-                                VC[l] = vc;
-                            }
+                            // vcnew = x + gc on every row of a family whose cone slack is on (:102-109), projected after the sweep, one
+                            // lane per (cone, knot): the cone step below.  A cell outside every item keeps this value as its vcnew.
+                            // (only the lanes that own a cell write: the pad the others share must stay zero whatever an instance diverges to)
+                            if constexpr (SOC) { if (soc_lane) sC[cw0 + l * SLOT_C] = fma(xi, socmask, gcl); }
                             if constexpr (LIN != 0) {
                                 // half-spaces applied one after the other, only when violated (admm.cpp:148-173, 186-211)
                                 auto halfspaces = [&](double z, const double* tabk, const int nk) {
@@ -523,6 +589,46 @@ void admm_tile_kernel(const SolveArgs P) {
                         VN[l] = vn;
                     }
                 }
+                if constexpr (SOC) {
+                    // ---- cone step (admm.cpp:112-135, 228-235), transposed: x + gc of every slot went to the W plane above; lane t of
+                    // pass p gathers the three components of its (cone, knot) item, projects them and writes the item's cells
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int p = 0; p < SOC_PASSES; ++p) {
+                        if (p > 0 && p >= soc_passes) break;               // wave-uniform
+                        const int at = item_at[p];
+                        const double s0 = sC[at], s1 = sC[at + 1], s2 = sC[at + 2];
+                        if (soc_all_inside(s0, s1, s2, item_mu[p])) {
+                            // no cone of the wave's iterating instances is active: vcnew = x + gc bit for bit, gc = 0, and vcnew - gc is
+                            // what the forward sweep left in W.  VC takes its copy; the GC cells are zeroed once per solve
+                            sC[at + PL_VC] = s0; sC[at + PL_VC + 1] = s1; sC[at + PL_VC + 2] = s2;
+                            if (!gcz[p]) {
+                                sC[at + PL_GC] = 0.0; sC[at + PL_GC + 1] = 0.0; sC[at + PL_GC + 2] = 0.0;
+                                gcz[p] = true;
+                            }
+                        } else {
+                            double r0, r1, r2;
+                            soc_project3(s0, s1, s2, item_mu[p], item_rmu[p], mu_pow2, r0, r1, r2);
+                            const double g0c = s0 - r0, g1c = s1 - r1, g2c = s2 - r2;   // :229 / :234  (gc + x) - vcnew
+                            sC[at + PL_VC] = r0; sC[at + PL_VC + 1] = r1; sC[at + PL_VC + 2] = r2;
+                            sC[at + PL_GC] = g0c; sC[at + PL_GC + 1] = g1c; sC[at + PL_GC + 2] = g2c;
+                            sC[at] = r0 - g0c; sC[at + 1] = r1 - g1c; sC[at + 2] = r2 - g2c;   // vcnew - gc: the next backward sweep's term
+                            gcz[p] = false;
+                        }
+                    }
+                    // this lane's own cells outside every item (a family row that belongs to no cone): vcnew = x + gc, so
+                    // gc = (x + gc) - vcnew = 0 from the first iteration on, whatever the warm start held there
+                    if (gc_own_dirty) {
+                        if (soc_lane && !proj_lane) {
+#pragma unroll
+                            for (int l = 0; l < L; ++l) sC[cw0 + l * SLOT_C + PL_GC] = 0.0;
+                        }
+                        gc_own_dirty = false;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 iter += 1;
                 if (countdown > 0 && --countdown == 0) {
                     countdown = P.check_termination;
@@ -560,11 +666,17 @@ void admm_tile_kernel(const SolveArgs P) {
                     iter = 0; solved = 0; countdown = P.check_termination;
                     x0_last = x0v;
                     if constexpr (SOC) {
-                        if (true) {                                        // vcnew = x, zcnew = u of the previous solve
+                        if (soc_lane) {                                    // vcnew = x, zcnew = u of the previous solve (admm.cpp:352-357); x[:,0] = x0
 #pragma unroll
-                            for (int l = 0; l < L; ++l) VC[l] = soc_lane ? sX[l * 64 + lane] : 0.0;
+                            for (int l = 0; l < L; ++l) {
+                                const double vc0 = (l == 0 && hrow == 0 && is_state) ? x0v : sX[l * 64 + lane];
+                                sC[cw0 + l * SLOT_C] = vc0 - sC[cw0 + l * SLOT_C + PL_GC];
+                                sC[cw0 + l * SLOT_C + PL_VC] = vc0;
+                            }
                         }
-                        if (hrow == 0 && is_state && soc_lane) VC[0] = x0v;   // x[:,0] = x0
+#pragma unroll
+                        for (int p = 0; p < SOC_PASSES; ++p) gcz[p] = false;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     }
                     if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
                         if (true) {
@@ -631,7 +743,14 @@ void admm_tile_kernel(const SolveArgs P) {
                         P.slack[off] = VN[l];
                         P.dual[off] = G[l];
                         if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else if constexpr (!VG) P.slack_prev[off] = VP[l];
-                        if constexpr (SOC) { if (soc_lane) { P.cslack[off] = VC[l]; P.cdual[off] = GC[l]; } }
+                        if constexpr (SOC) {
+                            // vcnew: the VC plane where the cell belongs to an item (or no iteration ran: what the solve started from),
+                            // else what the last forward sweep left in the W plane
+                            if (soc_lane) {
+                                P.cslack[off] = sC[cw0 + l * SLOT_C + ((proj_lane || iter == 0) ? PL_VC : 0)];
+                                P.cdual[off] = sC[cw0 + l * SLOT_C + PL_GC];
+                            }
+                        }
                         if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
                         if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
                     }
@@ -682,7 +801,7 @@ template <int NX, int NU, int N, int W, int R, int LMREQ, bool UB, bool DYN = fa
 constexpr TileKernelFn tile_kernel_or_null() {
     // LMREQ (6th column of tile_dims.txt): 99 = the rule above; else that very set, if one wave's static LDS holds it
     constexpr int lm = LMREQ == 99 ? tile_best_lm(NX, NU, N, W, R, UB) : (tile_lds_bytes(NX, NU, N, W, R, LMREQ, UB) <= TILE_LDS_STATIC_LIMIT ? LMREQ : -1);
-    if constexpr (lm >= 0) return admm_tile_kernel<NX, NU, N, W, R, false, 0, LIN_KMAX, UB, (lm >= 0 ? lm : 0), DYN>;
+    if constexpr (lm >= 0) return admm_tile_kernel<NX, NU, N, W, R, 0, 0, LIN_KMAX, UB, (lm >= 0 ? lm : 0), DYN>;
     else return nullptr;
 }
 

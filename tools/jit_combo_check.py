@@ -15,9 +15,9 @@ for (nx, nu, N) in ((5, 3, 7), (12, 4, 10), (8, 4, 30)):
             mode = 2
             names.append(f"tinympc_amd::admm_solve_kernel<{nx}, {nu}, {N}, {b(soc)}, {b(dbg)}, {mode}, {lin}, {b(het)}, {kmax}>")
 for (nx, nu, N, W, R) in ((20, 4, 10, 2, 1), (6, 2, 60, 1, 2), (12, 8, 30, 2, 2), (16, 8, 6, 2, 1)):
-    for soc, lin in itertools.product((0, 1), (0, 1, 2, 3)):
+    for soc, lin in itertools.product((0, 1, 2, 3), (0, 1, 2, 3)):      # (tile SOC: bit 0 input family, bit 1 state family)
         for kmax in ((4,) if lin == 0 else (4, 16)):
-            names.append(f"tinympc_amd::admm_tile_kernel<{nx}, {nu}, {N}, {W}, {R}, {b(soc)}, {lin}, {kmax}>")
+            names.append(f"tinympc_amd::admm_tile_kernel<{nx}, {nu}, {N}, {W}, {R}, {soc}, {lin}, {kmax}>")
 print(len(names), "instantiations", flush=True)
 bad = 0
 t0 = time.time()
