@@ -453,6 +453,20 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
     const int socm = ((b->set.en_input_soc && !b->Acu.empty()) ? 1 : 0) | ((b->set.en_state_soc && !b->Acx.empty()) ? 2 : 0);
     const int lv = tile_lin_variant(b);
     int vR = b->tile->R;                             // rows along the horizon of the form this launch takes
+    // the tile tables follow the problem's generation, not the one-row path's dirty flag: a one-row shape whose clock-decided
+    // dispatch keeps the tile form launches it from INSIDE path 0, after upload_tables() has cleared tab_dirty
+    if (b->ttab_gen != b->tab_gen || b->h_ttab.empty()) {
+        b->ttab_gen = b->tab_gen;
+        if (b->tile->W <= 1) build_tile_tables_w<1>(b); else build_tile_tables_w<2>(b);      // (W = 0, half rows, reads the one-row tables)
+        if (b->ttab_doubles < b->h_ttab.size()) {
+            if (b->d_ttab) (void)hipFree(b->d_ttab);
+            b->d_ttab = nullptr;
+            HIP_TRY(b, hipMalloc(&b->d_ttab, b->h_ttab.size() * sizeof(double)));
+            b->ttab_doubles = b->h_ttab.size();
+        }
+        HIP_TRY(b, hipMemcpyAsync(b->d_ttab, b->h_ttab.data(), b->h_ttab.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
+    const bool ub = b->tile_bounds_uniform && b->use_ub;
     if (b->tile_is_jit || soc || lv) {               // a tile shape outside tile_dims.txt, or a cone / half-space variant: instantiate it now (jit.hpp)
         std::string why;
         // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
@@ -467,26 +481,13 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
             jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, LIN_KMAX, &why, true);
             if (!jit_fn) { jit_dyn = false; why.clear(); }
         }
-        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, &why);
+        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, &why, false, ub && (soc || lv));
         if (!jit_fn) {                               // the coverage kernel takes over
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }
             b->tab_dirty = true;
             return launch_solve(b);
         }
-    }
-    // the tile tables follow the problem's generation, not the one-row path's dirty flag: a one-row shape whose clock-decided
-    // dispatch keeps the tile form launches it from INSIDE path 0, after upload_tables() has cleared tab_dirty
-    if (b->ttab_gen != b->tab_gen || b->h_ttab.empty()) {
-        b->ttab_gen = b->tab_gen;
-        if (b->tile->W <= 1) build_tile_tables_w<1>(b); else build_tile_tables_w<2>(b);      // (W = 0, half rows, reads the one-row tables)
-        if (b->ttab_doubles < b->h_ttab.size()) {
-            if (b->d_ttab) (void)hipFree(b->d_ttab);
-            b->d_ttab = nullptr;
-            HIP_TRY(b, hipMalloc(&b->d_ttab, b->h_ttab.size() * sizeof(double)));
-            b->ttab_doubles = b->h_ttab.size();
-        }
-        HIP_TRY(b, hipMemcpyAsync(b->d_ttab, b->h_ttab.data(), b->h_ttab.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
     SolveArgs a;
     a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0;
@@ -509,7 +510,6 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         if (int rc = ensure_step_logs(b, steps)) return rc;
         a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
     }
-    const bool ub = b->tile_bounds_uniform && b->use_ub;
     const TileEntry* te = jit_fn ? nullptr : pick_tile_entry(b, ub);
     if (!jit_fn && !te) return fail(b, TINY_ERR_UNSUPPORTED, "no compiled-in tile kernel form for (%d,%d,%d)", b->nx, b->nu, b->N);
     if (te) vR = te->R;

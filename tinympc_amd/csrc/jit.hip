@@ -141,6 +141,21 @@ Code compile(const std::string& name_s, const bool tile) {
         if (lt != std::string::npos && sscanf(name_s.c_str() + lt + 1, "%d , %d", &fnx, &fnu) == 2 && fnx > 0 && fnu > 0 && fnx + fnu <= 16)
             src = "#define TINYMPC_FUSED_NX " + std::to_string(fnx) + "\n#define TINYMPC_FUSED_NU " + std::to_string(fnu) + "\n" + src;
     }
+    // experiments: TINYMPC_AMD_JIT_DEFINES="NAME=value;NAME2=value2" puts those macros in front of the kernel source (not part of
+    // the disk cache's key: do not combine the two)
+    if (const char* defs = getenv("TINYMPC_AMD_JIT_DEFINES")) {
+        std::string d(defs), pre;
+        size_t a = 0;
+        while (a < d.size()) {
+            size_t e = d.find(';', a);
+            if (e == std::string::npos) e = d.size();
+            std::string one = d.substr(a, e - a);
+            const size_t eq = one.find('=');
+            if (!one.empty()) pre += "#define " + (eq == std::string::npos ? one : one.substr(0, eq) + " " + one.substr(eq + 1)) + "\n";
+            a = e + 1;
+        }
+        src = pre + src;
+    }
     const char* hn[] = {"admm_kernel.hip.h", "tile_kernel.hip.h"};
     const char* hs[] = {hdr.c_str(), kTileKernelSrc};
     Rtc::Program prog = nullptr;
@@ -225,11 +240,11 @@ hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
     return get(name, false, err);
 }
 
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn) {
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn, bool ub) {
     char name[256];
     // (dyn: the dynamic slot form -- persistent grid, slots draw instances from SolveArgs::work_counter; plain variants only)
     if (dyn) snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d, false, 0, true>", nx, nu, N, W, R, soc, lin, kmax);
-    else snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", nx, nu, N, W, R, soc, lin, kmax);
+    else snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d%s>", nx, nu, N, W, R, soc, lin, kmax, ub ? ", true" : "");
     return get(name, true, err);
 }
 

@@ -95,6 +95,20 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int 
             (lm == 0 || 8 * tile_lds_bytes(nx, nu, n, w, r, lm, true) <= 158 * 1024)) ? 2 : 1;
 }
 
+// waves per SIMD of a cone variant (five L-long arrays in registers, the trajectory, the bound tables and the three slack planes in
+// LDS): two when the arrays + matrix rows fit 256 VGPRs (same measured threshold as the box forms) and eight waves' LDS fits the CU
+constexpr long tile_soc_lds_bytes(int nx, int nu, int n, int w, int r, int soc, bool ub) {
+    const int cr = ((soc & 2) ? nx : 0) + ((soc & 1) ? nu : 0), csr = (cr + 1) | 1, ipw = 4 / (w * r);
+    return 8L * (2L * (ub ? 2 : n) * 16 * w + (n / r) * 64 + (long)(ipw * n + 1) * 3 * csr);
+}
+#ifndef TINYMPC_TILE_SOC_WAVES
+#define TINYMPC_TILE_SOC_WAVES 0                   // (experiments: 1 / 2 instead of the rule)
+#endif
+constexpr int tile_soc_waves(int nx, int nu, int n, int w, int r, int soc, bool ub) {
+    if (TINYMPC_TILE_SOC_WAVES > 0) return TINYMPC_TILE_SOC_WAVES;
+    return (2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 276 && 8 * tile_soc_lds_bytes(nx, nu, n, w, r, soc, ub) <= 158 * 1024) ? 2 : 1;
+}
+
 // SOC: second-order-cone slacks (admm.cpp:102-135, 228-235); bit 0: the input family's cone slack is on, bit 1: the state family's.
 // This variant is never compiled in, it is instantiated at run time (jit.hpp) when a wide / long shape has a cone switched on.
 // The slack lives in LDS planes and the cone step is TRANSPOSED, as in the one-row kernel (admm_kernel.hip.h): per instance and
@@ -111,14 +125,15 @@ constexpr int tile_waves_per_simd(int nx, int nu, int n, int r, int lm = 0, int 
 // and take that kernel's placement of the forward constant (d <- fma(res, nim, cf)).
 template <int NX, int NU, int N, int W, int R, int SOC = 0, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu((SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W), (SOC || LIN) ? 1 : tile_waves_per_simd(NX, NU, N, R, LM, W))))
+__attribute__((amdgpu_waves_per_eu(LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : tile_waves_per_simd(NX, NU, N, R, LM, W)),
+                                   LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : tile_waves_per_simd(NX, NU, N, R, LM, W)))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr bool HR = W == 0;                                        // half rows: two instances per DPP row (nx+nu <= 8)
     constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
     constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
-    constexpr bool TFUSED = W == 1 && !SOC && LIN == 0 && fused_shape(NX, NU);
+    constexpr bool TFUSED = W == 1 && LIN == 0 && fused_shape(NX, NU);
     constexpr int NB = UB ? 2 : N;                                     // UB: slots 0 and 1 speak for all
     constexpr bool QL = (LM & TILE_LM_QX) != 0, DL = (LM & TILE_LM_DN) != 0, VL_ = (LM & TILE_LM_VP) != 0, VG = (LM & TILE_LM_VPG) != 0,
                    QR = (LM & TILE_LM_QXR) != 0;
@@ -412,7 +427,8 @@ void admm_tile_kernel(const SolveArgs P) {
                                 pcur = qlo;                                             // p_{N-1}
                             } else if constexpr (TFUSED) {
                                 double q2, res;                                         // (q2 == qlo: the block forms it again in front of its chain)
-                                fused_backward_step<NX, NU>(q2, res, VN[l], G[l], qxl, rho, smask, cb, pcur, qhi, mb, mb + NX);
+                                if constexpr (SOC != 0) fused_backward_step_soc<NX, NU>(q2, res, VN[l], G[l], qxl, wl, rho, smask, cb, pcur, qhi, mb, mb + NX);
+                                else fused_backward_step<NX, NU>(q2, res, VN[l], G[l], qxl, rho, smask, cb, pcur, qhi, mb, mb + NX);
                                 pcur = res;
                                 const double dn = fma(res, nim, cf);                    // input lanes: -d_i; state lanes: fdyn
                                 if constexpr (DL) sD[l * SLOT + li] = dn; else Dn[l] = dn;

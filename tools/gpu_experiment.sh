@@ -1,4 +1,6 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 800 python -m pytest tests/test_gpu_jit.py -m gpu -q --durations=5 > $O/pytest_jit.txt 2>&1; tail -30 $O/pytest_jit.txt
-timeout 600 python tools/tile_variants_bench.py > $O/tile_variants_bench.md 2> $O/tile_variants_bench.err; cat $O/tile_variants_bench.md; tail -3 $O/tile_variants_bench.err
+for w in 0 2; do
+echo "== TINYMPC_TILE_SOC_WAVES=$w"
+TINYMPC_AMD_JIT_DEFINES="TINYMPC_TILE_SOC_WAVES=$w" timeout 600 python tools/tile_variants_bench.py > $O/tile_variants_w$w.md 2> $O/tile_variants_w$w.err; grep "cone" $O/tile_variants_w$w.md; tail -12 $O/tile_variants_w$w.err
+done

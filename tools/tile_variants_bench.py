@@ -17,6 +17,8 @@ for (nx, nu, N) in ((12, 8, 10), (12, 8, 30), (20, 8, 30), (12, 4, 50)):
     Ax = rng.standard_normal((2, nx)); bx = np.full(2, 2.0)
     Au = rng.standard_normal((2, nu)); bu = np.full(2, 0.4)
     for name, cone, lin in (("box", 0, 0), ("box + input cone", 1, 0), ("box + 2 + 2 half-spaces", 0, 1), ("box + cone + half-spaces", 1, 1)):
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+            continue
         s = tm.TinyBatchSolver.from_problem(prob, B)
         s.set_bound_constraints(np.full((nx, 1), -1e17), np.full((nx, 1), 1e17), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
         if cone:
@@ -36,3 +38,4 @@ for (nx, nu, N) in ((12, 8, 10), (12, 8, 30), (20, 8, 30), (12, 4, 50)):
         except Exception as e:                            # noqa: BLE001
             print(f"| ({nx},{nu},{N}) | {name} | failed: {e!r} | | | | | |", flush=True)
         s.close()
+print("\nrun-time instantiated:", *tm.jit_used(), sep="\n  ", file=sys.stderr)
