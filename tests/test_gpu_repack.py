@@ -39,6 +39,7 @@ def test_split_solve_is_bit_identical(name, caps):
     for cap in caps:
         same(whole, run_cases_hip(suite, debug=True, options={"repack_after": cap}), (name, cap))
     same(run_cases_hip(suite), run_cases_hip(suite, options={"repack_after": caps[0]}), (name, "no debug"))
+    same(whole, run_cases_hip(suite, debug=True, options={"repack_after": caps[0], "repack_sort": 1}), (name, "sorted stage lists"))
 
 
 def test_split_solve_with_a_coarse_termination_check():
@@ -80,9 +81,20 @@ def test_split_solve_large_divergent_batch_and_statistics():
         same(whole, run({"repack_after": cap}), cap)
     # the stage schedule (K, 2K, 4K, ... | K, 4K, 16K, ... | K, max_iter) and the way a follow-up stage hands out its tiles (fixed grid
     # stride | one atomic per tile off the stage's counter, fewer waves than tiles) change nothing either
+    # ... nor does the ORDER of a stage's list ("repack_sort": by residual / tolerance, so that rows which are equally far out share a wave)
     for opts in ({"repack_growth": 2}, {"repack_growth": 4}, {"repack_growth": 64}, {"repack_dynamic": 1, "repack_waves_per_cu": 1},
-                 {"repack_dynamic": 1, "repack_growth": 4, "repack_waves_per_cu": 2}, {"repack_dynamic": 0, "repack_waves_per_cu": 1}):
+                 {"repack_dynamic": 1, "repack_growth": 4, "repack_waves_per_cu": 2}, {"repack_dynamic": 0, "repack_waves_per_cu": 1},
+                 {"repack_sort": 1}, {"repack_sort": 1, "repack_growth": 4}, {"repack_sort": 0}, {"repack_sort": 1, "repack_dynamic": 1}):
         same(whole, run(dict(opts, repack_after=8)), opts)
+    s = make_batch(suite)
+    s.set_option("repack_after", 8); s.set_option("repack_sort", 1)
+    s.set_x0(suite["cases"]["x0"]); s.set("Xref", suite["cases"]["Xref"]); s.set("Uref", suite["cases"]["Uref"])
+    s.solve()
+    assert s.get_option("repack_sorted_stages") >= 2
+    s.set_option("repack_sort", -1)                   # automatic, no histogram to predict the stages from: not sorted
+    s.reset(); s.solve()
+    assert s.get_option("repack_sorted_stages") == 0
+    s.close()
     ref = sc.run_cases(OracleSolver, dict(base, cases={k: v[:32] for k, v in base["cases"].items()}))
     assert np.array_equal(whole["iter"][:32].astype(int), ref["iter"].astype(int))
 

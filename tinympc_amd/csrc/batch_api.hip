@@ -784,16 +784,21 @@ static double predicted_time(const unsigned* hist, int max_iter, int cap, int gr
     return t;
 }
 
+// one wave-iteration (4 instances) of the one-row kernel in microseconds: its FLOPs at ~75 % of a SIMD's FP64 issue rate (76.8 GFLOP/s
+// per SIMD), shared by the waves of the SIMD -- 1.7 us for the quadrotor at two waves (measured 1.64)
+static double wave_iteration_us(int nx, int nu, int N, int wps) {
+    const double S = (double)nx * N + (double)nu * (N - 1);
+    const double fl = 4.0 * S + 2.0 * nx * nx + 3.0 * nx + (N - 1.0) * (4.0 * nx * nx + 8.0 * nx * nu + 2.0 * nu * nu + 4.0 * nu + 5.0 * nx) + 11.0 * S;
+    return 4.0 * fl * wps / (76.8e3 * (wps == 2 ? 0.75 : 0.45));
+}
 // the K (multiple of check_termination) with the smallest predicted time, 0 when a plain launch is within 5 % of it
 static int choose_split_for(int nx, int nu, int N, bool soc, int M, int ct, int gr, int num_cus, const unsigned* hist, double* ratio, int* growth_out = nullptr) {
     const int wps = solve_kernel_waves_per_simd(nx + nu, N, soc);
     const double slots = (double)num_cus * 4.0 * wps;         // wave slots of the chip
-    // one wave-iteration (4 instances) in microseconds: its FLOPs at ~75 % of a SIMD's FP64 issue rate (76.8 GFLOP/s per SIMD),
-    // shared by the waves of the SIMD -- 1.7 us for the quadrotor at two waves (measured 1.64); the fixed costs of a
-    // stage in that unit: ~8 us of launch latency, and the record reload + store (2.45 us per wave for the quadrotor's 156 slots)
+    // one wave-iteration in microseconds (above); the fixed costs of a stage in that unit: ~8 us of launch latency, and the record
+    // reload + store (2.45 us per wave for the quadrotor's 156 slots)
     const double S = (double)nx * N + (double)nu * (N - 1);
-    const double fl = 4.0 * S + 2.0 * nx * nx + 3.0 * nx + (N - 1.0) * (4.0 * nx * nx + 8.0 * nx * nu + 2.0 * nu * nu + 4.0 * nu + 5.0 * nx) + 11.0 * S;
-    const double t_it = 4.0 * fl * wps / (76.8e3 * (wps == 2 ? 0.75 : 0.45));
+    const double t_it = wave_iteration_us(nx, nu, N, wps);
     const double launch_iters = 8.0 / t_it, reload_iters = 2.45 * (S / 156.0) / t_it;
     const double plain = predicted_time(hist, M, 0, 2, slots, launch_iters, reload_iters);
     double best = plain;
@@ -973,6 +978,51 @@ __global__ __launch_bounds__(256) void regroup_scatter_kernel(const int4* status
         __syncthreads();
     }
 }
+// ---- repack_sort: the open instances of a split solve's stage by their distance from the tolerances.  Key = the larger of
+// primal residual / tol_pri and dual residual / tol_dua (d_resid: what the stage before left at its last test), 16 bins per octave
+// from 2^-8 up; a residual that is not a positive number (a diverged instance) goes in front with the largest
+__device__ __forceinline__ int repack_key(const double* resid, const int b, const double rtp, const double rtd) {
+    const double4 r = *reinterpret_cast<const double4*>(resid + (size_t)b * 4);
+    const double m = fmax(fmax(r.x, r.y) * rtp, fmax(r.z, r.w) * rtd);
+    if (!(m > 0.0) || !(m < 1e300)) return RG_BINS - 1;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(m);
+    const int k = (int)((u >> 48) & 0x7FFFull) - ((1023 - 8) << 4);        // exponent and the mantissa's top four bits
+    return k < 0 ? 0 : (k > RG_BINS - 2 ? RG_BINS - 2 : k);
+}
+__global__ __launch_bounds__(256) void repack_hist_kernel(const int* list, const int* count, const double* resid, double rtp, double rtd, unsigned* bins) {
+    __shared__ unsigned h[RG_BINS];
+    for (int i = threadIdx.x; i < RG_BINS; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    const int n = *count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&h[repack_key(resid, list[i], rtp, rtd)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RG_BINS; i += blockDim.x)
+        if (h[i]) atomicAdd(&bins[i], h[i]);
+}
+__global__ __launch_bounds__(256) void repack_scatter_kernel(const int* list, const int* count, const double* resid, double rtp, double rtd, unsigned* bins, int* out) {
+    __shared__ unsigned base[RG_BINS], rank[RG_BINS];
+    const int n = *count;
+    for (int c0 = blockIdx.x * 1024; c0 < n; c0 += gridDim.x * 1024) {
+        for (int i = threadIdx.x; i < RG_BINS; i += 256) { base[i] = 0u; rank[i] = 0u; }
+        __syncthreads();
+        int key[4], inst[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = c0 + e * 256 + threadIdx.x;
+            inst[e] = i < n ? list[i] : -1;
+            key[e] = i < n ? repack_key(resid, inst[e], rtp, rtd) : -1;
+            if (key[e] >= 0) atomicAdd(&base[key[e]], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < RG_BINS; i += 256)
+            if (base[i]) base[i] = atomicAdd(&bins[i], base[i]);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (key[e] >= 0) out[base[key[e]] + atomicAdd(&rank[key[e]], 1u)] = inst[e];
+        __syncthreads();
+    }
+}
 // what lock step costs a batch whose waves take the instances four by four in their natural order, by the iteration totals each
 // instance has accumulated (d_accum): out[0] += rows x the largest total of every group of four, out[1] += the totals
 __global__ __launch_bounds__(256) void lockstep_estimate_kernel(const uint2* accum, int batch, unsigned long long* out) {
@@ -989,10 +1039,10 @@ __global__ __launch_bounds__(256) void lockstep_estimate_kernel(const uint2* acc
     for (int off = 32; off >= 1; off >>= 1) { m += __shfl_xor(m, off); t += __shfl_xor(t, off); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], m); atomicAdd(&out[1], t); }
 }
-static int ensure_regroup_buffers(TinyBatch* b) {
+static int ensure_regroup_buffers(TinyBatch* b, bool second_stream) {
     if (!b->d_perm) HIP_TRY(b, hipMalloc(&b->d_perm, (size_t)b->batch * sizeof(int)));
     if (!b->d_rg_bins) HIP_TRY(b, hipMalloc(&b->d_rg_bins, 2 * RG_BINS * sizeof(unsigned)));
-    if (b->regroup_streams == 2 && !b->stream2) {
+    if (second_stream && b->regroup_streams == 2 && !b->stream2) {
         HIP_TRY(b, hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
         HIP_TRY(b, hipEventCreateWithFlags(&b->rg_fork, hipEventDisableTiming));
         HIP_TRY(b, hipEventCreateWithFlags(&b->rg_join, hipEventDisableTiming));
@@ -1008,6 +1058,18 @@ static int enqueue_regroup_sort(TinyBatch* b, hipStream_t st, int half, int firs
     hipLaunchKernelGGL(regroup_hist_kernel, dim3(blocks), dim3(256), 0, st, b->d_status + first, count, bins);
     hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(RG_BINS), 0, st, bins);
     hipLaunchKernelGGL(regroup_scatter_kernel, dim3(blocks), dim3(256), 0, st, b->d_status + first, count, first, bins, b->d_perm + first);
+    HIP_TRY(b, hipGetLastError());
+    return TINY_OK;
+}
+// d_perm <- list[0 .. *count) ordered by repack_key, largest first (on the batch's stream)
+static int enqueue_repack_sort(TinyBatch* b, const int* list, const int* count) {
+    unsigned* bins = b->d_rg_bins;
+    HIP_TRY(b, hipMemsetAsync(bins, 0, RG_BINS * sizeof(unsigned), b->stream));
+    const int blocks = std::max(1, std::min(128, (b->batch + 1023) / 1024));
+    const double rtp = 1.0 / b->set.abs_pri_tol, rtd = 1.0 / b->set.abs_dua_tol;
+    hipLaunchKernelGGL(repack_hist_kernel, dim3(blocks), dim3(256), 0, b->stream, list, count, b->d_resid, rtp, rtd, bins);
+    hipLaunchKernelGGL(regroup_scan_kernel, dim3(1), dim3(RG_BINS), 0, b->stream, bins);
+    hipLaunchKernelGGL(repack_scatter_kernel, dim3(blocks), dim3(256), 0, b->stream, list, count, b->d_resid, rtp, rtd, bins, b->d_perm);
     HIP_TRY(b, hipGetLastError());
     return TINY_OK;
 }
@@ -1220,6 +1282,7 @@ int launch_solve(TinyBatch* b) {
         if (b->auto_verdict == 0) {                   // (a kept split keeps its K; a rejected one stays rejected until the options change)
             b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
             b->auto_cap_max_iter = a.max_iter;
+            b->hist_copy.assign(b->h_hist, b->h_hist + TinyBatch::HIST_BINS);
         }
     }
     // The same batch on the tile kernel's dynamic slot form (its one-row layout, tile_dims.txt): persistent waves whose rows take
@@ -1296,6 +1359,8 @@ int launch_solve(TinyBatch* b) {
     if (a.check_termination > 1) cap -= cap % a.check_termination;
     if (cap > 0 && cap < a.max_iter && split_ok) {
         if (int rc = ensure_repack_buffers(b)) return rc;
+        if (b->repack_sort != 0) { if (int rc = ensure_regroup_buffers(b, false)) return rc; }
+        b->last_sorted_stages = 0;
         HIP_TRY(b, hipMemsetAsync(b->d_repack_count, 0, 2 * MAX_STAGES * sizeof(int), b->stream));
         const int full = a.max_iter;
         int stage = 0;
@@ -1313,6 +1378,26 @@ int launch_solve(TinyBatch* b) {
             a.next_count = last ? nullptr : b->d_repack_count + stage + 1;
             // fewer waves than tiles: each takes its next tile off the stage's counter when it is free (repack_dynamic = 0: fixed grid stride)
             a.work_counter = b->repack_dynamic ? b->d_repack_count + MAX_STAGES + stage : nullptr;
+            // "repack_sort": the stage takes its list ordered by residual / tolerance (see batch_impl.hpp) when the stage is long enough
+            // to pay for the three small passes (~25 us; measured: (4,4,10) x 131 072, stages of 40-100 us, loses 10 % to them, (12,2,30)
+            // gains 11 %) -- predicted as in choose_split_for from the histogram the schedule came from, >= 300 us; without one: never
+            bool sort_stage = b->repack_sort > 0;
+            if (b->repack_sort < 0 && b->hist_copy.size() == (size_t)TinyBatch::HIST_BINS) {
+                double open = 0.0, depth = 0.0;              // instances that enter the stage; iterations they run inside it, summed
+                const long hi = last ? full : gr * base;
+                for (long i = base + 1; i < TinyBatch::HIST_BINS; ++i) {
+                    open += b->hist_copy[i];
+                    depth += (double)b->hist_copy[i] * (double)(std::min<long>(i, hi) - base);
+                }
+                const int wps = solve_kernel_waves_per_simd(b->nx + b->nu, b->N, soc);
+                sort_stage = depth / 4.0 / (b->num_cus * 4.0 * wps) * wave_iteration_us(b->nx, b->nu, b->N, wps) >= 300.0;
+                (void)open;
+            }
+            if (sort_stage) {
+                if (int rc = enqueue_repack_sort(b, a.index, a.count)) return rc;
+                a.index = b->d_perm;
+                b->last_sorted_stages++;
+            }
             if (int rc = launch(std::min(grid, b->num_cus * b->repack_waves_per_cu))) return rc;
             if (last) break;
         }
@@ -1330,7 +1415,7 @@ int launch_solve(TinyBatch* b) {
         const int rk = !regroup_ok ? 0 : (b->step_regroup > 0 ? b->step_regroup : ((regroup_auto && b->regroup_verdict == 1) ? regroup_auto_k(steps) : 0));
         b->last_regroup_stretches = 1;
         if (rk > 0 && rk < steps) {
-            if (int rc = ensure_regroup_buffers(b)) return rc;
+            if (int rc = ensure_regroup_buffers(b, true)) return rc;
             const int mask_all = a.store_mask, cold0 = a.cold;
             int* const ilog = a.iter_log; double* const ulog = a.u0_log;
             const bool keep_primal = soc || jk.lin || b->debug;        // (the next stretch reads x|u back: admm.cpp:352-374)
@@ -2037,9 +2122,10 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
-    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_pending = false; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
+    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_copy.clear(); b->hist_pending = false; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);
     else if (!strcmp(name, "repack_growth")) { b->repack_growth = (int)value; b->growth_verdict = 0; }
+    else if (!strcmp(name, "repack_sort")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "repack_sort: 1, 0 or -1 (automatic)"); b->repack_sort = (int)value; }
     else if (!strcmp(name, "repack_dynamic")) b->repack_dynamic = value != 0;   // follow-up stages: tiles off a counter (1) or a fixed grid stride (0)
     else if (!strcmp(name, "traj_step")) b->traj_step = value;
     else if (!strcmp(name, "timing")) {
@@ -2137,6 +2223,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
             if (b->auto_verdict == 0) {                        // (a decided batch keeps its K AND the stage schedule the clock chose)
                 b->auto_cap = choose_split(b, b->h_hist, &b->auto_gain);
                 b->auto_cap_max_iter = b->set.max_iter;
+                b->hist_copy.assign(b->h_hist, b->h_hist + TinyBatch::HIST_BINS);
             }
         }
         return b->auto_cap;
@@ -2151,6 +2238,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form
     if (!strcmp(name, "auto_split_measured_permille")) return (b->auto_plain_rate > 0.0 && b->auto_split_rate > 0.0) ? (long)(1000.0 * b->auto_split_rate / b->auto_plain_rate + 0.5) : 0;
     if (!strcmp(name, "repack_after")) return b->repack_after;
+    if (!strcmp(name, "repack_sorted_stages")) return b->last_sorted_stages;       // follow-up stages of the last split solve that took a sorted list
     if (!strcmp(name, "step_regroup")) return b->step_regroup;
     if (!strcmp(name, "step_regroup_stretches")) return b->last_regroup_stretches;   // launches the last fused solve was cut into (1: not cut)
     if (!strcmp(name, "step_regroup_verdict") || !strcmp(name, "lockstep_permille")) {

@@ -108,6 +108,13 @@ struct TinyBatch {
     int repack_waves_per_cu = 8, repack_growth = 0;   // grid of the follow-up stages; stage s runs to K * growth^s (0: the cost model picks 2 or 4 with K)
     int auto_growth = 2, growth_alt = 2, growth_verdict = 0;   // the stage schedule in use; the one on trial; 1 = the clock has compared the two
     bool probe_was_growth = false;
+    // repack_sort: the list of open instances a stage of a split solve takes is ordered by how far each is from its tolerances
+    // (largest residual / tolerance ratio first; 16 bins per octave, a counting sort between the stages): ADMM converges at a roughly
+    // geometric rate, so rows that are equally far out leave their wave together.  1: every follow-up stage; 0: never; -1 (default):
+    // the stages that the last iteration histogram says at least 16 384 instances enter
+    int repack_sort = -1;
+    std::vector<unsigned> hist_copy;     // the histogram the schedule in use was derived from (h_hist is overwritten asynchronously)
+    int last_sorted_stages = 0;
     int *d_repack_index = nullptr, *d_repack_count = nullptr;
     bool use_ub = true;                            // option "uniform_bounds": take the UB kernel variant when the box allows it
     bool bounds_uniform = false;                   // build_tables: every knot has the same box (admm_kernel.hip.h UB variant)
@@ -127,8 +134,12 @@ struct TinyBatch {
     int regroup_verdict = 0, regroup_since = 0;    // 0 open, 1 on, -1 off (the estimate of the last fused launch decided)
     bool status_valid = false;                     // d_status holds this episode's last iteration counts (not after setup / reset)
     int* d_perm = nullptr;
-    int regroup_streams = 2;                       // option "step_regroup_streams": 2 = the batch in two halves on two streams, their stretches half a stretch apart
-    hipStream_t stream2 = nullptr;                 // (a half that drains at the end of a stretch leaves its CUs to the other half, which is in the middle of one)
+    // option "step_regroup_streams": 2 = the batch in two halves on two streams, their stretches half a stretch apart (a half that
+    // drains at the end of a stretch leaves its CUs to the other half, which is in the middle of one): config 4 27.0 ms against 27.4 on
+    // one stream.  NOT the default: a second stream in the process costs every launch-bound path of the batch ~10 % ((4,4,10) split
+    // solve, seven launches of 100-300 us: 1.69 -> 1.85 ms while the stream merely exists)
+    int regroup_streams = 1;
+    hipStream_t stream2 = nullptr;
     hipEvent_t rg_fork = nullptr, rg_join = nullptr;
     unsigned* d_rg_bins = nullptr;                 // 1024 bins of the counting sort
     unsigned long long *d_ls = nullptr, *h_ls = nullptr;   // {4 x sum over waves of the largest total, sum of the totals}

@@ -1,6 +1,8 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-for w in 0 2; do
-echo "== TINYMPC_TILE_SOC_WAVES=$w"
-TINYMPC_AMD_JIT_DEFINES="TINYMPC_TILE_SOC_WAVES=$w" timeout 600 python tools/tile_variants_bench.py > $O/tile_variants_w$w.md 2> $O/tile_variants_w$w.err; grep "cone" $O/tile_variants_w$w.md; tail -12 $O/tile_variants_w$w.err
+timeout 800 python -m pytest tests/test_gpu_repack.py -m gpu -x -q > $O/pytest_repack.txt 2>&1; tail -5 $O/pytest_repack.txt
+CELLS="12,4,10;12,2,10;8,4,10;4,4,10;12,4,30;8,2,30;12,2,30"
+for opt in "repack_sort=0" "repack_sort=-1"; do
+echo "== $opt"
+TINYMPC_OPTS="$opt" timeout 600 python tools/sweep_bench.py --reps 10 --cells "$CELLS" > $O/sweep_$opt.md 2> $O/sweep_$opt.err; grep "^| [0-9]" $O/sweep_$opt.md | cut -d'|' -f2-8,11; tail -2 $O/sweep_$opt.err
 done
