@@ -1253,7 +1253,10 @@ int launch_solve(TinyBatch* b) {
     enum { MAX_STAGES = 32 };
     const bool split_ok = steps == 1 && !a.x0_next && !b->one_shot && !b->adaptive && a.check_termination > 0 && a.max_iter >= 16;
     const bool auto_split = b->repack_after < 0 && split_ok && b->batch >= 8192;
-    if (auto_split) { if (int rc = ensure_repack_buffers(b)) return rc; }      // (not inside a timed probe: the first split solve's clock reading must not pay for a hipMalloc)
+    if (auto_split) {                                // (not inside a timed probe: the first split solve's clock reading must not pay for a hipMalloc)
+        if (int rc = ensure_repack_buffers(b)) return rc;
+        if (b->repack_sort != 0) { if (int rc = ensure_regroup_buffers(b, false)) return rc; }
+    }
     if (auto_split && b->hist_pending && hipEventQuery(b->hist_ev) == hipSuccess) {
         b->hist_pending = false;
         // the clock's word on the previous eligible solve: microseconds per instance-iteration, plain or split
@@ -1379,8 +1382,9 @@ int launch_solve(TinyBatch* b) {
             // fewer waves than tiles: each takes its next tile off the stage's counter when it is free (repack_dynamic = 0: fixed grid stride)
             a.work_counter = b->repack_dynamic ? b->d_repack_count + MAX_STAGES + stage : nullptr;
             // "repack_sort": the stage takes its list ordered by residual / tolerance (see batch_impl.hpp) when the stage is long enough
-            // to pay for the three small passes (~25 us; measured: (4,4,10) x 131 072, stages of 40-100 us, loses 10 % to them, (12,2,30)
-            // gains 11 %) -- predicted as in choose_split_for from the histogram the schedule came from, >= 300 us; without one: never
+            // to pay for the three small passes (~20 us) -- predicted as in choose_split_for from the histogram the schedule came
+            // from, >= 60 us (measured at 131 072 instances: (4,4,10), stages of 100-150 us, gains 4 % from sorting every stage,
+            // (12,2,30) 14 %; config 3's follow-up stages, 5 % of the batch for ~25 us, stay as they are); without a histogram: never
             bool sort_stage = b->repack_sort > 0;
             if (b->repack_sort < 0 && b->hist_copy.size() == (size_t)TinyBatch::HIST_BINS) {
                 double open = 0.0, depth = 0.0;              // instances that enter the stage; iterations they run inside it, summed
@@ -1390,7 +1394,7 @@ int launch_solve(TinyBatch* b) {
                     depth += (double)b->hist_copy[i] * (double)(std::min<long>(i, hi) - base);
                 }
                 const int wps = solve_kernel_waves_per_simd(b->nx + b->nu, b->N, soc);
-                sort_stage = depth / 4.0 / (b->num_cus * 4.0 * wps) * wave_iteration_us(b->nx, b->nu, b->N, wps) >= 300.0;
+                sort_stage = depth / 4.0 / (b->num_cus * 4.0 * wps) * wave_iteration_us(b->nx, b->nu, b->N, wps) >= 60.0;
                 (void)open;
             }
             if (sort_stage) {

@@ -111,7 +111,7 @@ struct TinyBatch {
     // repack_sort: the list of open instances a stage of a split solve takes is ordered by how far each is from its tolerances
     // (largest residual / tolerance ratio first; 16 bins per octave, a counting sort between the stages): ADMM converges at a roughly
     // geometric rate, so rows that are equally far out leave their wave together.  1: every follow-up stage; 0: never; -1 (default):
-    // the stages that the last iteration histogram says at least 16 384 instances enter
+    // the stages that the last iteration histogram predicts to run for at least 60 us
     int repack_sort = -1;
     std::vector<unsigned> hist_copy;     // the histogram the schedule in use was derived from (h_hist is overwritten asynchronously)
     int last_sorted_stages = 0;
@@ -134,11 +134,11 @@ struct TinyBatch {
     int regroup_verdict = 0, regroup_since = 0;    // 0 open, 1 on, -1 off (the estimate of the last fused launch decided)
     bool status_valid = false;                     // d_status holds this episode's last iteration counts (not after setup / reset)
     int* d_perm = nullptr;
-    // option "step_regroup_streams": 2 = the batch in two halves on two streams, their stretches half a stretch apart (a half that
-    // drains at the end of a stretch leaves its CUs to the other half, which is in the middle of one): config 4 27.0 ms against 27.4 on
-    // one stream.  NOT the default: a second stream in the process costs every launch-bound path of the batch ~10 % ((4,4,10) split
-    // solve, seven launches of 100-300 us: 1.69 -> 1.85 ms while the stream merely exists)
-    int regroup_streams = 1;
+    // option "step_regroup_streams": 2 (default) = the batch in two halves on two streams, their stretches half a stretch apart (a
+    // half that drains at the end of a stretch leaves its CUs to the other half, which is in the middle of one): config 4 27.0 ms
+    // against 27.4 on one stream; joined back into the batch's stream before the solve call returns.  (A second stream in the process
+    // costs the launch-bound paths nothing: tools/second_stream_probe.py.)
+    int regroup_streams = 2;
     hipStream_t stream2 = nullptr;
     hipEvent_t rg_fork = nullptr, rg_join = nullptr;
     unsigned* d_rg_bins = nullptr;                 // 1024 bins of the counting sort
