@@ -133,6 +133,17 @@ static int variant_tile_r(const TinyBatch* b) {
         if (g_tiles[i]->nx == b->nx && g_tiles[i]->nu == b->nu && g_tiles[i]->N == b->N) r = g_tiles[i]->R;
     return r;
 }
+// R of a cone variant (no half-spaces): its slack lives in LDS planes, so five L-long arrays are all a lane holds -- the smallest R
+// whose arrays fit the register file of one wave per SIMD and whose planes + trajectory fit the wave's static LDS (a horizon
+// split over R rows leaves all but one of them idle in the sweeps)
+static int cone_variant_tile_r(const TinyBatch* b, int socm, bool ub) {
+    const int w = std::max(1, b->tile->W), nz = b->nx + b->nu;
+    for (int r = 1; r <= 4 / w; r *= 2) {
+        if (b->N % r || b->N / r < 2) continue;
+        if (2 * (5 * (b->N / r) + 2 * nz) + 44 + 24 <= 512 && tile_soc_lds_bytes(b->nx, b->nu, b->N, w, r, socm, ub) <= 60 * 1024) return r;
+    }
+    return variant_tile_r(b);
+}
 static const TileEntry* pick_tile_entry(const TinyBatch* b, bool ub) {
     const TileEntry* first_ok = nullptr;
     for (int i = 0; i < g_ntiles; ++i) {
@@ -471,7 +482,8 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         std::string why;
         // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
         // register / LDS budget of THAT form, not from the compiled-in plain form's entry)
-        if (!b->tile_is_jit) vR = variant_tile_r(b);
+        if (!b->tile_is_jit) vR = (soc && !lv) ? cone_variant_tile_r(b, socm, ub) : variant_tile_r(b);
+        if (b->tile_r > 0 && (soc || lv)) vR = b->tile_r;           // (option "tile_r": experiments)
         // a shape outside tile_dims.txt with plain box constraints: large batches of more than one instance per wave take the dynamic
         // slot form too (instantiated on first use like the static one; a failure falls back to the static form)
         const int jipw = 4 / (std::max(1, b->tile->W) * vR);

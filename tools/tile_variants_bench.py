@@ -26,6 +26,8 @@ for (nx, nu, N) in ((12, 8, 10), (12, 8, 30), (20, 8, 30), (12, 4, 50)):
         if lin:
             s.set_linear_constraints(Ax, bx, Au, bu)
         s.update_settings(max_iter=200, en_input_soc=cone, en_state_linear=lin, en_input_linear=lin)
+        if os.environ.get("TILE_R") and (cone or lin):
+            s.set_option("tile_r", int(os.environ["TILE_R"]))            # experiments: rows along the horizon of the variant form
         s.set_x0(x0); s.set_x_ref(xr)
         ms = []
         try:
