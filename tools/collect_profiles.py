@@ -37,7 +37,9 @@ copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", 
           ("counters", "kernel_counters.md", "kernel_counters_table.md"),      # (rNN_kernel_counters.md = this table + its reading)
           ("probes", "warm_order.md", "warm_launch_order.md"), ("probes", "warm_order_batches.md", "warm_launch_order_batches.md"),
           ("probes", "soc_iter_cost.txt", "soc_iter_cost.txt"), ("probes", "half_rows_bench.md", "half_rows_bench.md"),
-          ("cfgtraffic", "configs_traffic.json", "configs_traffic.json")]
+          ("cfgtraffic", "configs_traffic.json", "configs_traffic.json"),
+          ("probes4", "regroup_input_s1.md", "regroup_config4_one_stream.md"), ("probes4", "regroup_input_s2.md", "regroup_config4_two_streams.md"),
+          ("probes4", "tile_variants_bench.md", "tile_variants_bench.md"), ("probes4", "second_stream_probe.md", "second_stream_probe.md")]
 for stage, name, dst in copies:
     src = os.path.join(OUT, stage, name)
     if os.path.exists(src):

@@ -36,7 +36,7 @@ for f in sorted(glob.glob(os.path.join(d, "*_fetch.json"))):
     out[name] = {"hbm_bytes_per_instance_launch": hbm, "fetch_bytes_x2": 2 * tot["fetch"] / n, "write_bytes": tot["write"] / n,
                  "algorithmic_bytes_per_solve": e["hbm"]["algorithmic_bytes_per_solve"], "ratio_traffic_over_algorithmic": hbm / e["hbm"]["algorithmic_bytes_per_solve"],
                  "instance_launches_in_the_profiled_run": n, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE around `python tools/bench_configs.py %s` (tools/gpu_stage.sh cfgtraffic)" % name,
-                 "note": "per instance and launch (one cold solve; config 4: one fused 90-step episode -- the records move once per launch); L2-fabric-side counters: Infinity-Cache hits included"}
+                 "note": "per instance and launch (one cold solve; config 4: one fused 90-step EPISODE -- the records move once per launch, i.e. once per stretch where step_regroup cuts the episode); L2-fabric-side counters: Infinity-Cache hits included"}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
 t.setdefault("configs", {}).update(out)

@@ -12,6 +12,7 @@
 #   counters     rocprofv3 SQ / HBM counters of the sweep and cone kernels -> kernel_counters.md
 #   cfgtraffic   FETCH_SIZE / WRITE_SIZE per solve of every `configs` entry of the bench line -> profiles/traffic.json[configs]
 #   probes       warm-regime launch order table, cone iteration cost, half-row forms (round 4)
+#   probes4      config 4 in stretches (step_regroup) per K and stream count, the tile kernel's cone / half-space variants, the second-stream probe
 #   exp          whatever tools/gpu_experiment.sh holds (kernel experiments of the moment)
 set +e
 export TMPDIR=/tmp
@@ -47,7 +48,7 @@ for stage in "$@"; do
     configs)
       timeout 900 python tools/config_bench.py $O/configs_3_4.json > $O/configs.out 2> $O/configs.err; tail -c 800 $O/configs.out ;;
     sweep)
-      timeout 1500 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json --parity $O/sweep_parity.md > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md; tail -3 $O/sweep_parity.md ;;
+      timeout 1500 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json  > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md; tail -3 $O/sweep_parity.md ;;
     adaptive)
       timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt
       timeout 300 python tools/adaptive_bench.py > $O/adaptive_bench_run.txt 2>&1; tail -2 $O/adaptive_bench_run.txt ;;
@@ -79,6 +80,11 @@ for stage in "$@"; do
       BATCHES=16384,32768,65536,131072 QUICK=1 timeout 600 python tools/warm_order_probe.py > $O/warm_order_batches.md 2>&1
       timeout 300 python tools/soc_iter_cost.py > $O/soc_iter_cost.txt 2>&1; cat $O/soc_iter_cost.txt
       timeout 600 python tools/half_rows_bench.py > $O/half_rows_bench.md 2>&1; cat $O/half_rows_bench.md ;;
+    probes4)
+      # round 4, second half: config 4 uncut / in stretches (one and two streams), the tile kernel's cone / half-space variants, other streams
+      for st in 1 2; do timeout 300 python tools/regroup_bench.py --streams $st --cones input --ks 0,15,23,30,45,-1 > $O/regroup_input_s$st.md 2> $O/regroup_input_s$st.err; cat $O/regroup_input_s$st.md; done
+      timeout 600 python tools/tile_variants_bench.py > $O/tile_variants_bench.md 2> $O/tile_variants_bench.err; cat $O/tile_variants_bench.md
+      timeout 300 python tools/second_stream_probe.py > $O/second_stream_probe.md 2>&1 ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
