@@ -133,16 +133,43 @@ static int variant_tile_r(const TinyBatch* b) {
         if (g_tiles[i]->nx == b->nx && g_tiles[i]->nu == b->nu && g_tiles[i]->N == b->N) r = g_tiles[i]->R;
     return r;
 }
-// R of a cone variant (no half-spaces): its slack lives in LDS planes, so five L-long arrays are all a lane holds -- the smallest R
-// whose arrays fit the register file of one wave per SIMD and whose planes + trajectory fit the wave's static LDS (a horizon
-// split over R rows leaves all but one of them idle in the sweeps)
-static int cone_variant_tile_r(const TinyBatch* b, int socm, bool ub) {
+// the box is the same at every knot (what build_tables / build_tile_tables_w find out from the tables they build; here from the
+// host copies of the bounds, for decisions that are taken before a table exists)
+static bool box_is_uniform(const TinyBatch* b) {
+    if (b->N < 2) return false;
+    if (!b->have_bounds) return true;
+    const int nx = b->nx, nu = b->nu, N = b->N;
+    if (b->set.en_state_bound)
+        for (int i = 1; i < N; ++i)
+            for (int j = 0; j < nx; ++j)
+                if (b->x_min[(size_t)i * nx + j] != b->x_min[j] || b->x_max[(size_t)i * nx + j] != b->x_max[j]) return false;
+    if (b->set.en_input_bound)
+        for (int i = 1; i < N - 1; ++i)
+            for (int a = 0; a < nu; ++a)
+                if (b->u_min[(size_t)i * nu + a] != b->u_min[a] || b->u_max[(size_t)i * nu + a] != b->u_max[a]) return false;
+    return true;
+}
+// static LDS of a cone / half-space variant of the tile kernel at (w, r): bound tables (the UB form keeps two slots), the trajectory,
+// the cone slack's three planes (rows of the families that are on), two planes per half-space set (all rows) and the sets' tables
+static long variant_tile_lds_bytes(const TinyBatch* b, int w, int r, int socm, int lv, int km, bool ub) {
+    const long LW = 16L * w, N = b->N, ipw = 4 / (w * r), nz = b->nx + b->nu;
+    const long cr = ((socm & 2) ? b->nx : 0) + ((socm & 1) ? b->nu : 0), csr = (cr + 1) | 1, csl = (nz + 1) | 1;
+    long d = 2L * (ub ? 2 : N) * LW + (N / r) * 64;
+    if (socm) d += (ipw * N + 1) * 3 * csr;
+    if (lv & 1) d += 3L * km * LW + 2L * ipw * N * csl;
+    if (lv & 2) d += 3L * N * km * LW + 2L * ipw * N * csl;
+    return 8L * d;
+}
+// R of a cone / half-space variant of a compiled-in shape: its slacks live in LDS planes, so five L-long arrays are all a lane
+// holds -- the smallest R whose arrays fit the register file of one wave per SIMD and whose planes, tables and trajectory fit the
+// wave's static LDS (a horizon split over R rows leaves all but one of them idle in the sweeps); 0: none does
+static int budget_variant_tile_r(const TinyBatch* b, int socm, int lv, int km, bool ub) {
     const int w = std::max(1, b->tile->W), nz = b->nx + b->nu;
     for (int r = 1; r <= 4 / w; r *= 2) {
         if (b->N % r || b->N / r < 2) continue;
-        if (2 * (5 * (b->N / r) + 2 * nz) + 44 + 24 <= 512 && tile_soc_lds_bytes(b->nx, b->nu, b->N, w, r, socm, ub) <= 60 * 1024) return r;
+        if (2 * (5 * (b->N / r) + 2 * nz) + 44 + 24 <= 512 && variant_tile_lds_bytes(b, w, r, socm, lv, km, ub) <= TILE_LDS_STATIC_LIMIT) return r;
     }
-    return variant_tile_r(b);
+    return 0;
 }
 static const TileEntry* pick_tile_entry(const TinyBatch* b, bool ub) {
     const TileEntry* first_ok = nullptr;
@@ -428,10 +455,11 @@ static int tile_lin_variant(const TinyBatch* b) {
     const int km = lin_kmax(b);
     if (km == 0) return 0;
     const int lv = ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
-    const long LW = 16L * std::max(1, b->tile->W);
-    const int r2 = b->tile_is_jit ? b->tile->R : variant_tile_r(b);
-    const long lds = 8L * (2L * b->N * LW + (long)(b->N / r2) * 64 + ((lv & 1) ? 3L * km * LW : 1) + ((lv & 2) ? 3L * b->N * km * LW : 1));
-    return lds <= 60 * 1024 ? lv : 0;
+    // (the form must exist at some R for the families that are on)
+    const int socm = ((b->set.en_input_soc && !b->Acu.empty()) ? 1 : 0) | ((b->set.en_state_soc && !b->Acx.empty()) ? 2 : 0);
+    const bool ub = b->use_ub && box_is_uniform(b);
+    if (b->tile_is_jit) return variant_tile_lds_bytes(b, std::max(1, b->tile->W), b->tile->R, socm, lv, km, ub) <= TILE_LDS_STATIC_LIMIT ? lv : 0;
+    return budget_variant_tile_r(b, socm, lv, km, ub) > 0 ? lv : 0;
 }
 static bool cones_overlap(const TinyBatch* b);
 static bool use_tile(const TinyBatch* b) {
@@ -482,7 +510,10 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         std::string why;
         // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
         // register / LDS budget of THAT form, not from the compiled-in plain form's entry)
-        if (!b->tile_is_jit) vR = (soc && !lv) ? cone_variant_tile_r(b, socm, ub) : variant_tile_r(b);
+        if (!b->tile_is_jit) {
+            vR = budget_variant_tile_r(b, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, ub);
+            if (vR == 0) vR = variant_tile_r(b);
+        }
         if (b->tile_r > 0 && (soc || lv)) vR = b->tile_r;           // (option "tile_r": experiments)
         // a shape outside tile_dims.txt with plain box constraints: large batches of more than one instance per wave take the dynamic
         // slot form too (instantiated on first use like the static one; a failure falls back to the static form)

@@ -101,6 +101,7 @@ constexpr long tile_soc_lds_bytes(int nx, int nu, int n, int w, int r, int soc, 
     const int cr = ((soc & 2) ? nx : 0) + ((soc & 1) ? nu : 0), csr = (cr + 1) | 1, ipw = 4 / (w * r);
     return 8L * (2L * (ub ? 2 : n) * 16 * w + (n / r) * 64 + (long)(ipw * n + 1) * 3 * csr);
 }
+template <int V> struct TileIntTag { static constexpr int value = V; };
 #ifndef TINYMPC_TILE_SOC_WAVES
 #define TINYMPC_TILE_SOC_WAVES 0                   // (experiments: 1 / 2 instead of the rule)
 #endif
@@ -192,9 +193,48 @@ void admm_tile_kernel(const SolveArgs P) {
     bool lin_lane = false, tlin_lane = false;
     if constexpr (LS) lin_lane = P.tab[T::VEC + VEC_LINFLAG * LW + jj] != 0.0;
     if constexpr (LT) tlin_lane = P.tab[T::VEC + VEC_TLINFLAG * LW + jj] != 0.0;
-    double ones[LIN ? NZ : 1];
+    // (which families: uniform over the wave)
+    bool lin_x_on = false, lin_u_on = false, tlin_x_on = false, tlin_u_on = false;
+    if constexpr (LS) { lin_x_on = P.tab[T::VEC + VEC_LINFLAG * LW] != 0.0; lin_u_on = P.tab[T::VEC + VEC_LINFLAG * LW + NX] != 0.0; }
+    if constexpr (LT) { tlin_x_on = P.tab[T::VEC + VEC_TLINFLAG * LW] != 0.0; tlin_u_on = P.tab[T::VEC + VEC_TLINFLAG * LW + NX] != 0.0; }
+    // LIN: the half-space slacks live in LDS as well -- per set (static | time-varying) two planes of one cell per row and global
+    // slot: V (x + gl between the forward sweep and the projection step, then vlnew) and G (gl); the backward sweep adds
+    // -rho (V - G) (admm.cpp:272 ...).  The projections are TRANSPOSED like the cone step: one lane takes a whole (knot, family)
+    // column, applies the family's half-spaces to it one after the other in its registers (a'z as the reference forms it: products
+    // rounded, summed in row order; project_hyperplane only when violated, admm.cpp:148-173, 186-211) and writes vlnew and
+    // gl = (x + gl) - vlnew back -- N + N - 1 columns per instance and set instead of two DPP chains per knot, half-space and slot.
+    constexpr int CSL = LIN ? ((NZ + 1) | 1) : 1;                        // cells of a slot (+ the pad of the lanes beyond nx+nu), odd
+    __shared__ double sLV[LS ? IPW * N * CSL : 1], sLG[LS ? IPW * N * CSL : 1];
+    __shared__ double sTV[LT ? IPW * N * CSL : 1], sTG[LT ? IPW * N * CSL : 1];
+    const int cl0 = (inst * N + hrow * L) * CSL + (jj < NZ ? jj : NZ);   // this lane's cell of its first own slot (slot l: + l * CSL)
+    // one pass of columns: family rows [R0, R0 + NF), columns (= global slots) S0 + t of this lane's instance, t over the passes
+    auto project_columns = [&](auto nf_tag, const int R0, const int S0, double* pv, double* pg, const double* tab, const int tab_stride, const int nk) {
+#pragma clang fp contract(off)
+        constexpr int NF = decltype(nf_tag)::value;
+        const int t = lane - inst * LPI;
+        for (int c = S0 + t; c < N; c += LPI) {
+            const int at = (inst * N + c) * CSL + R0;
+            const double* tk = tab + c * tab_stride;
+            double z[NF], t0[NF];
 #pragma unroll
-    for (int k = 0; k < (LIN ? NZ : 1); ++k) ones[k] = 1.0;
+            for (int r = 0; r < NF; ++r) { z[r] = pv[at + r]; t0[r] = z[r]; }
+            for (int k = 0; k < nk; ++k) {
+                double cv = 0.0;
+#pragma unroll
+                for (int r = 0; r < NF; ++r) { const double pr = tk[k * LW + R0 + r] * z[r]; cv = cv + pr; }
+                const double bk = tk[KMAX * LW + k * LW + R0];
+                if (cv > bk) {
+                    const double dist = (cv - bk) / tk[2 * KMAX * LW + k * LW + R0];
+#pragma unroll
+                    for (int r = 0; r < NF; ++r) { const double pr = dist * tk[k * LW + R0 + r]; z[r] = z[r] - pr; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NF; ++r) { pv[at + r] = z[r]; pg[at + r] = t0[r] - z[r]; }
+        }
+    };
+    using NXTag = TileIntTag<NX>;
+    using NUTag = TileIntTag<NU>;
     const bool soc_lane = socmask != 0.0, proj_lane = soc_lane && cone_base >= 0;
     // ---- cone slack planes (see the header): CR cells per slot and plane, one per row of the families that are on; every other
     // lane shares the pad cell CR (it only ever holds zeros); a slot is 3 CSR doubles, an ODD number: the item gathers of a pass
@@ -257,7 +297,6 @@ void admm_tile_kernel(const SolveArgs P) {
     double G[L], VN[L], VP[(VL_ || VG) ? 1 : L], QX[(QL || QR) ? 1 : L], Dn[DL ? 1 : L];
     bool gcz[SOC_PASSES];                                              // SOC: the GC cells of this lane's item of pass p are known to be zero
     bool gc_own_dirty = false;                                         // SOC: this lane's own GC cells outside every item may hold a loaded value
-    double VL[LS ? L : 1], GL[LS ? L : 1], VT[LT ? L : 1], GT[LT ? L : 1];
     double ref_last = 0.0, x0v = 0.0, x1v = 0.0, x0_last = 0.0, rp = 0.0, rd = 0.0;   // x1v: slot 1 (x_1 | u_0) of the last sweep; x0_last: the x0 the last solve started from
     int b = 0, iter = 0, solved = 0, checked = 0, countdown = 0, step = 0;
     double *vpp = nullptr, *vpp0 = nullptr;                              // VPG: see the load
@@ -315,8 +354,8 @@ void admm_tile_kernel(const SolveArgs P) {
                     sC[cw0 + l * SLOT_C + PL_GC] = gc0;
                     sC[cw0 + l * SLOT_C + PL_VC] = vc0;
                 }
-                if constexpr (LS) { VL[l] = (valid && lin_lane) ? P.prim[off] : 0.0; GL[l] = (valid && lin_lane) ? P.ldual[off] : 0.0; }     // :361-365
-                if constexpr (LT) { VT[l] = (valid && tlin_lane) ? P.prim[off] : 0.0; GT[l] = (valid && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
+                if constexpr (LS) { sLV[cl0 + l * CSL] = (valid && lin_lane) ? P.prim[off] : 0.0; sLG[cl0 + l * CSL] = (valid && lin_lane) ? P.ldual[off] : 0.0; }     // :361-365
+                if constexpr (LT) { sTV[cl0 + l * CSL] = (valid && tlin_lane) ? P.prim[off] : 0.0; sTG[cl0 + l * CSL] = (valid && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
             x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
@@ -358,20 +397,8 @@ void admm_tile_kernel(const SolveArgs P) {
                     for (int p = 0; p < SOC_PASSES; ++p) gcz[p] = false;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 }
-                if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
-                    if (step > 0) {
-#pragma unroll
-                        for (int l = 0; l < L; ++l) VL[l] = lin_lane ? sX[l * 64 + lane] : 0.0;
-                    }
-                    if (hrow == 0 && is_state && lin_lane) VL[0] = x0v;
-                }
-                if constexpr (LT) {                                        // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
-                    if (step > 0) {
-#pragma unroll
-                        for (int l = 0; l < L; ++l) VT[l] = tlin_lane ? sX[l * 64 + lane] : 0.0;
-                    }
-                    if (hrow == 0 && is_state && tlin_lane) VT[0] = x0v;
-                }
+                if constexpr (LS) { if (hrow == 0 && is_state && lin_lane) sLV[cl0] = x0v; }      // x[:,0] = x0 (admm.cpp:361-365)
+                if constexpr (LT) { if (hrow == 0 && is_state && tlin_lane) sTV[cl0] = x0v; }     // (:370-374)
             }
             bool conv = false;
             if (iter < P.max_iter) {
@@ -400,14 +427,26 @@ void admm_tile_kernel(const SolveArgs P) {
                         // SOC: vcnew - gc of slot l out of its W cell, two steps ahead of its use (one wave per SIMD: see QX above)
                         double wa = 0.0, wb = 0.0;
                         if constexpr (SOC) { wa = sC[cw0 + (L - 1) * SLOT_C]; wb = sC[cw0 + (L - 2) * SLOT_C]; }
+                        // LIN: vlnew and gl of slot l out of their planes, likewise
+                        double lva = 0.0, lvb = 0.0, lga = 0.0, lgb = 0.0, tva = 0.0, tvb = 0.0, tga = 0.0, tgb = 0.0;
+                        if constexpr (LS) { lva = sLV[cl0 + (L - 1) * CSL]; lvb = sLV[cl0 + (L - 2) * CSL]; lga = sLG[cl0 + (L - 1) * CSL]; lgb = sLG[cl0 + (L - 2) * CSL]; }
+                        if constexpr (LT) { tva = sTV[cl0 + (L - 1) * CSL]; tvb = sTV[cl0 + (L - 2) * CSL]; tga = sTG[cl0 + (L - 1) * CSL]; tgb = sTG[cl0 + (L - 2) * CSL]; }
 #pragma unroll
                         for (int l = L - 1; l >= 0; --l) {
-                            double wl = 0.0;
+                            double wl = 0.0, lvl = 0.0, lgl = 0.0, tvl = 0.0, tgl = 0.0;
                             if constexpr (SOC) {
                                 wl = wa; wa = wb;
                                 if (l >= 2) wb = sC[cw0 + (l - 2) * SLOT_C];
-                                __builtin_amdgcn_sched_barrier(0);
                             }
+                            if constexpr (LS) {
+                                lvl = lva; lva = lvb; lgl = lga; lga = lgb;
+                                if (l >= 2) { lvb = sLV[cl0 + (l - 2) * CSL]; lgb = sLG[cl0 + (l - 2) * CSL]; }
+                            }
+                            if constexpr (LT) {
+                                tvl = tva; tva = tvb; tgl = tga; tga = tgb;
+                                if (l >= 2) { tvb = sTV[cl0 + (l - 2) * CSL]; tgb = sTG[cl0 + (l - 2) * CSL]; }
+                            }
+                            if constexpr (SOC != 0 || LIN != 0) __builtin_amdgcn_sched_barrier(0);
                             double qxl;
                             if constexpr (QL) {
                                 qxl = qa; qa = qb;
@@ -421,8 +460,8 @@ void admm_tile_kernel(const SolveArgs P) {
                             } else qxl = QX[l];
                             double qlo = fma(-rho, VN[l] - G[l], qxl);                  // admm.cpp:267 | :280 | :293
                             if constexpr (SOC) qlo = fma(-rho, wl, qlo);                // :269 | :282 | :295
-                            if constexpr (LS) qlo = fma(-rho, VL[l] - GL[l], qlo);      // :272 | :285 | :298
-                            if constexpr (LT) qlo = fma(-rho, VT[l] - GT[l], qlo);      // :275 | :288 | :301
+                            if constexpr (LS) qlo = fma(-rho, lvl - lgl, qlo);          // :272 | :285 | :298
+                            if constexpr (LT) qlo = fma(-rho, tvl - tgl, qlo);          // :275 | :288 | :301
                             if (ph == R - 1 && l == L - 1) {
                                 pcur = qlo;                                             // p_{N-1}
                             } else if constexpr (TFUSED) {
@@ -472,6 +511,9 @@ void admm_tile_kernel(const SolveArgs P) {
                         if constexpr (VL_) { va = sV[li]; vb = sV[SLOT + li]; }
                         double ga = 0.0, gb = 0.0;                      // SOC: gc of slot l out of its GC cell, likewise
                         if constexpr (SOC) { ga = sC[cw0 + PL_GC]; gb = sC[cw0 + SLOT_C + PL_GC]; }
+                        double fla = 0.0, flb = 0.0, fta = 0.0, ftb = 0.0;   // LIN: gl | gl_tv of slot l
+                        if constexpr (LS) { fla = sLG[cl0]; flb = sLG[cl0 + CSL]; }
+                        if constexpr (LT) { fta = sTG[cl0]; ftb = sTG[cl0 + CSL]; }
 #pragma unroll
                         for (int l = 0; l < L; ++l) {
                             const int g = ph * L + l;
@@ -494,7 +536,10 @@ void admm_tile_kernel(const SolveArgs P) {
                                 gcl = ga; ga = gb;
                                 if (l + 2 < L) gb = sC[cw0 + (l + 2) * SLOT_C + PL_GC];
                             }
-                            if constexpr (!UB || DL || VL_ || SOC != 0) __builtin_amdgcn_sched_barrier(0);   // (pins the reads ABOVE this step: the compiler otherwise sinks them to their use)
+                            double gll = 0.0, gtl = 0.0;
+                            if constexpr (LS) { gll = fla; fla = flb; if (l + 2 < L) flb = sLG[cl0 + (l + 2) * CSL]; }
+                            if constexpr (LT) { gtl = fta; fta = ftb; if (l + 2 < L) ftb = sTG[cl0 + (l + 2) * CSL]; }
+                            if constexpr (!UB || DL || VL_ || SOC != 0 || LIN != 0) __builtin_amdgcn_sched_barrier(0);   // (pins the reads ABOVE this step: the compiler otherwise sinks them to their use)
                             const double xi = xcur;
                             if constexpr (KEEPX) sX[l * 64 + lane] = xi;
                             if constexpr (DEFER) {                                       // the chains only; the slot update follows the sweep
@@ -552,36 +597,10 @@ void admm_tile_kernel(const SolveArgs P) {
                             // lane per (cone, knot): the cone step below.  A cell outside every item keeps this value as its vcnew.
                             // (only the lanes that own a cell write: the pad the others share must stay zero whatever an instance diverges to)
                             if constexpr (SOC) { if (soc_lane) sC[cw0 + l * SLOT_C] = fma(xi, socmask, gcl); }
-                            if constexpr (LIN != 0) {
-                                // half-spaces applied one after the other, only when violated (admm.cpp:148-173, 186-211)
-                                auto halfspaces = [&](double z, const double* tabk, const int nk) {
-                                    for (int k = 0; k < nk; ++k) {
-                                        const double a = tabk[k * LW + jj];
-                                        const double bk = tabk[KMAX * LW + k * LW + jj];
-                                        const double nn = tabk[2 * KMAX * LW + k * LW + jj];
-                                        const double prod = a * z;
-                                        const double cs = tile_matvec<W, 0, NX>(0.0, prod, ones);
-                                        const double ci = tile_matvec<W, NX, NZ>(0.0, prod, ones + NX);
-                                        const double cv = is_state ? cs : ci;
-                                        if (cv > bk) z = z - ((cv - bk) / nn) * a;
-                                    }
-                                    return z;
-                                };
-                                if constexpr (LS) {
-                                    const bool on = lin_lane && (is_state || g >= 1);
-                                    double vl = on ? (xi + GL[l]) : 0.0;                // :139 / :144
-                                    vl = halfspaces(vl, sLin, P.n_lin);
-                                    GL[l] = on ? ((GL[l] + xi) - vl) : 0.0;             // :239 / :244
-                                    VL[l] = on ? vl : 0.0;
-                                }
-                                if constexpr (LT) {
-                                    const bool on = tlin_lane && (is_state || g >= 1);
-                                    double vt = on ? (xi + GT[l]) : 0.0;                // :177 / :182
-                                    vt = halfspaces(vt, sTLin + g * 3 * KMAX * LW, P.n_tlin);
-                                    GT[l] = on ? ((GT[l] + xi) - vt) : 0.0;             // :249 / :254
-                                    VT[l] = on ? vt : 0.0;
-                                }
-                            }
+                            // vlnew = x + gl on the rows of a family whose half-space slack is on (:139 / :144 / :177 / :182), projected after the
+                            // sweep, one lane per (knot, family) column
+                            if constexpr (LS) sLV[cl0 + l * CSL] = (lin_lane && (is_state || g >= 1)) ? (xi + gll) : 0.0;
+                            if constexpr (LT) sTV[cl0 + l * CSL] = (tlin_lane && (is_state || g >= 1)) ? (xi + gtl) : 0.0;
                         }
                     }
                 }
@@ -604,6 +623,21 @@ void admm_tile_kernel(const SolveArgs P) {
                         G[l] = tt - vn;
                         VN[l] = vn;
                     }
+                }
+                if constexpr (LIN != 0) {
+                    // ---- half-space projections (admm.cpp:137-211) + their dual update (:239-254), transposed (see project_columns)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if constexpr (LS) {
+                        if (lin_x_on) project_columns(NXTag{}, 0, 0, sLV, sLG, sLin, 0, P.n_lin);
+                        if (lin_u_on) project_columns(NUTag{}, NX, 1, sLV, sLG, sLin, 0, P.n_lin);
+                    }
+                    if constexpr (LT) {
+                        if (tlin_x_on) project_columns(NXTag{}, 0, 0, sTV, sTG, sTLin, 3 * KMAX * LW, P.n_tlin);
+                        if (tlin_u_on) project_columns(NUTag{}, NX, 1, sTV, sTG, sTLin, 3 * KMAX * LW, P.n_tlin);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if constexpr (SOC) {
                     // ---- cone step (admm.cpp:112-135, 228-235), transposed: x + gc of every slot went to the W plane above; lane t of
@@ -694,20 +728,15 @@ void admm_tile_kernel(const SolveArgs P) {
                         for (int p = 0; p < SOC_PASSES; ++p) gcz[p] = false;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     }
-                    if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365)
-                        if (true) {
+                    if constexpr (LS) {                                        // vlnew = x, zlnew = u (admm.cpp:361-365); x[:,0] = x0
 #pragma unroll
-                            for (int l = 0; l < L; ++l) VL[l] = lin_lane ? sX[l * 64 + lane] : 0.0;
-                        }
-                        if (hrow == 0 && is_state && lin_lane) VL[0] = x0v;
+                        for (int l = 0; l < L; ++l) sLV[cl0 + l * CSL] = lin_lane ? ((l == 0 && hrow == 0 && is_state) ? x0v : sX[l * 64 + lane]) : 0.0;
                     }
                     if constexpr (LT) {                                        // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
-                        if (true) {
 #pragma unroll
-                            for (int l = 0; l < L; ++l) VT[l] = tlin_lane ? sX[l * 64 + lane] : 0.0;
-                        }
-                        if (hrow == 0 && is_state && tlin_lane) VT[0] = x0v;
+                        for (int l = 0; l < L; ++l) sTV[cl0 + l * CSL] = tlin_lane ? ((l == 0 && hrow == 0 && is_state) ? x0v : sX[l * 64 + lane]) : 0.0;
                     }
+                    if constexpr (LIN != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 } else {
                 if constexpr (!KEEPX) {
                     // ---- the x|u trajectory, regenerated: forward_pass (admm.cpp:25-32) once more with the d of the last iteration and
@@ -767,8 +796,8 @@ void admm_tile_kernel(const SolveArgs P) {
                                 P.cdual[off] = sC[cw0 + l * SLOT_C + PL_GC];
                             }
                         }
-                        if constexpr (LS) { if (lin_lane) { P.lslack[off] = VL[l]; P.ldual[off] = GL[l]; } }
-                        if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = VT[l]; P.tldual[off] = GT[l]; } }
+                        if constexpr (LS) { if (lin_lane) { P.lslack[off] = sLV[cl0 + l * CSL]; P.ldual[off] = sLG[cl0 + l * CSL]; } }
+                        if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = sTV[cl0 + l * CSL]; P.tldual[off] = sTG[cl0 + l * CSL]; } }
                     }
                 }
                 if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = x1v;
