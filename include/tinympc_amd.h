@@ -250,6 +250,11 @@ long tiny_batch_get_option(TinyBatch* b, const char* name);
 /* the cost model behind "repack_after" = -1 by itself (host arithmetic, no GPU): hist[1024], hist[i] = instances whose solve takes
  * i iterations; returns the proposed K (0 = plain launch), *ratio = predicted time of the best split / of the plain launch */
 int tiny_predict_split(const unsigned* hist, int nx, int nu, int N, int max_iter, int check_termination, int num_cus, double* ratio);
+/* the schedule behind "step_regroup" by itself (host arithmetic, no GPU): the stretches a fused launch of `steps` MPC steps is cut into
+ * -- k > 0: stretches of k steps, k <= 0: the automatic length (steps / 4, at least 8); known = 0: nothing is known about the instances
+ * yet, ONE step of all of them goes first; half = 1: the second half of the batch under "step_regroup_streams" = 2, half a stretch out
+ * of step with the first.  Writes the lengths to out[0 .. capacity), returns their number (their sum is `steps`). */
+int tiny_step_regroup_plan(int steps, int k, int known, int half, int* out, int capacity);
 int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a caller-owned stream */
 /* Closed-loop tracking (examples/quadrotor_tracking.cpp:65,89): a reference trajectory of n_points state
  * vectors ([n_points][nx] doubles), shared by every instance.  While it is set, the state reference of a solve

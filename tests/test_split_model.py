@@ -49,3 +49,29 @@ def test_the_cap_sits_one_check_interval_behind_the_mode():
     assert k == 10 and 0.6 < ratio < 0.9, (k, ratio)
     k5, _ = tm.predict_split(h, 12, 4, 10, max_iter=100, check_termination=5)
     assert k5 % 5 == 0 and k5 >= 10
+
+
+def test_step_regroup_plan_covers_every_step_once():
+    """CPU: the stretches "step_regroup" cuts a fused launch into (tiny_step_regroup_plan): every step exactly once, a single step first
+    when nothing is known about the instances, no stretch shorter than half of K except that first one, the second half of a
+    two-stream launch half a stretch out of step"""
+    for steps in (1, 2, 7, 16, 20, 24, 89, 90, 100):
+        for k in (-1, 1, 3, 8, 23, 45, 200):
+            for known in (False, True):
+                for half in (0, 1):
+                    plan = tm.step_regroup_plan(steps, k, known, half)
+                    assert sum(plan) == steps and all(n >= 1 for n in plan), (steps, k, known, half, plan)
+                    K = k if k > 0 else max(8, (steps + 3) // 4)
+                    if K >= steps:                               # not cut at all: one launch
+                        assert plan == [steps]
+                        continue
+                    body = plan[1:] if not known else plan
+                    if not known:
+                        assert plan[0] == 1
+                    assert max(body) < K + (K + 1) // 2 and len(body) <= steps // K + 2, (steps, k, known, half, plan)
+                    if not half and len(body) > 1:               # (only the LAST stretch may fall short of K, and never below half of it)
+                        assert all(n == K for n in body[:-1]) or body[-1] >= K, (steps, k, known, half, plan)
+                        assert body[-1] >= (K + 1) // 2, (steps, k, known, half, plan)
+    assert tm.step_regroup_plan(90, -1, False) == [1, 23, 23, 23, 20]                  # BASELINE config 4's episode
+    assert tm.step_regroup_plan(90, -1, False, half=1) == [1, 12, 23, 23, 31]
+    assert tm.step_regroup_plan(90, -1, True) == [23, 23, 23, 21]

@@ -44,7 +44,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
     "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy", "tiny_rccl_comm_count", "tiny_rccl_available", "tiny_reduce_stats_messages",
-    "tiny_batch_get_option", "tiny_predict_split", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
+    "tiny_batch_get_option", "tiny_predict_split", "tiny_step_regroup_plan", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -146,6 +146,7 @@ def lib():
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_set_cache.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.tiny_predict_split.argtypes = [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
+        L.tiny_step_regroup_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int]
         L.tiny_batch_get_option.argtypes = [C.c_void_p, C.c_char_p]
         L.tiny_batch_get_option.restype = C.c_long
         L.tiny_batch_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -659,6 +660,14 @@ class TinyGroupSolver:
         self._check(lib().tiny_group_get_status(self._h, it.ctypes.data_as(_ip), so.ctypes.data_as(_ip), st.ctypes.data_as(_ip),
                                                 res.ctypes.data_as(_dp)), "get_status")
         return dict(iter=it, solved=so, status=st, residuals=res)
+
+
+def step_regroup_plan(steps, k=-1, known=False, half=0):
+    """the stretches option "step_regroup" cuts a fused launch of `steps` MPC steps into (k <= 0: the automatic length).  Host
+    arithmetic, no GPU."""
+    out = np.zeros(max(int(steps), 1) + 1, dtype=np.int32)
+    n = lib().tiny_step_regroup_plan(int(steps), int(k), int(bool(known)), int(half), out.ctypes.data_as(_ip), len(out))
+    return [int(v) for v in out[:n]]
 
 
 def predict_split(hist, nx, nu, N, max_iter, check_termination=1, num_cus=256):

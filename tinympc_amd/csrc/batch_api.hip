@@ -2259,6 +2259,23 @@ int tiny_predict_split(const unsigned* hist, int nx, int nu, int N, int max_iter
     return choose_split_for(nx, nu, N, false, max_iter, std::max(1, check_termination), 0, num_cus > 0 ? num_cus : 256, hist, ratio);
 }
 
+// The schedule "step_regroup" cuts a fused launch of `steps` MPC steps into (host arithmetic, no GPU): k > 0 = stretches of k steps,
+// k <= 0 = the automatic length; `known` = the instances' last iteration counts are known at the start (else ONE step goes first: it
+// is what tells them apart); half = 1: the schedule of the second half of the batch under "step_regroup_streams" = 2 (half a stretch
+// out of step).  Writes the stretch lengths to out[0 .. capacity) and returns their number.
+int tiny_step_regroup_plan(int steps, int k, int known, int half, int* out, int capacity) {
+    if (steps < 1) return 0;
+    const int K = k > 0 ? k : regroup_auto_k(steps);
+    std::vector<int> plan;
+    int lead = 0;
+    if (!known && steps > 1) { plan.push_back(1); lead = 1; }
+    if (K < steps)
+        for (const int n : regroup_stretches(steps - lead, K, half ? (K + 1) / 2 : 0)) plan.push_back(n);
+    else plan.assign(1, steps);
+    for (int i = 0; i < (int)plan.size() && i < capacity; ++i) out[i] = plan[i];
+    return (int)plan.size();
+}
+
 // read-back of derived state: "auto_split_k" (the K the automatic split picked from the last histogram, 0 = plain launch),
 // "auto_split_permille" (its predicted time in 1/1000 of the plain launch's), "repack_after"
 long tiny_batch_get_option(TinyBatch* b, const char* name) {
