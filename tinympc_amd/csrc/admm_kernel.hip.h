@@ -798,6 +798,49 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc, bool lin = fa
     return (n <= 10 || 2 * ((soc ? 8 : 6) * n + 2 * nz + 8) + 40 <= 256) ? 2 : 1;
 }
 
+// Half-space variants: the slacks live in LDS planes (see the kernel), so a lane holds the box kernel's arrays and the variant takes
+// the box kernel's two waves per SIMD -- when eight waves' planes and tables fit the CU's LDS
+#ifndef TINYMPC_LIN_WAVES
+#define TINYMPC_LIN_WAVES 0                        // (experiments: 1 / 2 instead of the rule)
+#endif
+constexpr int solve_kernel_lin_waves(int nx, int nu, int n, bool soc, int lin, int kmax, bool ub) {
+    if (TINYMPC_LIN_WAVES > 0) return TINYMPC_LIN_WAVES;
+    const int nz = nx + nu, csl = (nz + 1) | 1, cs = (nz + 1) | 1;
+    const long lds = 8L * (nx * 16 + (ub ? 2 : 2 * n * 16) + ((lin & 1) ? 3 * kmax * 16 + 2 * 4 * n * csl : 0) +
+                           ((lin & 2) ? 3 * n * kmax * 16 + 2 * 4 * n * csl : 0) + (soc ? (4 * n + 1) * 3 * cs : 0));
+    return (solve_kernel_waves_per_simd(nz, n, soc) == 2 && 8 * lds <= 158 * 1024) ? 2 : 1;
+}
+// One lane projects whole (knot, family) columns of a half-space slack: column c of instance `inst`, rows [R0, R0 + NF) -- the cells
+// pv[(inst * n + c) * csl + R0 ...] hold x + gl; the family's half-spaces are applied one after the other, only when violated
+// (admm.cpp:148-173, 186-211; project_hyperplane :70-73; a'z as the reference forms it: products rounded, summed in row order), vlnew
+// goes back to pv and gl = (x + gl) - vlnew (:239-254) to pg.  Lane t of the LPI lanes of an instance takes columns S0 + t, S0 + t +
+// LPI, ...; tab: [3][KMAX][LW] coefficient | offset | squared norm, + c * tab_stride for the time-varying family.
+template <int NF, int KMAX_, int LW_, int LPI_>
+__device__ __forceinline__ void project_halfspace_columns(const int t, const int inst, const int n, const int csl, const int R0, const int S0,
+                                                          double* pv, double* pg, const double* tab, const int tab_stride, const int nk) {
+#pragma clang fp contract(off)
+    for (int c = S0 + t; c < n; c += LPI_) {
+        const int at = (inst * n + c) * csl + R0;
+        const double* tk = tab + c * tab_stride;
+        double z[NF], t0[NF];
+#pragma unroll
+        for (int r = 0; r < NF; ++r) { z[r] = pv[at + r]; t0[r] = z[r]; }
+        for (int k = 0; k < nk; ++k) {
+            double cv = 0.0;
+#pragma unroll
+            for (int r = 0; r < NF; ++r) { const double pr = tk[k * LW_ + R0 + r] * z[r]; cv = cv + pr; }
+            const double bk = tk[KMAX_ * LW_ + k * LW_ + R0];
+            if (cv > bk) {
+                const double dist = (cv - bk) / tk[2 * KMAX_ * LW_ + k * LW_ + R0];
+#pragma unroll
+                for (int r = 0; r < NF; ++r) { const double pr = dist * tk[k * LW_ + R0 + r]; z[r] = z[r] - pr; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NF; ++r) { pv[at + r] = z[r]; pg[at + r] = t0[r] - z[r]; }
+    }
+}
+
 // LIN: bit 0 = static half-spaces (admm.cpp:137-173), bit 1 = time-varying ones (:176-211); 0 = neither
 // HET: per-instance problem data (riccati_kernel.hip.h): the matrix rows are re-loaded for every instance
 // ADAPT: adaptive rho (admm.cpp:397-423): per-instance rho / Kinf / Pinf, re-estimated every 5th iteration
@@ -807,12 +850,15 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc, bool lin = fa
 // serves twice the instances; a mat-vec column is a pair of bank-masked FMAs (fused_*_step_half).  Plain box variants only.
 template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false, bool HALF = false>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(solve_kernel_waves_per_simd(NX + NU, N, SOC, LIN != 0, ADAPT), solve_kernel_waves_per_simd(NX + NU, N, SOC, LIN != 0, ADAPT))))
+__attribute__((amdgpu_waves_per_eu(LIN != 0 ? solve_kernel_lin_waves(NX, NU, N, SOC, LIN, KMAX, UB) : solve_kernel_waves_per_simd(NX + NU, N, SOC, false, ADAPT),
+                                   LIN != 0 ? solve_kernel_lin_waves(NX, NU, N, SOC, LIN, KMAX, UB) : solve_kernel_waves_per_simd(NX + NU, N, SOC, false, ADAPT))))
 void admm_solve_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr int NZ = NX + NU;
     static_assert(NZ <= 16, "one instance per 16-lane DPP row");
     constexpr bool FUSED = MODE == 2 && LIN == 0 && fused_shape(NX, NU);              // fused_backward_step(_soc) / fused_forward_step
+    // (LIN on the fused blocks -- two / three extra linear-cost terms in the asm statement -- was built and measured: no difference,
+    // (12,4,10) + 2 + 2 half-spaces 5.31 ms either way; what the variant pays is its projection step and 208 B/lane of scratch)
     static_assert(!HALF || (NZ <= 8 && FUSED && !SOC && !DBG && !HET && !ADAPT), "half rows: nx+nu <= 8, the plain box kernel on its fused step blocks");
     constexpr int RL = HALF ? 8 : 16;                                  // lanes of one instance
     constexpr int IPW = 64 / RL;                                       // instances per wave
@@ -931,9 +977,16 @@ void admm_solve_kernel(const SolveArgs P) {
     bool lin_lane = false, tlin_lane = false;
     if constexpr (LS) lin_lane = P.tab[TAB_VEC + VEC_LINFLAG * 16 + j] != 0.0;
     if constexpr (LT) tlin_lane = P.tab[TAB_VEC + VEC_TLINFLAG * 16 + j] != 0.0;
-    double ones[LIN ? 16 : 1];
-#pragma unroll
-    for (int k = 0; k < (LIN ? 16 : 1); ++k) ones[k] = 1.0;
+    // LIN: the half-space slacks live in LDS -- per set (static | time-varying) two planes of one cell per row and slot: V (x + gl
+    // between the forward sweep and the projection step, then vlnew) and G (gl); the backward sweep adds -rho (V - G) (admm.cpp:272
+    // ...), read two steps ahead like the cone slack.  The projections are transposed (project_halfspace_columns): a lane holds
+    // the box kernel's arrays, nothing per slot but one LDS write, and the variant runs two waves per SIMD.
+    constexpr int CSL = LIN ? ((NZ + 1) | 1) : 1;
+    __shared__ double sLV[LS ? 4 * N * CSL : 1], sLG[LS ? 4 * N * CSL : 1];
+    __shared__ double sTV[LT ? 4 * N * CSL : 1], sTG[LT ? 4 * N * CSL : 1];
+    bool lin_x_on = false, lin_u_on = false, tlin_x_on = false, tlin_u_on = false;     // which families (uniform over the wave)
+    if constexpr (LS) { lin_x_on = P.tab[TAB_VEC + VEC_LINFLAG * 16] != 0.0; lin_u_on = P.tab[TAB_VEC + VEC_LINFLAG * 16 + NX] != 0.0; }
+    if constexpr (LT) { tlin_x_on = P.tab[TAB_VEC + VEC_TLINFLAG * 16] != 0.0; tlin_u_on = P.tab[TAB_VEC + VEC_TLINFLAG * 16 + NX] != 0.0; }
     double rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // LDS tables were written by other lanes of this wave
@@ -987,7 +1040,7 @@ void admm_solve_kernel(const SolveArgs P) {
             // cone slack cells of this lane (W plane of slot 0): sC[cw + s * SLOT_D (+ PL_GC | PL_VC)]
             const int cw = grp * N * SLOT_D + (j < NZ ? j : NZ);
             const double x0v_in = is_state ? P.x0[(size_t)b * NX + j] : 0.0;      // tiny_set_x0
-            double VL[LS ? N : 1], GL[LS ? N : 1], VT[LT ? N : 1], GT[LT ? N : 1];
+            const int cl = grp * N * CSL + (j < NZ ? j : NZ);  // LIN: this lane's cell of slot 0 (slot s: + s * CSL)
             double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
             double ref_last = 0.0, qx_last_plain = 0.0;
             // ---- load the instance record (coalesced: contiguous NZ*8-byte knot segments)
@@ -1013,12 +1066,12 @@ void admm_solve_kernel(const SolveArgs P) {
                     sC[cw + s * SLOT_D + PL_VC] = vc0;
                 }
                 if constexpr (LS) {
-                    VL[s] = (warm && lin_lane) ? (resumed ? P.lslack : P.prim)[off] : 0.0;         // admm.cpp:361-365
-                    GL[s] = (warm && lin_lane) ? P.ldual[off] : 0.0;
+                    sLV[cl + s * CSL] = (warm && lin_lane) ? (resumed ? P.lslack : P.prim)[off] : 0.0;     // admm.cpp:361-365
+                    sLG[cl + s * CSL] = (warm && lin_lane) ? P.ldual[off] : 0.0;
                 }
                 if constexpr (LT) {
-                    VT[s] = (warm && tlin_lane) ? (resumed ? P.tlslack : P.prim)[off] : 0.0;       // admm.cpp:370-374
-                    GT[s] = (warm && tlin_lane) ? P.tldual[off] : 0.0;
+                    sTV[cl + s * CSL] = (warm && tlin_lane) ? (resumed ? P.tlslack : P.prim)[off] : 0.0;   // admm.cpp:370-374
+                    sTG[cl + s * CSL] = (warm && tlin_lane) ? P.tldual[off] : 0.0;
                 }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
@@ -1106,15 +1159,16 @@ void admm_solve_kernel(const SolveArgs P) {
                 if constexpr (LS) {                            // vlnew = x, zlnew = u (admm.cpp:361-365)
                     if (step > 0) {
 #pragma unroll
-                        for (int s = 0; s < N; ++s) VL[s] = lin_lane ? X[s] : 0.0;
-                    } else if (is_state && lin_lane && !resumed) VL[0] = x0v;
+                        for (int s = 0; s < N; ++s) sLV[cl + s * CSL] = lin_lane ? X[s] : 0.0;
+                    } else if (is_state && lin_lane && !resumed) sLV[cl] = x0v;
                 }
                 if constexpr (LT) {                            // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
                     if (step > 0) {
 #pragma unroll
-                        for (int s = 0; s < N; ++s) VT[s] = tlin_lane ? X[s] : 0.0;
-                    } else if (is_state && tlin_lane && !resumed) VT[0] = x0v;
+                        for (int s = 0; s < N; ++s) sTV[cl + s * CSL] = tlin_lane ? X[s] : 0.0;
+                    } else if (is_state && tlin_lane && !resumed) sTV[cl] = x0v;
                 }
+                if constexpr (LIN != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 const int iter0 = iter_first;
                 iter = iter0; solved = 0;
                 if (resumed && P.check_termination > 0) checked = 1;
@@ -1130,20 +1184,29 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int d = 1; d <= SPR && d <= N; ++d) wr[(N - d) % SPR] = sC[cw + (N - d) * SLOT_D];
                 }
                 for (int it = iter0; it < P.max_iter; ++it) {
+                    // LIN: vlnew and gl of slot i come out of their planes two sweep steps before their use (rings of three registers)
+                    double lvr[LS ? SPR : 1], lgr[LS ? SPR : 1], tvr[LT ? SPR : 1], tgr[LT ? SPR : 1];
+                    if constexpr (LIN != 0) {
+#pragma unroll
+                        for (int d = 1; d <= SPR && d <= N; ++d) {
+                            if constexpr (LS) { lvr[(N - d) % SPR] = sLV[cl + (N - d) * CSL]; lgr[(N - d) % SPR] = sLG[cl + (N - d) * CSL]; }
+                            if constexpr (LT) { tvr[(N - d) % SPR] = sTV[cl + (N - d) * CSL]; tgr[(N - d) % SPR] = sTG[cl + (N - d) * CSL]; }
+                        }
+                    }
                     // ---- update_linear_cost (lane-local) fused into the backward sweep.
                     // qv(s): state lanes q_s (s = N-1: the terminal p), input lanes r_{s-1}.
                     double qhi;
                     {
                         double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293 | :280
                         if constexpr (SOC) t = fma(-rho, wr[(N - 1) % SPR], t);     // :295 | :282
-                        if constexpr (LS) t = fma(-rho, VL[N - 1] - GL[N - 1], t);  // :298 | :285
-                        if constexpr (LT) t = fma(-rho, VT[N - 1] - GT[N - 1], t);  // :301 | :288
+                        if constexpr (LS) t = fma(-rho, lvr[(N - 1) % SPR] - lgr[(N - 1) % SPR], t);  // :298 | :285
+                        if constexpr (LT) t = fma(-rho, tvr[(N - 1) % SPR] - tgr[(N - 1) % SPR], t);  // :301 | :288
                         qhi = t;
                         if constexpr (DBG) {
                             double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
                             if constexpr (SOC) ql = fma(-rho, wr[(N - 1) % SPR], ql);       // :269
-                            if constexpr (LS) ql = fma(-rho, VL[N - 1] - GL[N - 1], ql);    // :272
-                            if constexpr (LT) ql = fma(-rho, VT[N - 1] - GT[N - 1], ql);    // :275
+                            if constexpr (LS) ql = fma(-rho, lvr[(N - 1) % SPR] - lgr[(N - 1) % SPR], ql);    // :272
+                            if constexpr (LT) ql = fma(-rho, tvr[(N - 1) % SPR] - tgr[(N - 1) % SPR], ql);    // :275
                             Qd[N - 1] = is_state ? ql : t;
                             Pd[N - 1] = t;
                         }
@@ -1169,8 +1232,10 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int i = N - 2; i >= 0 && !HALF; --i) {
                         if constexpr (SOC) {
                             if (i >= SPD) wr[(i - SPD) % SPR] = sC[cw + (i - SPD) * SLOT_D];      // (slot i + 1's register is free by now)
-                            __builtin_amdgcn_sched_barrier(0);
                         }
+                        if constexpr (LS) { if (i >= SPD) { lvr[(i - SPD) % SPR] = sLV[cl + (i - SPD) * CSL]; lgr[(i - SPD) % SPR] = sLG[cl + (i - SPD) * CSL]; } }
+                        if constexpr (LT) { if (i >= SPD) { tvr[(i - SPD) % SPR] = sTV[cl + (i - SPD) * CSL]; tgr[(i - SPD) % SPR] = sTG[cl + (i - SPD) * CSL]; } }
+                        if constexpr (SOC || LIN != 0) __builtin_amdgcn_sched_barrier(0);
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
                             if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % SPR], rho, smask, cb, pcur, qhi, mb, mb + NX);
@@ -1183,8 +1248,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
                         if constexpr (SOC) qlo = fma(-rho, wr[i % SPR], qlo);       // :269 | :282
-                        if constexpr (LS) qlo = fma(-rho, VL[i] - GL[i], qlo);      // :272 | :285
-                        if constexpr (LT) qlo = fma(-rho, VT[i] - GT[i], qlo);      // :275 | :288
+                        if constexpr (LS) qlo = fma(-rho, lvr[i % SPR] - lgr[i % SPR], qlo);      // :272 | :285
+                        if constexpr (LT) qlo = fma(-rho, tvr[i % SPR] - tgr[i % SPR], qlo);      // :275 | :288
                         // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
                         const double res = ring_sum2<MODE, NX, NU>(fma(qlo, smask, cb), pcur, mb, qhi, mb + NX);
                         pcur = res;                                                 // p_i | d_i
@@ -1201,7 +1266,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     // the running maxima of the forward sweep
                     constexpr bool LAZY_RES = N <= 12;
                     double pmax = 0.0, dmax = 0.0;
-                    auto slot_update = [&](const int s, const double lo, const double hi, const double gcv) {
+                    auto slot_update = [&](const int s, const double lo, const double hi, const double gcv, const double glv, const double gtv) {
                         const double xi = X[s];
                         const double t = xi + G[s];                                 // :85 / :88
                         const double vn = vmin64(hi, vmax64(lo, t));                // :91-98
@@ -1218,37 +1283,10 @@ void admm_solve_kernel(const SolveArgs P) {
                             // value as its vcnew, so its gc = (x + gc) - vcnew = 0 (written once per solve, behind the cone step)
                             sC[cw + s * SLOT_D] = fma(xi, socmask, gcv);
                         }
-                        // half-space projections (admm.cpp:148-173, 186-211): a'z is a lane-local product summed over
-                        // the row with the broadcast-FMA chain (against a vector of ones), separately for the state
-                        // and the input rows; constraints are applied sequentially, only when violated (:154).
-                        auto halfspaces = [&](double z, const double* tabk, const int nk) {
-                            for (int k = 0; k < nk; ++k) {
-                                const double a = tabk[k * 16 + j];
-                                const double bk = tabk[KMAX * 16 + k * 16 + j];
-                                const double nn = tabk[2 * KMAX * 16 + k * 16 + j];
-                                const double prod = a * z;
-                                double cs = 0.0, ci = 0.0;
-                                ring1<0, NX>(cs, prod, ones);
-                                ring1<NX, NU>(ci, prod, ones);
-                                const double cv = is_state ? cs : ci;
-                                if (cv > bk) z = z - ((cv - bk) / nn) * a;
-                            }
-                            return z;
-                        };
-                        if constexpr (LS) {
-                            const bool on = lin_lane && (is_state || s >= 1);
-                            double vl = on ? (xi + GL[s]) : 0.0;                    // :139 / :144
-                            vl = halfspaces(vl, sLin, P.n_lin);
-                            GL[s] = on ? ((GL[s] + xi) - vl) : 0.0;                 // :239 / :244
-                            VL[s] = on ? vl : 0.0;
-                        }
-                        if constexpr (LT) {
-                            const bool on = tlin_lane && (is_state || s >= 1);
-                            double vt = on ? (xi + GT[s]) : 0.0;                    // :177 / :182
-                            vt = halfspaces(vt, sTLin + s * 3 * KMAX * 16, P.n_tlin);
-                            GT[s] = on ? ((GT[s] + xi) - vt) : 0.0;                 // :249 / :254
-                            VT[s] = on ? vt : 0.0;
-                        }
+                        // half-space slacks: vlnew = x + gl on the rows of a family whose slack is on (:139 / :144 / :177 / :182), projected
+                        // after the sweep, one lane per (knot, family) column (project_halfspace_columns)
+                        if constexpr (LS) sLV[cl + s * CSL] = (lin_lane && (is_state || s >= 1)) ? (xi + glv) : 0.0;
+                        if constexpr (LT) sTV[cl + s * CSL] = (tlin_lane && (is_state || s >= 1)) ? (xi + gtv) : 0.0;
                     };
                     // Software pipeline: the box bounds of slot i+1 are read from LDS one whole step before
                     // they are used (sched_barrier pins the reads above the step), and slot i's update is
@@ -1259,10 +1297,21 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                         for (int d = 0; d < SPD && d < N; ++d) gr[d % SPR] = sC[cw + d * SLOT_D + PL_GC];
                     } else gr[0] = 0.0;
+                    double glr[LS ? SPR : 1], gtr[LT ? SPR : 1];   // LIN: gl | gl_tv of slot i, likewise
+                    glr[0] = 0.0; gtr[0] = 0.0;
+                    if constexpr (LIN != 0) {
+#pragma unroll
+                        for (int d = 0; d < SPD && d < N; ++d) {
+                            if constexpr (LS) glr[d % SPR] = sLG[cl + d * CSL];
+                            if constexpr (LT) gtr[d % SPR] = sTG[cl + d * CSL];
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < N - 1; ++i) {
                         const double lo_n = UB ? lo_u : sLo[(i + 1) * 16 + j], hi_n = UB ? hi_u : sHi[(i + 1) * 16 + j];
                         if constexpr (SOC) { if (i + SPD < N) gr[(i + SPD) % SPR] = sC[cw + (i + SPD) * SLOT_D + PL_GC]; }
+                        if constexpr (LS) { if (i + SPD < N) glr[(i + SPD) % SPR] = sLG[cl + (i + SPD) * CSL]; }
+                        if constexpr (LT) { if (i + SPD < N) gtr[(i + SPD) % SPR] = sTG[cl + (i + SPD) * CSL]; }
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
                             double tt, vn, xn, t = Dn[i];
@@ -1294,10 +1343,25 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
                         X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)
-                        slot_update(i, lo_c, hi_c, gr[SOC ? i % SPR : 0]);
+                        slot_update(i, lo_c, hi_c, gr[SOC ? i % SPR : 0], glr[LS ? i % SPR : 0], gtr[LT ? i % SPR : 0]);
                         lo_c = lo_n; hi_c = hi_n;
                     }
-                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % SPR : 0]);
+                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % SPR : 0], glr[LS ? (N - 1) % SPR : 0], gtr[LT ? (N - 1) % SPR : 0]);
+                    if constexpr (LIN != 0) {
+                        // ---- half-space projections (admm.cpp:137-211) + their dual update (:239-254), transposed
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if constexpr (LS) {
+                            if (lin_x_on) project_halfspace_columns<NX, KMAX, 16, 16>(j, grp, N, CSL, 0, 0, sLV, sLG, sLin, 0, P.n_lin);
+                            if (lin_u_on) project_halfspace_columns<NU, KMAX, 16, 16>(j, grp, N, CSL, NX, 1, sLV, sLG, sLin, 0, P.n_lin);
+                        }
+                        if constexpr (LT) {
+                            if (tlin_x_on) project_halfspace_columns<NX, KMAX, 16, 16>(j, grp, N, CSL, 0, 0, sTV, sTG, sTLin, 3 * KMAX * 16, P.n_tlin);
+                            if (tlin_u_on) project_halfspace_columns<NU, KMAX, 16, 16>(j, grp, N, CSL, NX, 1, sTV, sTG, sTLin, 3 * KMAX * 16, P.n_tlin);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                     // ---- termination_condition, admm.cpp:310-328 (the box residuals: the cone slacks do not enter them)
                     bool conv = false;
                     // The 2N subtractions and maxima behind the four residuals (a tenth of the quadrotor iteration) are only formed when the
@@ -1517,8 +1581,8 @@ void admm_solve_kernel(const SolveArgs P) {
                             P.cdual[off] = sC[cw + s * SLOT_D + PL_GC];
                         }
                     }
-                    if constexpr (LS) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
-                    if constexpr (LT) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }
+                    if constexpr (LS) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = sLV[cl + s * CSL]; P.ldual[off] = sLG[cl + s * CSL]; } }
+                    if constexpr (LT) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = sTV[cl + s * CSL]; P.tldual[off] = sTG[cl + s * CSL]; } }
                     if constexpr (DBG) {
                         if (P.dbg_qr && acc_iter > 0) {
                             P.dbg_qr[off] = Qd[s];                          // work->q | work->r

@@ -462,11 +462,14 @@ static int tile_lin_variant(const TinyBatch* b) {
     return budget_variant_tile_r(b, socm, lv, km, ub) > 0 ? lv : 0;
 }
 static bool cones_overlap(const TinyBatch* b);
+static int lin_variant(const TinyBatch* b);
 static bool use_tile(const TinyBatch* b) {
     if (cones_overlap(b)) return false;
     if (linear_active(b) && (tile_lin_variant(b) == 0 || b->no_jit || b->tile_soc_failed)) return false;
     // (a cone on a tile shape needs the SOC variant, which only exists through run-time instantiation)
-    return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile) && !b->no_tile && !b->hetero && !b->adaptive && !b->force_general && !b->debug &&
+    // a one-row shape whose half-space variant does not fit a wave's LDS (its planes grow with the horizon) takes the tile kernel's
+    const bool regs_cannot = linear_active(b) && lin_variant(b) == 0 && !b->force_general;
+    return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile || regs_cannot) && !b->no_tile && !b->hetero && !b->adaptive && !b->force_general && !b->debug &&
            !b->d_traj && !b->reset_duals && !b->one_shot;
 }
 
@@ -615,7 +618,15 @@ static int lin_variant(const TinyBatch* b) {
     if (b->variant_jit_failed && b->debug) return 0;                   // LIN x debug needs hipRTC; without it: coverage kernel
     if (lin_kmax(b) == 0) return 0;                                    // too many half-spaces per knot: coverage kernel
     if (lin_kmax(b) > LIN_KMAX && (b->no_jit || b->variant_jit_failed)) return 0;
-    return ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
+    const int lv = ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
+    {   // the variant's static LDS: tables + two slack planes per set (+ the cone slack's three) -- a wave has 64 KiB
+        const long N = b->N, km = lin_kmax(b), nz = b->nx + b->nu, csl = (nz + 1) | 1;
+        long d = b->nx * 16 + 2 * N * 16 + (soc_active(b) ? (4 * N + 1) * 3 * csl : 0);
+        if (lv & 1) d += 3 * km * 16 + 2 * 4 * N * csl;
+        if (lv & 2) d += 3 * N * km * 16 + 2 * 4 * N * csl;
+        if (8 * d > TILE_LDS_STATIC_LIMIT) return 0;
+    }
+    return lv;
 }
 // cones of an ENABLED family share rows: sequential projections (admm.cpp:111-135), coverage kernel only
 static bool cones_overlap(const TinyBatch* b) {

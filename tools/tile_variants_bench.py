@@ -11,7 +11,8 @@ import tinympc_amd as tm
 B = int(os.environ.get("BATCH", "32768"))
 print("| shape | constraints | kernel | ms (median) | ADMM it/s | it/solve | solved | FP64 frac (box FLOPs) |")
 print("|---|---|---|---|---|---|---|---|")
-for (nx, nu, N) in ((12, 8, 10), (12, 8, 30), (20, 8, 30), (12, 4, 50)):
+SHAPES = [tuple(int(v) for v in c.split(",")) for c in os.environ["SHAPES"].split(";")] if os.environ.get("SHAPES") else [(12, 8, 10), (12, 8, 30), (20, 8, 30), (12, 4, 50)]
+for (nx, nu, N) in SHAPES:
     prob, rng = tm.random_problem(nx, nu, N)
     x0 = rng.uniform(-1, 1, (B, nx)); xr = np.repeat(rng.uniform(-0.2, 0.2, (B, nx, 1)), N, axis=2)
     Ax = rng.standard_normal((2, nx)); bx = np.full(2, 2.0)
