@@ -803,12 +803,21 @@ constexpr int solve_kernel_waves_per_simd(int nz, int n, bool soc, bool lin = fa
 #ifndef TINYMPC_LIN_WAVES
 #define TINYMPC_LIN_WAVES 0                        // (experiments: 1 / 2 instead of the rule)
 #endif
-constexpr int solve_kernel_lin_waves(int nx, int nu, int n, bool soc, int lin, int kmax, bool ub) {
-    if (TINYMPC_LIN_WAVES > 0) return TINYMPC_LIN_WAVES;
+// static LDS of a half-space variant with its slack planes: the tables, two planes per set, the cone slack's three, Pinf', the bounds
+constexpr long solve_kernel_lin_lds(int nx, int nu, int n, bool soc, int lin, int kmax, bool ub) {
     const int nz = nx + nu, csl = (nz + 1) | 1, cs = (nz + 1) | 1;
-    const long lds = 8L * (nx * 16 + (ub ? 2 : 2 * n * 16) + ((lin & 1) ? 3 * kmax * 16 + 2 * 4 * n * csl : 0) +
-                           ((lin & 2) ? 3 * n * kmax * 16 + 2 * 4 * n * csl : 0) + (soc ? (4 * n + 1) * 3 * cs : 0));
-    return (solve_kernel_waves_per_simd(nz, n, soc) == 2 && 8 * lds <= 158 * 1024) ? 2 : 1;
+    return 8L * (nx * 16 + (ub ? 2 : 2 * n * 16) + ((lin & 1) ? 3 * kmax * 16 + 2 * 4 * n * csl : 0) +
+                 ((lin & 2) ? 3 * n * kmax * 16 + 2 * 4 * n * csl : 0) + (soc ? (4 * n + 1) * 3 * cs : 0));
+}
+// ... which must fit a wave's 64 KiB of static LDS; a variant whose planes do not (long horizons with time-varying tables) keeps its
+// slacks in register arrays and projects per knot, as every half-space variant did before round 4 (one wave per SIMD)
+constexpr bool solve_kernel_lin_planes(int nx, int nu, int n, bool soc, int lin, int kmax, bool ub) {
+    return lin != 0 && solve_kernel_lin_lds(nx, nu, n, soc, lin, kmax, ub) <= 64 * 1024 - 512;
+}
+constexpr int solve_kernel_lin_waves(int nx, int nu, int n, bool soc, int lin, int kmax, bool ub) {
+    if (!solve_kernel_lin_planes(nx, nu, n, soc, lin, kmax, ub)) return 1;
+    if (TINYMPC_LIN_WAVES > 0) return TINYMPC_LIN_WAVES;
+    return (solve_kernel_waves_per_simd(nx + nu, n, soc) == 2 && 8 * solve_kernel_lin_lds(nx, nu, n, soc, lin, kmax, ub) <= 158 * 1024) ? 2 : 1;
 }
 // One lane projects whole (knot, family) columns of a half-space slack: column c of instance `inst`, rows [R0, R0 + NF) -- the cells
 // pv[(inst * n + c) * csl + R0 ...] hold x + gl; the family's half-spaces are applied one after the other, only when violated
@@ -981,9 +990,15 @@ void admm_solve_kernel(const SolveArgs P) {
     // between the forward sweep and the projection step, then vlnew) and G (gl); the backward sweep adds -rho (V - G) (admm.cpp:272
     // ...), read two steps ahead like the cone slack.  The projections are transposed (project_halfspace_columns): a lane holds
     // the box kernel's arrays, nothing per slot but one LDS write, and the variant runs two waves per SIMD.
-    constexpr int CSL = LIN ? ((NZ + 1) | 1) : 1;
-    __shared__ double sLV[LS ? 4 * N * CSL : 1], sLG[LS ? 4 * N * CSL : 1];
-    __shared__ double sTV[LT ? 4 * N * CSL : 1], sTG[LT ? 4 * N * CSL : 1];
+    // (LSP / LTP: the set's slack in planes; LSR / LTR: in register arrays, projected per knot -- the variant whose planes do not fit)
+    constexpr bool LPL = solve_kernel_lin_planes(NX, NU, N, SOC, LIN, KMAX, UB);
+    constexpr bool LSP = LS && LPL, LTP = LT && LPL, LSR = LS && !LPL, LTR = LT && !LPL;
+    constexpr int CSL = LPL ? ((NZ + 1) | 1) : 1;
+    __shared__ double sLV[LSP ? 4 * N * CSL : 1], sLG[LSP ? 4 * N * CSL : 1];
+    __shared__ double sTV[LTP ? 4 * N * CSL : 1], sTG[LTP ? 4 * N * CSL : 1];
+    double ones[(LSR || LTR) ? 16 : 1];
+#pragma unroll
+    for (int k = 0; k < ((LSR || LTR) ? 16 : 1); ++k) ones[k] = 1.0;
     bool lin_x_on = false, lin_u_on = false, tlin_x_on = false, tlin_u_on = false;     // which families (uniform over the wave)
     if constexpr (LS) { lin_x_on = P.tab[TAB_VEC + VEC_LINFLAG * 16] != 0.0; lin_u_on = P.tab[TAB_VEC + VEC_LINFLAG * 16 + NX] != 0.0; }
     if constexpr (LT) { tlin_x_on = P.tab[TAB_VEC + VEC_TLINFLAG * 16] != 0.0; tlin_u_on = P.tab[TAB_VEC + VEC_TLINFLAG * 16 + NX] != 0.0; }
@@ -1041,6 +1056,7 @@ void admm_solve_kernel(const SolveArgs P) {
             const int cw = grp * N * SLOT_D + (j < NZ ? j : NZ);
             const double x0v_in = is_state ? P.x0[(size_t)b * NX + j] : 0.0;      // tiny_set_x0
             const int cl = grp * N * CSL + (j < NZ ? j : NZ);  // LIN: this lane's cell of slot 0 (slot s: + s * CSL)
+            double VL[LSR ? N : 1], GL[LSR ? N : 1], VT[LTR ? N : 1], GT[LTR ? N : 1];
             double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
             double ref_last = 0.0, qx_last_plain = 0.0;
             // ---- load the instance record (coalesced: contiguous NZ*8-byte knot segments)
@@ -1066,12 +1082,14 @@ void admm_solve_kernel(const SolveArgs P) {
                     sC[cw + s * SLOT_D + PL_VC] = vc0;
                 }
                 if constexpr (LS) {
-                    sLV[cl + s * CSL] = (warm && lin_lane) ? (resumed ? P.lslack : P.prim)[off] : 0.0;     // admm.cpp:361-365
-                    sLG[cl + s * CSL] = (warm && lin_lane) ? P.ldual[off] : 0.0;
+                    const double vl0 = (warm && lin_lane) ? (resumed ? P.lslack : P.prim)[off] : 0.0;      // admm.cpp:361-365
+                    const double gl0 = (warm && lin_lane) ? P.ldual[off] : 0.0;
+                    if constexpr (LSP) { sLV[cl + s * CSL] = vl0; sLG[cl + s * CSL] = gl0; } else { VL[s] = vl0; GL[s] = gl0; }
                 }
                 if constexpr (LT) {
-                    sTV[cl + s * CSL] = (warm && tlin_lane) ? (resumed ? P.tlslack : P.prim)[off] : 0.0;   // admm.cpp:370-374
-                    sTG[cl + s * CSL] = (warm && tlin_lane) ? P.tldual[off] : 0.0;
+                    const double vt0 = (warm && tlin_lane) ? (resumed ? P.tlslack : P.prim)[off] : 0.0;    // admm.cpp:370-374
+                    const double gt0 = (warm && tlin_lane) ? P.tldual[off] : 0.0;
+                    if constexpr (LTP) { sTV[cl + s * CSL] = vt0; sTG[cl + s * CSL] = gt0; } else { VT[s] = vt0; GT[s] = gt0; }
                 }
                 if constexpr (DBG) { Qd[s] = 0.0; Pd[s] = 0.0; Dd[s] = 0.0; }
             }
@@ -1159,16 +1177,16 @@ void admm_solve_kernel(const SolveArgs P) {
                 if constexpr (LS) {                            // vlnew = x, zlnew = u (admm.cpp:361-365)
                     if (step > 0) {
 #pragma unroll
-                        for (int s = 0; s < N; ++s) sLV[cl + s * CSL] = lin_lane ? X[s] : 0.0;
-                    } else if (is_state && lin_lane && !resumed) sLV[cl] = x0v;
+                        for (int s = 0; s < N; ++s) { if constexpr (LSP) sLV[cl + s * CSL] = lin_lane ? X[s] : 0.0; else VL[s] = lin_lane ? X[s] : 0.0; }
+                    } else if (is_state && lin_lane && !resumed) { if constexpr (LSP) sLV[cl] = x0v; else VL[0] = x0v; }
                 }
                 if constexpr (LT) {                            // vlnew_tv = x, zlnew_tv = u (admm.cpp:370-374)
                     if (step > 0) {
 #pragma unroll
-                        for (int s = 0; s < N; ++s) sTV[cl + s * CSL] = tlin_lane ? X[s] : 0.0;
-                    } else if (is_state && tlin_lane && !resumed) sTV[cl] = x0v;
+                        for (int s = 0; s < N; ++s) { if constexpr (LTP) sTV[cl + s * CSL] = tlin_lane ? X[s] : 0.0; else VT[s] = tlin_lane ? X[s] : 0.0; }
+                    } else if (is_state && tlin_lane && !resumed) { if constexpr (LTP) sTV[cl] = x0v; else VT[0] = x0v; }
                 }
-                if constexpr (LIN != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if constexpr (LPL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 const int iter0 = iter_first;
                 iter = iter0; solved = 0;
                 if (resumed && P.check_termination > 0) checked = 1;
@@ -1185,28 +1203,31 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
                 for (int it = iter0; it < P.max_iter; ++it) {
                     // LIN: vlnew and gl of slot i come out of their planes two sweep steps before their use (rings of three registers)
-                    double lvr[LS ? SPR : 1], lgr[LS ? SPR : 1], tvr[LT ? SPR : 1], tgr[LT ? SPR : 1];
-                    if constexpr (LIN != 0) {
+                    double lvr[LSP ? SPR : 1], lgr[LSP ? SPR : 1], tvr[LTP ? SPR : 1], tgr[LTP ? SPR : 1];
+                    if constexpr (LPL) {
 #pragma unroll
                         for (int d = 1; d <= SPR && d <= N; ++d) {
-                            if constexpr (LS) { lvr[(N - d) % SPR] = sLV[cl + (N - d) * CSL]; lgr[(N - d) % SPR] = sLG[cl + (N - d) * CSL]; }
-                            if constexpr (LT) { tvr[(N - d) % SPR] = sTV[cl + (N - d) * CSL]; tgr[(N - d) % SPR] = sTG[cl + (N - d) * CSL]; }
+                            if constexpr (LSP) { lvr[(N - d) % SPR] = sLV[cl + (N - d) * CSL]; lgr[(N - d) % SPR] = sLG[cl + (N - d) * CSL]; }
+                            if constexpr (LTP) { tvr[(N - d) % SPR] = sTV[cl + (N - d) * CSL]; tgr[(N - d) % SPR] = sTG[cl + (N - d) * CSL]; }
                         }
                     }
+                    // vlnew - gl | vlnew_tv - gl_tv of slot s_: from the rings, or the register arrays of the per-knot variant
+                    auto lin_w = [&](const int s_) { if constexpr (LSP) return lvr[s_ % SPR] - lgr[s_ % SPR]; else return VL[LSR ? s_ : 0] - GL[LSR ? s_ : 0]; };
+                    auto tlin_w = [&](const int s_) { if constexpr (LTP) return tvr[s_ % SPR] - tgr[s_ % SPR]; else return VT[LTR ? s_ : 0] - GT[LTR ? s_ : 0]; };
                     // ---- update_linear_cost (lane-local) fused into the backward sweep.
                     // qv(s): state lanes q_s (s = N-1: the terminal p), input lanes r_{s-1}.
                     double qhi;
                     {
                         double t = fma(-rho, VN[N - 1] - G[N - 1], QX[N - 1]);      // admm.cpp:293 | :280
                         if constexpr (SOC) t = fma(-rho, wr[(N - 1) % SPR], t);     // :295 | :282
-                        if constexpr (LS) t = fma(-rho, lvr[(N - 1) % SPR] - lgr[(N - 1) % SPR], t);  // :298 | :285
-                        if constexpr (LT) t = fma(-rho, tvr[(N - 1) % SPR] - tgr[(N - 1) % SPR], t);  // :301 | :288
+                        if constexpr (LS) t = fma(-rho, lin_w(N - 1), t);           // :298 | :285
+                        if constexpr (LT) t = fma(-rho, tlin_w(N - 1), t);          // :301 | :288
                         qhi = t;
                         if constexpr (DBG) {
                             double ql = fma(-rho, VN[N - 1] - G[N - 1], qx_last_plain);   // q[:,N-1], :267
                             if constexpr (SOC) ql = fma(-rho, wr[(N - 1) % SPR], ql);       // :269
-                            if constexpr (LS) ql = fma(-rho, lvr[(N - 1) % SPR] - lgr[(N - 1) % SPR], ql);    // :272
-                            if constexpr (LT) ql = fma(-rho, tvr[(N - 1) % SPR] - tgr[(N - 1) % SPR], ql);    // :275
+                            if constexpr (LS) ql = fma(-rho, lin_w(N - 1), ql);             // :272
+                            if constexpr (LT) ql = fma(-rho, tlin_w(N - 1), ql);            // :275
                             Qd[N - 1] = is_state ? ql : t;
                             Pd[N - 1] = t;
                         }
@@ -1233,9 +1254,9 @@ void admm_solve_kernel(const SolveArgs P) {
                         if constexpr (SOC) {
                             if (i >= SPD) wr[(i - SPD) % SPR] = sC[cw + (i - SPD) * SLOT_D];      // (slot i + 1's register is free by now)
                         }
-                        if constexpr (LS) { if (i >= SPD) { lvr[(i - SPD) % SPR] = sLV[cl + (i - SPD) * CSL]; lgr[(i - SPD) % SPR] = sLG[cl + (i - SPD) * CSL]; } }
-                        if constexpr (LT) { if (i >= SPD) { tvr[(i - SPD) % SPR] = sTV[cl + (i - SPD) * CSL]; tgr[(i - SPD) % SPR] = sTG[cl + (i - SPD) * CSL]; } }
-                        if constexpr (SOC || LIN != 0) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (LSP) { if (i >= SPD) { lvr[(i - SPD) % SPR] = sLV[cl + (i - SPD) * CSL]; lgr[(i - SPD) % SPR] = sLG[cl + (i - SPD) * CSL]; } }
+                        if constexpr (LTP) { if (i >= SPD) { tvr[(i - SPD) % SPR] = sTV[cl + (i - SPD) * CSL]; tgr[(i - SPD) % SPR] = sTG[cl + (i - SPD) * CSL]; } }
+                        if constexpr (SOC || LPL) __builtin_amdgcn_sched_barrier(0);
                         if constexpr (FUSED) {                  // linear-cost terms + both mat-vec chains in one asm statement (no s_nop)
                             double qlo, res;
                             if constexpr (SOC) fused_backward_step_soc<NX, NU>(qlo, res, VN[i], G[i], QX[i], wr[i % SPR], rho, smask, cb, pcur, qhi, mb, mb + NX);
@@ -1248,8 +1269,8 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         double qlo = fma(-rho, VN[i] - G[i], QX[i]);                // :267 | :280
                         if constexpr (SOC) qlo = fma(-rho, wr[i % SPR], qlo);       // :269 | :282
-                        if constexpr (LS) qlo = fma(-rho, lvr[i % SPR] - lgr[i % SPR], qlo);      // :272 | :285
-                        if constexpr (LT) qlo = fma(-rho, tvr[i % SPR] - tgr[i % SPR], qlo);      // :275 | :288
+                        if constexpr (LS) qlo = fma(-rho, lin_w(i), qlo);           // :272 | :285
+                        if constexpr (LT) qlo = fma(-rho, tlin_w(i), qlo);          // :275 | :288
                         // state lanes: q_i + APf + AmBKt p_{i+1} - Kinf' r_i ; input lanes: Quu_inv (B' p_{i+1} + r_i + BPf)
                         const double res = ring_sum2<MODE, NX, NU>(fma(qlo, smask, cb), pcur, mb, qhi, mb + NX);
                         pcur = res;                                                 // p_i | d_i
@@ -1285,8 +1306,40 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         // half-space slacks: vlnew = x + gl on the rows of a family whose slack is on (:139 / :144 / :177 / :182), projected
                         // after the sweep, one lane per (knot, family) column (project_halfspace_columns)
-                        if constexpr (LS) sLV[cl + s * CSL] = (lin_lane && (is_state || s >= 1)) ? (xi + glv) : 0.0;
-                        if constexpr (LT) sTV[cl + s * CSL] = (tlin_lane && (is_state || s >= 1)) ? (xi + gtv) : 0.0;
+                        if constexpr (LSP) sLV[cl + s * CSL] = (lin_lane && (is_state || s >= 1)) ? (xi + glv) : 0.0;
+                        if constexpr (LTP) sTV[cl + s * CSL] = (tlin_lane && (is_state || s >= 1)) ? (xi + gtv) : 0.0;
+                        if constexpr (LSR || LTR) {
+                            // the per-knot form: a'z is a lane-local product summed over the row with the broadcast-FMA chain (against a vector of
+                            // ones), separately for the state and the input rows; constraints are applied sequentially, only when violated (:154)
+                            auto halfspaces = [&](double z, const double* tabk, const int nk) {
+                                for (int k = 0; k < nk; ++k) {
+                                    const double a = tabk[k * 16 + j];
+                                    const double bk = tabk[KMAX * 16 + k * 16 + j];
+                                    const double nn = tabk[2 * KMAX * 16 + k * 16 + j];
+                                    const double prod = a * z;
+                                    double cs = 0.0, ci = 0.0;
+                                    ring1<0, NX>(cs, prod, ones);
+                                    ring1<NX, NU>(ci, prod, ones);
+                                    const double cv = is_state ? cs : ci;
+                                    if (cv > bk) z = z - ((cv - bk) / nn) * a;
+                                }
+                                return z;
+                            };
+                            if constexpr (LSR) {
+                                const bool on = lin_lane && (is_state || s >= 1);
+                                double vl = on ? (xi + GL[s]) : 0.0;                    // :139 / :144
+                                vl = halfspaces(vl, sLin, P.n_lin);
+                                GL[s] = on ? ((GL[s] + xi) - vl) : 0.0;                 // :239 / :244
+                                VL[s] = on ? vl : 0.0;
+                            }
+                            if constexpr (LTR) {
+                                const bool on = tlin_lane && (is_state || s >= 1);
+                                double vt = on ? (xi + GT[s]) : 0.0;                    // :177 / :182
+                                vt = halfspaces(vt, sTLin + s * 3 * KMAX * 16, P.n_tlin);
+                                GT[s] = on ? ((GT[s] + xi) - vt) : 0.0;                 // :249 / :254
+                                VT[s] = on ? vt : 0.0;
+                            }
+                        }
                     };
                     // Software pipeline: the box bounds of slot i+1 are read from LDS one whole step before
                     // they are used (sched_barrier pins the reads above the step), and slot i's update is
@@ -1297,21 +1350,21 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
                         for (int d = 0; d < SPD && d < N; ++d) gr[d % SPR] = sC[cw + d * SLOT_D + PL_GC];
                     } else gr[0] = 0.0;
-                    double glr[LS ? SPR : 1], gtr[LT ? SPR : 1];   // LIN: gl | gl_tv of slot i, likewise
+                    double glr[LSP ? SPR : 1], gtr[LTP ? SPR : 1];   // LIN: gl | gl_tv of slot i, likewise
                     glr[0] = 0.0; gtr[0] = 0.0;
-                    if constexpr (LIN != 0) {
+                    if constexpr (LPL) {
 #pragma unroll
                         for (int d = 0; d < SPD && d < N; ++d) {
-                            if constexpr (LS) glr[d % SPR] = sLG[cl + d * CSL];
-                            if constexpr (LT) gtr[d % SPR] = sTG[cl + d * CSL];
+                            if constexpr (LSP) glr[d % SPR] = sLG[cl + d * CSL];
+                            if constexpr (LTP) gtr[d % SPR] = sTG[cl + d * CSL];
                         }
                     }
 #pragma unroll
                     for (int i = 0; i < N - 1; ++i) {
                         const double lo_n = UB ? lo_u : sLo[(i + 1) * 16 + j], hi_n = UB ? hi_u : sHi[(i + 1) * 16 + j];
                         if constexpr (SOC) { if (i + SPD < N) gr[(i + SPD) % SPR] = sC[cw + (i + SPD) * SLOT_D + PL_GC]; }
-                        if constexpr (LS) { if (i + SPD < N) glr[(i + SPD) % SPR] = sLG[cl + (i + SPD) * CSL]; }
-                        if constexpr (LT) { if (i + SPD < N) gtr[(i + SPD) % SPR] = sTG[cl + (i + SPD) * CSL]; }
+                        if constexpr (LSP) { if (i + SPD < N) glr[(i + SPD) % SPR] = sLG[cl + (i + SPD) * CSL]; }
+                        if constexpr (LTP) { if (i + SPD < N) gtr[(i + SPD) % SPR] = sTG[cl + (i + SPD) * CSL]; }
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (FUSED) {                  // first half of slot i's update in front of the chains (no s_nop)
                             double tt, vn, xn, t = Dn[i];
@@ -1343,19 +1396,19 @@ void admm_solve_kernel(const SolveArgs P) {
                         }
                         const double t = ring_sum<MODE, 0, NX>(Dn[i], X[i], mf1);   // f + A x_i | u_i = -d_i - Kinf x_i
                         X[i + 1] = ring_short<MODE, NX, NU>(t, t, mf2);             // x_{i+1} = (f + A x_i) + B u_i | u_i (slot i+1)
-                        slot_update(i, lo_c, hi_c, gr[SOC ? i % SPR : 0], glr[LS ? i % SPR : 0], gtr[LT ? i % SPR : 0]);
+                        slot_update(i, lo_c, hi_c, gr[SOC ? i % SPR : 0], glr[LSP ? i % SPR : 0], gtr[LTP ? i % SPR : 0]);
                         lo_c = lo_n; hi_c = hi_n;
                     }
-                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % SPR : 0], glr[LS ? (N - 1) % SPR : 0], gtr[LT ? (N - 1) % SPR : 0]);
-                    if constexpr (LIN != 0) {
+                    slot_update(N - 1, lo_c, hi_c, gr[SOC ? (N - 1) % SPR : 0], glr[LSP ? (N - 1) % SPR : 0], gtr[LTP ? (N - 1) % SPR : 0]);
+                    if constexpr (LPL) {
                         // ---- half-space projections (admm.cpp:137-211) + their dual update (:239-254), transposed
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        if constexpr (LS) {
+                        if constexpr (LSP) {
                             if (lin_x_on) project_halfspace_columns<NX, KMAX, 16, 16>(j, grp, N, CSL, 0, 0, sLV, sLG, sLin, 0, P.n_lin);
                             if (lin_u_on) project_halfspace_columns<NU, KMAX, 16, 16>(j, grp, N, CSL, NX, 1, sLV, sLG, sLin, 0, P.n_lin);
                         }
-                        if constexpr (LT) {
+                        if constexpr (LTP) {
                             if (tlin_x_on) project_halfspace_columns<NX, KMAX, 16, 16>(j, grp, N, CSL, 0, 0, sTV, sTG, sTLin, 3 * KMAX * 16, P.n_tlin);
                             if (tlin_u_on) project_halfspace_columns<NU, KMAX, 16, 16>(j, grp, N, CSL, NX, 1, sTV, sTG, sTLin, 3 * KMAX * 16, P.n_tlin);
                         }
@@ -1581,8 +1634,10 @@ void admm_solve_kernel(const SolveArgs P) {
                             P.cdual[off] = sC[cw + s * SLOT_D + PL_GC];
                         }
                     }
-                    if constexpr (LS) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = sLV[cl + s * CSL]; P.ldual[off] = sLG[cl + s * CSL]; } }
-                    if constexpr (LT) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = sTV[cl + s * CSL]; P.tldual[off] = sTG[cl + s * CSL]; } }
+                    if constexpr (LSP) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = sLV[cl + s * CSL]; P.ldual[off] = sLG[cl + s * CSL]; } }
+                    if constexpr (LTP) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = sTV[cl + s * CSL]; P.tldual[off] = sTG[cl + s * CSL]; } }
+                    if constexpr (LSR) { if (lin_lane && (P.store_mask & 16)) { P.lslack[off] = VL[s]; P.ldual[off] = GL[s]; } }
+                    if constexpr (LTR) { if (tlin_lane && (P.store_mask & 16)) { P.tlslack[off] = VT[s]; P.tldual[off] = GT[s]; } }
                     if constexpr (DBG) {
                         if (P.dbg_qr && acc_iter > 0) {
                             P.dbg_qr[off] = Qd[s];                          // work->q | work->r

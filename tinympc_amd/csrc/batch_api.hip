@@ -468,7 +468,10 @@ static bool use_tile(const TinyBatch* b) {
     if (linear_active(b) && (tile_lin_variant(b) == 0 || b->no_jit || b->tile_soc_failed)) return false;
     // (a cone on a tile shape needs the SOC variant, which only exists through run-time instantiation)
     // a one-row shape whose half-space variant does not fit a wave's LDS (its planes grow with the horizon) takes the tile kernel's
-    const bool regs_cannot = linear_active(b) && lin_variant(b) == 0 && !b->force_general;
+    // (it would run its per-knot form there, at one wave per SIMD: (8,4,30) with a cone and half-spaces 72 ms against 54)
+    const int lvr = linear_active(b) ? lin_variant(b) : 0;
+    const bool regs_cannot = linear_active(b) && !b->force_general &&
+                             (lvr == 0 || !solve_kernel_lin_planes(b->nx, b->nu, b->N, soc_active(b), lvr, lin_kmax(b), false));   // (the one-row half-space variants are instantiated without UB)
     return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile || regs_cannot) && !b->no_tile && !b->hetero && !b->adaptive && !b->force_general && !b->debug &&
            !b->d_traj && !b->reset_duals && !b->one_shot;
 }
@@ -618,15 +621,7 @@ static int lin_variant(const TinyBatch* b) {
     if (b->variant_jit_failed && b->debug) return 0;                   // LIN x debug needs hipRTC; without it: coverage kernel
     if (lin_kmax(b) == 0) return 0;                                    // too many half-spaces per knot: coverage kernel
     if (lin_kmax(b) > LIN_KMAX && (b->no_jit || b->variant_jit_failed)) return 0;
-    const int lv = ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
-    {   // the variant's static LDS: tables + two slack planes per set (+ the cone slack's three) -- a wave has 64 KiB
-        const long N = b->N, km = lin_kmax(b), nz = b->nx + b->nu, csl = (nz + 1) | 1;
-        long d = b->nx * 16 + 2 * N * 16 + (soc_active(b) ? (4 * N + 1) * 3 * csl : 0);
-        if (lv & 1) d += 3 * km * 16 + 2 * 4 * N * csl;
-        if (lv & 2) d += 3 * N * km * 16 + 2 * 4 * N * csl;
-        if (8 * d > TILE_LDS_STATIC_LIMIT) return 0;
-    }
-    return lv;
+    return ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
 }
 // cones of an ENABLED family share rows: sequential projections (admm.cpp:111-135), coverage kernel only
 static bool cones_overlap(const TinyBatch* b) {
