@@ -1503,15 +1503,18 @@ int launch_solve(TinyBatch* b) {
                 hipStream_t st[2] = {b->stream, b->stream2};
                 HIP_TRY(b, hipEventRecord(b->rg_fork, b->stream));
                 HIP_TRY(b, hipStreamWaitEvent(b->stream2, b->rg_fork, 0));
-                int done[2] = {done0, done0};
-                for (size_t c = 0; c < std::max(sched[0].size(), sched[1].size()); ++c)
-                    for (int h = 0; h < 2; ++h)
+                int done[2] = {done0, done0}, rc2 = TINY_OK;
+                for (size_t c = 0; c < std::max(sched[0].size(), sched[1].size()) && rc2 == TINY_OK; ++c)
+                    for (int h = 0; h < 2 && rc2 == TINY_OK; ++h)
                         if (c < sched[h].size()) {
-                            if (int rc = stretch(st[h], h, first[h], count[h], done[h], sched[h][c], true)) return rc;
+                            rc2 = stretch(st[h], h, first[h], count[h], done[h], sched[h][c], true);
                             done[h] += sched[h][c];
                         }
+                // (whatever happened: the batch's stream waits for what the second one was given, so that nothing the caller enqueues
+                // next can overtake it)
                 HIP_TRY(b, hipEventRecord(b->rg_join, b->stream2));
                 HIP_TRY(b, hipStreamWaitEvent(b->stream, b->rg_join, 0));
+                if (rc2 != TINY_OK) return rc2;
             } else {
                 int done = done0;
                 for (const int n : regroup_stretches(steps - done0, rk, 0)) {
