@@ -2,7 +2,9 @@
 """What VERDICT r03 ("missing" item 5) said had never been timed: wide / long shapes WITH a cone or half-spaces.  Those run on
 run-time instantiated variants of the tile kernel (all arrays in registers, trajectory in LDS, one wave per SIMD; tile_kernel.hip.h SOC /
 LIN) or, where that cannot be built, on the coverage kernel.  Per shape: box only (the compiled-in form), + an input cone, + static
-half-spaces, + both; 32 768 instances (BATCH), one cold solve, max_iter 200; median of 3 settled repetitions; FP64 fraction on box FLOPs."""
+half-spaces, + both; 32 768 instances (BATCH), one cold solve, max_iter 200; median of 3 settled repetitions; FP64 fraction on box FLOPs.
+Environment: SHAPES="12,4,10;6,3,10" (other shapes, e.g. the one-row kernel's: profiles/r04_onerow_variants_bench.md), ONLY=<substring of
+the constraint column>, TILE_R=<rows along the horizon of the variant form> (experiments), TINYMPC_AMD_JIT_DEFINES (jit.hip)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
