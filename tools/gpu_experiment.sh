@@ -1,4 +1,7 @@
 #!/bin/bash
 O=$1; mkdir -p $O; export O
-timeout 300 python -m pytest tests/test_gpu_regroup.py tests/test_gpu_repack.py -m gpu -q -x > $O/pytest_regroup.txt 2>&1; tail -3 $O/pytest_regroup.txt
-SHAPES="12,4,10;6,3,10;8,4,30;4,2,30" BATCH=65536 timeout 300 python tools/tile_variants_bench.py > $O/onerow_variants_after.md 2> $O/onerow_variants_after.err; cat $O/onerow_variants_after.md
+R=$PWD
+cd /tmp; export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/regroup_stats -o rg -- python $R/tools/regroup_bench.py --cones input --ks -1 --reps 3 > $R/$O/regroup_stats.out 2> $R/$O/regroup_stats.err
+cd $R; find $O/regroup_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/regroup_kernel_stats.csv; cat $O/regroup_kernel_stats.csv | cut -c1-200; cat $O/regroup_stats.out
+rm -rf $O/regroup_stats
