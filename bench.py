@@ -25,7 +25,11 @@ torch.distributed) closes every timed repetition.  --scaling weak (default): 65 
 Under weak scaling with N > 1 the strong-scaling form is measured as well, after the headline, and reported as
 `strong_scaling` in the same line.
 
-Rooflines (all in the one JSON line):
+Output: stdout carries exactly ONE line, compact (compact_line: <= 4 KiB of strict JSON -- the contract's keys, `roofline`,
+`cpu_baseline`, a few numbers per regime and per `configs` entry); the full record described below goes to
+gpurun_out/bench_details.json (the line names it under `details`).
+
+Rooflines (full record; the line keeps frac / achieved / peak / kernel / avg_launch_ms of each):
   roofline         the bound that BINDS the timed launches: FP64 VALU issue when the launches carry many
                    ADMM iterations (cold / fused steps), HBM when they are single warm steps; `traffic` = HBM
                    bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json, `traffic_source`)
@@ -33,6 +37,8 @@ Rooflines (all in the one JSON line):
   regimes          an untimed replay of the reference episode with ONE launch per MPC step after the
                    timed region: cold steps 0-4 (FP64 fraction) and steady state steps 70-99 -- `hbm_frac` counts the
                    bytes the launch form really moves, `hbm_frac_formula` SURVEY.md 8(d)'s bytes_warm
+                   `regimes.beyond_l3`: the same replay at batch 262 144 (working set ~4x the 256 MiB Infinity Cache), the
+                   line's `roofline_hbm` -- the warm regime where the records really come from HBM
   configs          (1 GPU) BASELINE configs 3, 4 (input cone / state cone / both) and six cells of config 5, each with its own
                    roofline (median), a parity sample against the oracle and the reference timed on the same records
   cpu_baseline     (1 GPU) the real reference on the host cores, AFTER the GPU legs, in processes of its own
@@ -116,6 +122,143 @@ def traffic_per_launch(T, B):
     return None, None
 
 
+COMPACT_LINE_LIMIT = 4096    # bytes: the driver keeps a bounded tail of stdout (r04's 32 992-byte line was dropped)
+DETAILS_PATH = os.path.join("gpurun_out", "bench_details.json")
+
+
+def _r(x, digits=5):
+    """a float with `digits` significant digits (None / non-finite -> None: the line must be strict JSON)"""
+    if x is None:
+        return None
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def _config_summary(e):
+    """one `configs` entry of the details file -> the few numbers of it the line carries"""
+    if not isinstance(e, dict):
+        return None
+    if "error" in e or "skipped" in e:
+        return {"error": str(e.get("error", e.get("skipped")))[:80]}
+    c = {"ms": _r(e.get("ms")), "frac": _r((e.get("roofline") or {}).get("frac"), 4), "path": e.get("kernel")}
+    tr = e.get("traffic")
+    if isinstance(tr, dict) and tr.get("ratio_traffic_over_algorithmic") is not None:
+        c["traffic_ratio"] = _r(tr["ratio_traffic_over_algorithmic"], 3)
+    ps = e.get("parity_sample")
+    if isinstance(ps, dict):
+        c["mismatches"] = ps.get("iteration_count_mismatches", ps.get("error"))
+    if e.get("first_call_ms") is not None:
+        c["first_call_ms"] = _r(e["first_call_ms"])
+    return c
+
+
+def compact_line(out, details_path=None):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` and a handful of numbers per regime / config, at
+    most COMPACT_LINE_LIMIT bytes of strict JSON.  Everything else the run measured (timed_region, regimes, full `configs`
+    entries, notes) goes to the details file this line names.  Pure function of `out` (tests/test_bench_cpu.py feeds it canned
+    input): if the line still comes out too long, the optional blocks are dropped one by one, never the contract's keys."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(out.get("value"), 7), _r(out.get("ms_per_step"), 6)
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "batch_per_gpu", "total_batch", "parallelism", "mpc_steps_per_launch", "stats_exchange")
+                      if k in cfg}
+    if "error" in out:
+        line["error"] = str(out["error"])[:600]
+    for k in ("rccl_ranks", "solved_fraction"):
+        if k in out:
+            line[k] = out[k]
+    for k in ("admm_iters_per_s", "admm_iters_per_solve"):
+        if k in out:
+            line[k] = _r(out[k], 6)
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                            "frac": _r(rf.get("frac"), 4), "traffic": rf.get("traffic"),
+                            "traffic_source": "cited" if rf.get("traffic") is not None else None,
+                            "kernel": rf.get("kernel"), "avg_launch_ms": _r(rf.get("avg_launch_ms")),
+                            "mpc_steps_per_launch": rf.get("mpc_steps_per_launch")}
+    optional = []
+    rh, rq = out.get("roofline_hbm"), out.get("roofline_fp64")
+    if isinstance(rh, dict) and isinstance(rq, dict):
+        line["roofline_timed"] = {"hbm_frac": _r(rh.get("frac"), 4), "fp64_frac": _r(rq.get("frac"), 4)}
+        optional.append("roofline_timed")
+    reg = out.get("regimes")
+    if isinstance(reg, dict):
+        w = {}
+        for key, short in (("steady_state", "shared_ref"), ("steady_state_per_instance_refs", "own_refs")):
+            r_ = reg.get(key)
+            if isinstance(r_, dict):
+                w[short] = {"hbm_frac": _r(r_.get("hbm_frac"), 4), "gbs": _r(r_.get("hbm_gbs"), 4), "ms": _r(r_.get("ms_per_launch"), 4)}
+        if w:
+            w["batch"] = (out.get("config") or {}).get("batch_per_gpu")
+            w["beyond_L3"] = False
+            line["warm_regime"] = w
+            optional.append("warm_regime")
+        big = reg.get("beyond_l3")
+        if isinstance(big, dict) and "error" not in big:
+            b_ = {"batch": big.get("batch"), "beyond_L3": True}
+            for key, short in (("steady_state", "shared_ref"), ("steady_state_per_instance_refs", "own_refs")):
+                r_ = big.get(key)
+                if isinstance(r_, dict):
+                    b_[short] = {"hbm_frac": _r(r_.get("hbm_frac"), 4), "gbs": _r(r_.get("hbm_gbs"), 4), "ms": _r(r_.get("ms_per_launch"), 4)}
+            line["roofline_hbm"] = b_
+            optional.append("roofline_hbm")
+        cold = reg.get("cold")
+        if isinstance(cold, dict):
+            line["cold_regime"] = {"fp64_frac": _r(cold.get("fp64_frac"), 4), "ms": _r(cold.get("ms_per_launch"), 4)}
+            optional.append("cold_regime")
+    cpu = out.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        if "error" in cpu:
+            line["cpu_baseline"] = {"error": str(cpu["error"])[:200]}
+        else:
+            line["cpu_baseline"] = {"value": _r(cpu.get("value"), 6), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                    "sample": str(cpu.get("sample", ""))[:200]}
+    cfgs = out.get("configs")
+    if isinstance(cfgs, dict):
+        line["configs"] = {k: _config_summary(v) for k, v in cfgs.items()}
+        mism = [v.get("mismatches") for v in line["configs"].values() if isinstance(v, dict) and "mismatches" in v]
+        line["parity"] = {"entries_checked": len(mism), "mismatches": (sum(m for m in mism if isinstance(m, int)) if all(isinstance(m, int) for m in mism)
+                                                                       else "see details")}
+        optional[:0] = ["configs"]
+    if "strong_scaling" in out and isinstance(out["strong_scaling"], dict):
+        ss = out["strong_scaling"]
+        line["strong_scaling"] = {"total_batch": ss.get("total_batch"), "value": _r(ss.get("value"), 7), "ms_per_step": _r(ss.get("ms_per_step"), 6)}
+        optional.append("strong_scaling")
+    if "wall_seconds" in out:
+        line["wall_seconds"] = out["wall_seconds"]
+    if details_path:
+        line["details"] = details_path
+
+    def dumps(d):
+        return json.dumps(d, allow_nan=False, separators=(",", ":"))
+    text = dumps(line)
+    while len(text) > COMPACT_LINE_LIMIT and optional:
+        line.pop(optional.pop(0), None)
+        line["truncated"] = True
+        text = dumps(line)
+    return text
+
+
+def write_details(out, path=None):
+    """the full record of the run (every regime, every `configs` entry with its notes) -> gpurun_out/bench_details.json; returns
+    the path written, or None (an unwritable directory must not cost the run its line)"""
+    path = path or os.path.join(ROOT, DETAILS_PATH)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, default=lambda o: repr(o))
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,9 +281,13 @@ def parse_args(argv=None):
     ap.add_argument("--configs-budget", type=float, default=60.0, help="seconds after which no further config entry is started")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, weak scaling: skip the additional strong-scaling measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
-    ap.add_argument("--configs-cpu-seconds", type=float, default=1.0,
-                    help="seconds of reference solve time per host core and `configs` entry (oracle/config_check.py)")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="seconds of reference solve time per host core (the cpu_baseline leg)")
+    ap.add_argument("--configs-cpu-seconds", type=float, default=0.25,
+                    help="seconds of reference solve time per checker process and `configs` entry (oracle/config_check.py); 0 = parity sample only")
+    ap.add_argument("--configs-cpu-cores", type=int, default=64, help="checker processes of the `configs` leg (a bounded sample of the host's cores)")
+    ap.add_argument("--beyond-l3-batch", type=int, default=262144,
+                    help="1 GPU: batch of the second warm-regime replay, whose working set is several times the 256 MiB Infinity Cache (0 = skip)")
+    ap.add_argument("--details", default=None, help="where the full record goes (default gpurun_out/bench_details.json)")
     ap.add_argument("--dist-timeout", type=float, default=120.0,
                     help="N > 1: seconds a rendezvous / process-group collective / communicator setup may take before the rank gives up")
     ap.add_argument("--run-timeout", type=float, default=900.0,
@@ -165,8 +312,10 @@ def error_line(args, world, message, **extra):
         pre["library_error"] = repr(e)
     pre["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
     out["preflight"] = pre
-    out.update(extra)
-    return json.dumps(out)
+    out["error"] = str(message)[:1200]
+    for k, v in extra.items():                           # launcher_rc, partial_lines ...: bounded, the line must stay parseable
+        out[k] = [str(x)[:300] for x in v[:2]] if isinstance(v, (list, tuple)) else v
+    return json.dumps(out, allow_nan=False, default=repr)
 
 
 def spawn_ranks(args):
@@ -225,6 +374,13 @@ def spawn_ranks(args):
     return 1 if (timed_out or p.returncode == 0) else (p.returncode if 0 < p.returncode < 256 else 1)
 
 
+_PHASE = ["start", 0.0]      # what the rank is doing and since when (the N > 1 watchdog reads it)
+
+
+def enter_phase(name):
+    _PHASE[0], _PHASE[1] = name, time.perf_counter()
+
+
 class Job:
     """One rank's view of the job: device, process group, barrier, max over ranks."""
 
@@ -254,11 +410,13 @@ class Job:
                     time.sleep(1e6)
                 os._exit(17)
             to = datetime.timedelta(seconds=float(os.environ.get("TINYMPC_DIST_TIMEOUT", args.dist_timeout)))
+            enter_phase("process_group")
             if self.share_gpu:
                 os.environ["TINYMPC_EXCHANGE"] = "torch"
                 dist.init_process_group("gloo", timeout=to)
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), timeout=to)   # "nccl" is RCCL on ROCm
+        enter_phase("solver_setup")
         self.one = torch.zeros(1, device=self.dev)
         self.stream = torch.cuda.Stream(device=self.local_rank)
 
@@ -285,7 +443,7 @@ class Job:
 class Hover:
     """BASELINE configs[1] on this rank's shard: the solver, its cold start, the timed repetition."""
 
-    def __init__(self, job, args, B, total_batch):
+    def __init__(self, job, args, B, total_batch, exchange=True):
         import numpy as np
         import tinympc_amd as tm
         from tinympc_amd.distributed import StatsExchange
@@ -313,7 +471,11 @@ class Hover:
         self.xref = np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N))
         self.x0 = np.array(h["x0"], dtype=np.float64)
         self.stats = job.torch.zeros(10, dtype=job.torch.float64, device=job.dev)
-        self.exchange = StatsExchange(s, job.dist, job.local_rank, total_batch=total_batch) if job.dist is not None else None
+        self.exchange = None
+        if job.dist is not None and exchange:
+            enter_phase("communicator")
+            self.exchange = StatsExchange(s, job.dist, job.local_rank, total_batch=total_batch)
+            enter_phase("solver_setup")
 
     def cold_start(self):
         self.s.reset()
@@ -372,7 +534,7 @@ class Hover:
         self.s.close()
 
 
-def regimes_replay(hv, fl, bytes_warm):
+def regimes_replay(hv, fl, bytes_warm, full=True, reps=5):
     """Untimed replay (rank 0): the same episode with ONE launch per MPC step, so that the two regimes SURVEY.md 8(d) asks
     for are visible in every line -- cold steps (100 ADMM iterations each, FP64 bound) and steady state (1-2 iterations:
     every launch loads and stores the records, the real HBM roofline of this path).  Median over five replays."""
@@ -384,7 +546,7 @@ def regimes_replay(hv, fl, bytes_warm):
         runs = []
         s.set_option("store_primal", store_primal)
         s.set_option("share_ref", share_ref)
-        for _ in range(5):
+        for _ in range(reps):
             hv.cold_start()
             s.set_option("timing", 100)
             for _ in range(100):
@@ -399,8 +561,8 @@ def regimes_replay(hv, fl, bytes_warm):
         s.set_option("steps_per_launch", 1)
         ms = replay(1)
         ms_own = replay(1, share_ref=0)
-        ms_lean = replay(0)
-        ms_u0 = replay(2)
+        ms_lean = replay(0) if full else None
+        ms_u0 = replay(2) if full else None
         # the iteration count of every step of the episode (all instances are identical): which launches skip the v|z store
         hv.cold_start()
         iters = []
@@ -422,7 +584,8 @@ def regimes_replay(hv, fl, bytes_warm):
                 "hbm_frac_formula": bytes_warm * B / t / 1e9 / HBM_PEAK_GBS, "note": note}
 
     cold = float(ms[:5].mean()) * 1e-3
-    return {
+    out = {
+        "batch": B,
         "cold": {"steps": "0-4", "admm_iters_per_solve": float(iters[:5].mean()), "ms_per_launch": cold * 1e3,
                  "fp64_tflops": float(iters[:5].mean()) * B * fl / cold / 1e12,
                  "fp64_frac": float(iters[:5].mean()) * B * fl / cold / 1e12 / FP64_PEAK_TFLOPS},
@@ -434,14 +597,36 @@ def regimes_replay(hv, fl, bytes_warm):
         "steady_state_per_instance_refs": steady(ms_own, False, 1,
                                                  "option share_ref = 0: every instance reads its OWN reference record, what any "
                                                  "non-identical batch needs -- the general warm-step figure of this path"),
-        "steady_state_no_primal_store": steady(ms_lean, True, 0,
-                                               "option store_primal = 0: x|u is not written back either (no consumer between steps when "
-                                               "the plant step runs on the device; solution->x|u = vnew|znew is still stored)"),
-        "steady_state_first_knot_store": steady(ms_u0, True, 2,
-                                                "option store_primal = 2: of x|u only x[:,0], x[:,1], u[:,0] are written (the control a "
-                                                "closed-loop caller applies)"),
         "iters_per_step": iters.tolist(),
     }
+    if full:
+        out["steady_state_no_primal_store"] = steady(ms_lean, True, 0,
+                                                     "option store_primal = 0: x|u is not written back either (no consumer between steps when "
+                                                     "the plant step runs on the device; solution->x|u = vnew|znew is still stored)")
+        out["steady_state_first_knot_store"] = steady(ms_u0, True, 2,
+                                                      "option store_primal = 2: of x|u only x[:,0], x[:,1], u[:,0] are written (the control a "
+                                                      "closed-loop caller applies)")
+    return out
+
+
+def beyond_l3_replay(job, args, fl, batch):
+    """The warm regime where the records really come from HBM: the same one-launch-per-step replay over a batch
+    whose working set is several times the 256 MiB Infinity Cache (262 144 instances x ~3.7 KB of records per warm solve ~ 1 GB),
+    shared and per-instance reference records."""
+    try:
+        hb = Hover(job, args, batch, batch, exchange=False)
+        with job.torch.cuda.stream(job.stream):          # one untimed episode: first-use costs of this batch size
+            hb.cold_start()
+            hb.s.set_option("steps_per_launch", hb.Tw)
+            hb.s.solve_async()
+            hb.s.synchronize()
+        r = regimes_replay(hb, fl, hb.s.algorithmic_bytes(cold=False), full=False, reps=3)
+        hb.close()
+        r.pop("iters_per_step", None)
+        r["working_set_bytes"] = int(batch * r["steady_state_per_instance_refs"]["bytes_moved_per_solve"])
+        return r
+    except Exception as e:                               # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def cpu_baseline_subprocess(seconds, steps):
@@ -459,9 +644,9 @@ def cpu_baseline_subprocess(seconds, steps):
         return {"error": repr(e)}
 
 
-def config_check_subprocess(spec_path, seconds):
+def config_check_subprocess(spec_path, seconds, cores=None):
     code = ("import sys, json; sys.path.insert(0, %r); import config_check; "
-            "print('@@CHK@@' + json.dumps(config_check.run(%r, seconds=%r)))" % (os.path.join(ROOT, "oracle"), spec_path, seconds))
+            "print('@@CHK@@' + json.dumps(config_check.run(%r, seconds=%r, cores=%r)))" % (os.path.join(ROOT, "oracle"), spec_path, seconds, cores))
     try:
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=max(300.0, 200 * seconds))
         for line in p.stdout.splitlines():
@@ -486,7 +671,7 @@ def main():
     # A rank of an N > 1 job must never end in silence: whatever stops it -- an exception out of a collective that timed out
     # (--dist-timeout), a setup phase that never returns (watchdog below: ncclCommInitRank has no timeout of its own) -- rank 0
     # still writes ONE JSON line with "error" before it leaves.
-    setup_done = [False]
+    setup_done = _PHASE
 
     def give_up(message):
         if env_rank == 0:
@@ -497,9 +682,12 @@ def main():
         import threading
 
         def watchdog():
-            time.sleep(args.dist_timeout)
-            if not setup_done[0]:
-                give_up("rank %d: process group / RCCL communicator setup did not finish within --dist-timeout %.0f s" % (env_rank, args.dist_timeout))
+            # only the phases that can hang without a timeout of their own are on the clock (rendezvous / init_process_group,
+            # ncclCommInitRank inside StatsExchange): a slow cold start of the solver itself (library load, first-use hipRTC) is not
+            while _PHASE[0] != "measuring":
+                time.sleep(1.0)
+                if _PHASE[0] in ("process_group", "communicator") and time.perf_counter() - _PHASE[1] > args.dist_timeout:
+                    give_up("rank %d: %s setup did not finish within --dist-timeout %.0f s" % (env_rank, _PHASE[0], args.dist_timeout))
         threading.Thread(target=watchdog, daemon=True).start()
     try:
         run(args, result_fd, setup_done)
@@ -531,7 +719,7 @@ def run(args, result_fd, setup_done):
         with job.torch.cuda.stream(job.stream):
             hv.exchange()
             job.barrier()
-    setup_done[0] = True
+    enter_phase("measuring")
     nx, nu, N, T, launches = hv.nx, hv.nu, hv.N, hv.T, hv.launches
     m = hv.measure(args.min_seconds)
     elapsed, rep_s, st = m["elapsed"], m["rep_s"], m["st"]
@@ -543,6 +731,7 @@ def run(args, result_fd, setup_done):
     regimes = None
     if rank == 0 and not args.no_regimes:
         regimes = regimes_replay(hv, fl, bytes_warm)
+        regimes["traffic_note"] = "roofline.traffic is a citation of a committed rocprofv3 PMC run (profiles/traffic.json), not of this run"
     exchange_kind = hv.exchange.kind if hv.exchange is not None else "none (one rank)"
     # ranks of the communicator the exchange really ran on: asked of RCCL (ncclCommCount) on the native path, of the process group
     # when the exchange went through torch.distributed (`stats_exchange` says which)
@@ -553,6 +742,8 @@ def run(args, result_fd, setup_done):
     else:
         rccl_ranks = job.dist.get_world_size()
     hv.close()
+    if regimes is not None and world == 1 and args.beyond_l3_batch > 0:
+        regimes["beyond_l3"] = beyond_l3_replay(job, args, fl, args.beyond_l3_batch)
 
     # N > 1 under weak scaling: the strong-scaling form of the metric as well (65 536 instances in TOTAL, sharded)
     strong_extra = None
@@ -582,7 +773,7 @@ def run(args, result_fd, setup_done):
         # ... and the checker of the `configs` entries: the oracle on a sample of each entry's own records (`parity_sample`), the
         # real reference timed on the same records (`cpu_baseline` of the entry) -- oracle/config_check.py, processes of its own
         if configs is not None and spec_path and os.path.exists(spec_path):
-            chk = config_check_subprocess(spec_path, args.configs_cpu_seconds)
+            chk = config_check_subprocess(spec_path, args.configs_cpu_seconds, args.configs_cpu_cores)
             for name, e in configs.items():
                 if isinstance(chk.get(name), dict) and "error" not in e and "skipped" not in e:
                     e.update(chk[name])
@@ -650,8 +841,10 @@ def run(args, result_fd, setup_done):
             out["configs"] = configs
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        out["wall_seconds"] = _r(time.perf_counter() - t_start, 4)
+        details = write_details(out, args.details)
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        os.write(result_fd, (compact_line(out, details) + "\n").encode())
     job.close()
 
 

@@ -131,7 +131,7 @@ def run(spec_path, seconds=1.0, cores=None):
                                iteration_count_mismatches=int((g_it != it).sum()), solves_compared=int(it.size),
                                max_rel_err_u0=rel,
                                note="per solve: |iterations| and the solved flag (sign) must be equal; u[:,0] relative to the solve's largest |u0| entry"),
-            cpu_baseline=dict(value=rate, unit="QP solves/s", cores=active, kind=kind, admm_iters_per_s=irate,
+            cpu_baseline=None if seconds <= 0 else dict(value=rate, unit="QP solves/s", cores=active, kind=kind, admm_iters_per_s=irate,
                               admm_iters_per_solve=iters / max(solves, 1),
                               sample="%d of this entry's own input records (%s), %d solves in %.1f s of solve time per core, one process per core, "
                                      "cold state restored and inputs set outside the clock" % (n, e["kind"], solves, busy_max)))

@@ -122,7 +122,6 @@ class StatsExchange:
         except Exception:                            # noqa: BLE001
             can = False
         ok = self._agree(can)
-        self.timeout_s = float(os.environ.get("TINYMPC_DIST_TIMEOUT", "120"))
         if ok:
             try:
                 box = [tm.rccl_unique_id() if self.rank == 0 else None]
