@@ -271,3 +271,50 @@ def test_tile_cone_variant_fused_steps_equal_single_step_launches(dims):
     assert outs[0]["acc"][0] > T
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("dims", [(8, 4, 10), (12, 4, 30)])
+def test_lean_shape_without_hiprtc_falls_back_to_the_coverage_kernel(dims):
+    """a LEAN shape of kernel_dims.txt carries only its box kernel compiled in.  A cone / debug-output launch whose
+    variant hipRTC cannot make (option no_jit stands for a box without hipRTC or a compile error) must be served by the coverage
+    kernel -- as for a shape outside kernel_dims.txt -- not refused; the box launch of the same batch stays on the one-row kernel."""
+    nx, nu, N = dims
+    assert dims in tm.supported_dims()
+    suite = sc.sweep_suite(nx, nu, N, B=6, max_iter=60)
+    cfg = suite["config"]
+    cfg.update(en_input_soc=1, input_cone=([0], [3], [0.6]))
+    ref = sc.run_cases(OracleSolver, suite)
+    out = run_cases_hip(suite, options={"no_jit": 1})
+    assert np.array_equal(out["iter"].astype(int), ref["iter"].astype(int))
+    for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z", "vcnew", "gc"):
+        assert rel_err(out[k], ref[k]) < RTOL, k
+    s = make_batch(suite)
+
+    def settings(**kw):
+        c = dict(cfg, **kw)
+        s.update_settings(c["abs_pri_tol"], c["abs_dua_tol"], c["max_iter"], c["check_termination"], c["en_state_bound"], c["en_input_bound"],
+                          c["en_state_soc"], c["en_input_soc"])
+    s.set_option("no_jit", 1)
+    s.set_x0(suite["cases"]["x0"])
+    s.set("Xref", suite["cases"]["Xref"])
+    s.solve()
+    assert s.kernel_path() == "cover"                 # the cone launch went to the coverage kernel
+    settings(en_input_soc=0)                          # ... the box launch of the same handle does not
+    s.reset()
+    s.set_x0(suite["cases"]["x0"])
+    s.set("Xref", suite["cases"]["Xref"])
+    s.solve()
+    assert s.kernel_path() == "regs"
+    s.set_option("debug", 1)                          # debug outputs of a lean shape: not compiled in either
+    s.solve()
+    assert s.kernel_path() == "cover"
+    # what the coverage kernel cannot do is still refused, loudly
+    s.set_option("debug", 0)
+    settings(en_input_soc=1)
+    s.set_option("steps_per_launch", 3)
+    with pytest.raises(tm.TinyMPCError):
+        s.solve()
+    s.set_option("no_jit", 0)                         # with hipRTC back the variant is instantiated and the launch runs
+    s.solve()
+    assert s.kernel_path() == "regs"
+    s.close()

@@ -437,7 +437,9 @@ static void build_tile_tables_w(TinyBatch* b) {
     for (int j = 0; j < nx + nu && uniform; ++j)
         for (int i = (j < nx ? 0 : 1); i < N && uniform; ++i)
             uniform = lo[i * LW + j] == lo[LW + j] && hi[i * LW + j] == hi[LW + j];
-    b->tile_bounds_uniform = uniform;
+    // (one predicate for the decision -- tile_lin_variant / use_tile budget the UB form from the host bounds -- and for the launch: the
+    // table is a copy of those bounds, so the two agree by construction; should they ever not, the non-UB form is the safe one)
+    b->tile_bounds_uniform = uniform && box_is_uniform(b);
 }
 
 static bool soc_active(const TinyBatch* b);
@@ -534,7 +536,7 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         if (!jit_fn) {                               // the coverage kernel takes over
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }
-            b->tab_dirty = true;
+            b->tab_dirty = true; b->redispatch = true;
             return launch_solve(b);
         }
     }
@@ -621,7 +623,19 @@ static int lin_variant(const TinyBatch* b) {
     if (b->variant_jit_failed && b->debug) return 0;                   // LIN x debug needs hipRTC; without it: coverage kernel
     if (lin_kmax(b) == 0) return 0;                                    // too many half-spaces per knot: coverage kernel
     if (lin_kmax(b) > LIN_KMAX && (b->no_jit || b->variant_jit_failed)) return 0;
-    return ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
+    const int lv = ((b->set.en_state_linear || b->set.en_input_linear) ? 1 : 0) | ((b->set.en_tv_state_linear || b->set.en_tv_input_linear) ? 2 : 0);
+    // a LEAN shape (kernel_entry.hpp KERNELS_LEAN) carries no half-space variant compiled in: without hipRTC the coverage kernel serves it
+    if (b->variant_jit_failed && b->kernel && !b->hetero && !b->kernel->klin[soc_active(b) ? 1 : 0][lv]) return 0;
+    return lv;
+}
+// The compiled-in instantiation of the one-row kernel that serves a box / cone launch with these debug outputs and FMA block
+// form, nullptr if the shape's set does not hold it (LEAN shapes: only <box, no debug, mode 2> and the UB form)
+static SolveKernel compiled_in_plain_variant(const TinyBatch* b, bool soc, bool dbg, int mode) {
+    if (!b->kernel) return nullptr;
+    if (!dbg && mode == 2 && b->bounds_uniform && b->use_ub) {
+        if (SolveKernel k = soc ? b->kernel->kubsoc : b->kernel->kub) return k;
+    }
+    return b->kernel->k[soc ? 1 : 0][dbg ? 1 : 0][mode];
 }
 // cones of an ENABLED family share rows: sequential projections (admm.cpp:111-135), coverage kernel only
 static bool cones_overlap(const TinyBatch* b) {
@@ -631,7 +645,11 @@ static bool use_general(const TinyBatch* b) {
     if (cones_overlap(b)) return true;
     if (b->adaptive) return false;                    // adaptive rho lives on the one-row kernel only (launch_solve refuses the rest)
     if (linear_active(b)) return lin_variant(b) == 0;
-    return !b->hetero && (!has_regs(b) || b->force_general);
+    if (b->hetero) return false;
+    // a variant outside the compiled-in set of a LEAN shape that hipRTC could not make either (no_jit, no hipRTC on the box, a
+    // compile error): the coverage kernel serves cone / debug / dpp-mode launches exactly as it does for shapes outside kernel_dims.txt
+    if (b->variant_jit_failed && b->kernel && !compiled_in_plain_variant(b, soc_active(b), b->debug, (b->dpp_mode >= 0 && b->dpp_mode <= 2) ? b->dpp_mode : 0)) return true;
+    return !has_regs(b) || b->force_general;
 }
 
 // Tables of the coverage kernel (general_kernel.hip.h): row-major [row][nz+1] matrices + vectors + constraints.
@@ -1156,6 +1174,9 @@ static std::vector<int> regroup_stretches(int steps, int K, int lead) {
 }
 constexpr int REGROUP_AUTO_MIN_STEPS = 16, REGROUP_AUTO_MIN_BATCH = 4096;
 static int regroup_auto_k(int steps) { return std::max(8, (steps + 3) / 4); }
+// the two-stream form (halves of the batch half a stretch out of step) only makes sense when more than one stretch is left after the
+// lead step: the condition the launch and tiny_step_regroup_plan share
+static bool regroup_two_streams_apply(int steps, int lead, int K) { return steps - lead > K; }
 
 // index lists + per-stage counters of the split solve: [stage] list lengths, [32 + stage] tile counters
 static int ensure_repack_buffers(TinyBatch* b) {
@@ -1171,7 +1192,11 @@ int launch_solve(TinyBatch* b) {
     // solve saved (the first solve after a reset: BASELINE configs 3 and 5, every cold start).  Any launch ends that knowledge.
     const bool zero_state = b->records_zero;
     b->records_zero = false;
-    if (b->tab_dirty) b->tab_gen++;                  // something the tables are built from has changed since the last launch
+    if (b->tab_dirty) {                              // something the tables are built from has changed since the last launch
+        b->tab_gen++;
+        if (!b->redispatch) b->tile_soc_failed = false;   // (a failed variant instantiation is retried when the CALLER changed something)
+    }
+    b->redispatch = false;
     if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
         return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
     if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
@@ -1281,16 +1306,20 @@ int launch_solve(TinyBatch* b) {
         else jit_fn = jit_solve_kernel(jk, &why);
         if (!jit_fn) {
             if (b->kernel) {
-                if (jk.lin && !jk.het && !b->variant_jit_failed) {     // half-spaces + debug outputs: the coverage kernel can do it
+                // the shape's compiled-in set does not hold this variant (half-spaces + debug outputs; any cone / debug / dpp-mode /
+                // half-space variant of a LEAN shape) and hipRTC could not make it: the coverage kernel can do everything but
+                // per-instance data, adaptive rho and the fused / windowed / one-shot launch forms
+                const bool general_can = !jk.het && !jk.adapt && steps == 1 && !b->d_traj && !b->reset_duals && !b->one_shot;
+                if (general_can && !b->variant_jit_failed) {
                     b->variant_jit_failed = true;
-                    b->tab_dirty = true;
+                    b->tab_dirty = true; b->redispatch = true;
                     return launch_solve(b);
                 }
-                return fail(b, TINY_ERR_UNSUPPORTED, "this combination of debug outputs / half-spaces / per-instance data needs hipRTC: %s", why.c_str());
+                return fail(b, TINY_ERR_UNSUPPORTED, "this combination of cone / debug outputs / half-spaces / per-instance data / launch form needs hipRTC: %s", why.c_str());
             }
             if (b->adaptive) return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho kernel for (nx,nu,N)=(%d,%d,%d) could not be instantiated: %s", b->nx, b->nu, b->N, why.c_str());
             b->jit_failed = true;                    // has_regs() turns false: the coverage kernel takes over
-            b->tab_dirty = true;
+            b->tab_dirty = true; b->redispatch = true;
             if (b->hetero || b->steps_per_launch > 1 || b->d_traj || b->reset_duals || b->one_shot)
                 return fail(b, TINY_ERR_UNSUPPORTED, "no register-resident kernel for (nx,nu,N)=(%d,%d,%d): %s", b->nx, b->nu, b->N, why.c_str());
             return launch_solve(b);
@@ -1496,7 +1525,7 @@ int launch_solve(TinyBatch* b) {
                 done0 = 1;
             }
             const int half0 = ((b->batch / 2 + 7) / 8) * 8;
-            if (b->regroup_streams == 2 && b->stream2 && half0 < b->batch && (b->step_regroup > 0 || b->batch >= 2 * REGROUP_AUTO_MIN_BATCH) && steps - done0 > rk) {
+            if (b->regroup_streams == 2 && b->stream2 && half0 < b->batch && (b->step_regroup > 0 || b->batch >= 2 * REGROUP_AUTO_MIN_BATCH) && regroup_two_streams_apply(steps, done0, rk)) {
                 // two halves on two streams, the second one half a stretch out of step with the first
                 const int first[2] = {0, half0}, count[2] = {half0, b->batch - half0};
                 const std::vector<int> sched[2] = {regroup_stretches(steps - done0, rk, 0), regroup_stretches(steps - done0, rk, (rk + 1) / 2)};
@@ -2160,7 +2189,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "dpp_mode")) b->dpp_mode = (int)value;
     else if (!strcmp(name, "steps_per_launch")) b->steps_per_launch = (int)value;
     else if (!strcmp(name, "force_general")) { b->force_general = value != 0; b->tab_dirty = true; }
-    else if (!strcmp(name, "no_jit")) { b->no_jit = value != 0; b->tab_dirty = true; }
+    else if (!strcmp(name, "no_jit")) { b->no_jit = value != 0; b->tab_dirty = true; if (!b->no_jit) b->variant_jit_failed = false; }
     else if (!strcmp(name, "no_tile")) { b->no_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "tile_dyn")) b->tile_dyn_opt = (int)value;   // -1 (default): by batch size; 0: static tiles; 1: the dynamic form whenever it exists
@@ -2279,7 +2308,7 @@ int tiny_step_regroup_plan(int steps, int k, int known, int half, int* out, int 
     int lead = 0;
     if (!known && steps > 1) { plan.push_back(1); lead = 1; }
     if (K < steps)
-        for (const int n : regroup_stretches(steps - lead, K, half ? (K + 1) / 2 : 0)) plan.push_back(n);
+        for (const int n : regroup_stretches(steps - lead, K, (half && regroup_two_streams_apply(steps, lead, K)) ? (K + 1) / 2 : 0)) plan.push_back(n);
     else plan.assign(1, steps);
     for (int i = 0; i < (int)plan.size() && i < capacity; ++i) out[i] = plan[i];
     return (int)plan.size();

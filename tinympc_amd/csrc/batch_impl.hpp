@@ -33,6 +33,7 @@ struct TinyBatch {
     std::vector<double> h_ttab;
     tinympc_amd::TileEntry tile_dyn = {0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};   // tile shape chosen at run time (b->tile points here; jit.hpp)
     bool tile_is_jit = false, tile_soc_failed = false;
+    bool redispatch = false;                     // launch_solve re-entered by itself after a failed instantiation (not a caller-side change)
     bool no_jit = false, jit_failed = false, variant_jit_failed = false;     // run-time instantiation of the one-row kernel for shapes outside kernel_dims.txt (jit.hpp)
     int tile_verdict = 0, tile_since = 0;        // the dynamic tile form tried on a one-row shape: 1 kept, -1 rejected, 0 open (batch_api.hip launch_solve)
     double tile_rate = 0.0;
