@@ -387,6 +387,19 @@ def sweep_suite(nx, nu, N, B=4, max_iter=500):
     return dict(problem=prob, config=cfg, cases=cases)
 
 
+def sweep_cone_suite(nx, nu, N, B=3, max_iter=120, state_cone=False, seed=31):
+    """a config-5 sweep cell with a second-order cone on the first three inputs (and, state_cone, on three states) and a warm
+    random slack / dual state: the tile kernel's cone variant on wide / long shapes (tile_dims.txt)"""
+    suite = sweep_suite(nx, nu, N, B=B, max_iter=max_iter)
+    rng = np.random.default_rng(seed)
+    suite["config"].update(en_input_soc=1, input_cone=([0], [3], [0.6]) if nu >= 3 else ([0], [2], [0.6]))
+    if state_cone:
+        suite["config"].update(en_state_soc=1, state_cone=([1], [3], [0.8]))
+    for k in ("vnew", "znew", "g", "y", "v", "z", "gc", "yc", "x", "u"):
+        suite["cases"][k] = rng.normal(0.0, 0.2, suite["cases"][k].shape)
+    return suite
+
+
 def random_state_suite(name="quadrotor_20hz", B=8, seed=7, scale=0.3, soc=False):
     """Fully random warm state (every input array random) -- transpose-detecting: no
     symmetric / replicated structure anywhere (guide rule 16)."""

@@ -17,7 +17,8 @@ BUILD = os.path.join(ROOT, "tests", "dropin", "_build")
 def test_reference_example_stdout_identical(ex):
     exe = os.path.join(BUILD, ex)
     if not os.path.exists(exe):
-        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+        pytest.fail("tests/dropin/_build/%s is missing: the drop-in binaries are built by __graft_entry__.build() in the container that has "
+                    "/root/reference and travel to the GPU box with the snapshot -- a box without them must not pass the (b) row by skipping it" % os.path.basename(exe))
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     gold = open(os.path.join(ROOT, "tests", "golden", f"stdout_{ex}.txt")).read()
@@ -35,7 +36,8 @@ def test_phase_functions_called_with_real_eigen_types():
     (1e-9 of the line's largest magnitude: FMA contraction differs, nothing else may)."""
     exe = os.path.join(BUILD, "phase_driver")
     if not os.path.exists(exe):
-        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+        pytest.fail("tests/dropin/_build/%s is missing: the drop-in binaries are built by __graft_entry__.build() in the container that has "
+                    "/root/reference and travel to the GPU box with the snapshot -- a box without them must not pass the (b) row by skipping it" % os.path.basename(exe))
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     gold = open(os.path.join(ROOT, "tests", "golden", "stdout_phase_driver.txt")).read().splitlines()
@@ -61,7 +63,7 @@ def test_plain_c_example_of_the_batched_abi():
     closed-loop MPC steps; every instance ends at the origin."""
     exe = os.path.join(ROOT, "examples", "_build", "batched_double_integrator")
     if not os.path.exists(exe):
-        pytest.skip("examples/_build is produced by __graft_entry__.build()")
+        pytest.fail("examples/_build/batched_double_integrator is missing: __graft_entry__.build() produces it")
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, (p.stdout, p.stderr[-500:])
     assert "4096 instances x 60 MPC steps" in p.stdout and "kernel path 0" in p.stdout
@@ -75,7 +77,8 @@ def test_adaptive_rho_through_the_reference_structs():
     Taylor steps of a closed loop; the batched tests hold single solves to 1e-9)."""
     exe = os.path.join(BUILD, "adaptive_driver")
     if not os.path.exists(exe):
-        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+        pytest.fail("tests/dropin/_build/%s is missing: the drop-in binaries are built by __graft_entry__.build() in the container that has "
+                    "/root/reference and travel to the GPU box with the snapshot -- a box without them must not pass the (b) row by skipping it" % os.path.basename(exe))
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     gold = open(os.path.join(ROOT, "tests", "golden", "stdout_adaptive_driver.txt")).read().splitlines()
@@ -103,7 +106,8 @@ def test_reference_codegen_examples_generate_a_project_that_solves(tmp_path, ex,
     import re
     exe = os.path.join(BUILD, ex)
     if not os.path.exists(exe):
-        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+        pytest.fail("tests/dropin/_build/%s is missing: the drop-in binaries are built by __graft_entry__.build() in the container that has "
+                    "/root/reference and travel to the GPU box with the snapshot -- a box without them must not pass the (b) row by skipping it" % os.path.basename(exe))
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert p.returncode == 0 and p.stdout == "", p.stdout + p.stderr          # verbose = 0: the reference prints nothing either
     out = tmp_path / gen_dir
@@ -132,7 +136,8 @@ def test_rho_benchmark_helpers_called_through_their_cxx_names():
     import re
     exe = os.path.join(BUILD, "rho_driver")
     if not os.path.exists(exe):
-        pytest.skip("drop-in binaries are built in the container that has /root/reference")
+        pytest.fail("tests/dropin/_build/%s is missing: the drop-in binaries are built by __graft_entry__.build() in the container that has "
+                    "/root/reference and travel to the GPU box with the snapshot -- a box without them must not pass the (b) row by skipping it" % os.path.basename(exe))
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     gold = open(os.path.join(ROOT, "tests", "golden", "stdout_rho_driver.txt")).read().splitlines()

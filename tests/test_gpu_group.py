@@ -106,11 +106,14 @@ def test_c_examples_run(exe, args):
     import subprocess
     path = os.path.join(ROOT, "examples", "_build", exe)
     if not os.path.exists(path):
-        pytest.skip("examples/_build missing: run __graft_entry__.build()")
+        pytest.fail("examples/_build/%s is missing: __graft_entry__.build() produces it (the (e) row must not pass by skipping)" % exe)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([path] + args, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "solves converged" in p.stdout
+    # EVERY visible device takes part (one today; on an 8-GPU node the same test runs 8 ranks / 8 shards): the line names the count
+    gpus = tm.device_count()
+    assert p.stdout.startswith("%d %s" % (gpus, "GPU(s)" if exe == "multi_gpu_group" else "rank(s)")), p.stdout[:200]
     if exe == "multi_gpu_group":
         assert "RCCL" in p.stdout
 
