@@ -281,7 +281,7 @@ def parse_args(argv=None):
     ap.add_argument("--configs-budget", type=float, default=60.0, help="seconds after which no further config entry is started")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, weak scaling: skip the additional strong-scaling measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="seconds of reference solve time per host core (the cpu_baseline leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="seconds of reference solve time per host core (the cpu_baseline leg)")
     ap.add_argument("--configs-cpu-seconds", type=float, default=0.25,
                     help="seconds of reference solve time per checker process and `configs` entry (oracle/config_check.py); 0 = parity sample only")
     ap.add_argument("--configs-cpu-cores", type=int, default=64, help="checker processes of the `configs` leg (a bounded sample of the host's cores)")
@@ -768,8 +768,12 @@ def run(args, result_fd, setup_done):
 
     # CPU baseline LAST (rank 0, N = 1 only): the real reference on every host core, the SAME workload as the timed region
     cpu = None
+    cpu_phase_s = check_phase_s = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        t_cpu = time.perf_counter()
         cpu = cpu_baseline_subprocess(args.cpu_seconds, args.steps)
+        cpu_phase_s = time.perf_counter() - t_cpu
+        t_cpu = time.perf_counter()
         # ... and the checker of the `configs` entries: the oracle on a sample of each entry's own records (`parity_sample`), the
         # real reference timed on the same records (`cpu_baseline` of the entry) -- oracle/config_check.py, processes of its own
         if configs is not None and spec_path and os.path.exists(spec_path):
@@ -779,6 +783,7 @@ def run(args, result_fd, setup_done):
                     e.update(chk[name])
                 elif "error" in chk and "error" not in e and "skipped" not in e:
                     e["parity_sample"] = {"error": chk["error"]}
+            check_phase_s = time.perf_counter() - t_cpu
 
     solves = float(total) * args.steps
     value = solves / elapsed
@@ -829,7 +834,7 @@ def run(args, result_fd, setup_done):
             "roofline_fp64": roofline_fp64,
             "kernel_ms": {"first_launch_median": float(np.median(m["kern_first"])), "sum_per_repetition_median": kern_sum_rep,
                           "min": float(kern_ms.min()), "max": float(kern_ms.max()), "count": int(kern_ms.size)},
-            "gpu_phase_seconds": gpu_phase_s,
+            "gpu_phase_seconds": gpu_phase_s, "cpu_baseline_phase_seconds": cpu_phase_s, "configs_checker_phase_seconds": check_phase_s,
         }
         if job.share_gpu:
             out["data"] = "synthetic; SMOKE RUN: %d ranks share %d GPU(s) over gloo -- not a measurement" % (world, torch.cuda.device_count())

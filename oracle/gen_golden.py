@@ -74,7 +74,7 @@ def single_solve_suites(only=None):
         # the tile kernel's cone variant (VERDICT r04 nit): a wide shape with an input cone, a long one with both families on
         "sweep_20_4_10_isoc": sc.sweep_cone_suite(20, 4, 10, B=3, max_iter=250),
         "sweep_12_8_30_isoc": sc.sweep_cone_suite(12, 8, 30, B=3, max_iter=150),
-        "sweep_8_2_50_bothsoc": sc.sweep_cone_suite(8, 2, 50, B=2, max_iter=60, state_cone=True),
+        "sweep_8_4_50_bothsoc": sc.sweep_cone_suite(8, 4, 50, B=2, max_iter=60, state_cone=True),
         # adaptive rho (admm.cpp:397-423, rho_benchmark.cpp) with the reference's own sensitivity tables; the real reference
         # runs with the stack under solve() scrubbed (oracle/ref_shim.cpp: its RhoAdapter flag is uninitialised)
         "adaptive_hover": sc.hover_adaptive_suite(RefSolver),

@@ -392,7 +392,8 @@ def sweep_cone_suite(nx, nu, N, B=3, max_iter=120, state_cone=False, seed=31):
     random slack / dual state: the tile kernel's cone variant on wide / long shapes (tile_dims.txt)"""
     suite = sweep_suite(nx, nu, N, B=B, max_iter=max_iter)
     rng = np.random.default_rng(seed)
-    suite["config"].update(en_input_soc=1, input_cone=([0], [3], [0.6]) if nu >= 3 else ([0], [2], [0.6]))
+    assert nu >= 3 and nx >= 4, "the reference's project_soc only handles dimension 3 (admm.cpp:53)"
+    suite["config"].update(en_input_soc=1, input_cone=([0], [3], [0.6]))
     if state_cone:
         suite["config"].update(en_state_soc=1, state_cone=([1], [3], [0.8]))
     for k in ("vnew", "znew", "g", "y", "v", "z", "gc", "yc", "x", "u"):
