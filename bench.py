@@ -154,6 +154,8 @@ def _config_summary(e):
         c["mismatches"] = ps.get("iteration_count_mismatches", ps.get("error"))
     if e.get("first_call_ms") is not None:
         c["first_call_ms"] = _r(e["first_call_ms"])
+    if e.get("planned_first_call_ms") is not None:
+        c["planned_first_call_ms"] = _r(e["planned_first_call_ms"])
     return c
 
 

@@ -247,6 +247,26 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value);
 /* derived state: "auto_split_k" (the K the automatic split solve derived from the last iteration histogram; 0 = plain launch),
  * "auto_split_permille" (its predicted time, in 1/1000 of the plain launch's), "repack_after" */
 long tiny_batch_get_option(TinyBatch* b, const char* name);
+/* The settled launch form of a batch as plain data.  The library decides by the clock how a batch is launched (plain or split solve
+ * and its K / stage schedule, the tile kernel's dynamic form for a one-row shape, stretches of MPC steps for a fused launch); the first
+ * solves of a batch are probes.  tiny_batch_get_plan exports what they found, tiny_batch_set_plan imports it into another handle of
+ * the same (nx, nu, N) -- in this process or another one: the plan is a POD without pointers, write it to a file as it is -- which
+ * then takes the settled form on its FIRST solve.  A plan is advice about launch forms only: results are bit-identical whatever it
+ * says.  It applies to solves with the max_iter it was learnt for (auto_cap_max_iter).  open_questions > 0: the exporter had not
+ * finished probing (the importer carries on where it stopped). */
+#define TINY_PLAN_MAGIC   0x4e4c5054   /* "TPLN" */
+#define TINY_PLAN_VERSION 1
+typedef struct TinyBatchPlan {
+    int magic, version, bytes;
+    int nx, nu, N, batch, max_iter, check_termination;
+    int open_questions;
+    int auto_verdict, auto_cap, auto_cap_max_iter, auto_growth, growth_verdict, auto_probes;   /* split solve: 1 kept / -1 rejected, K, its max_iter, stage growth 2 | 4 */
+    int tile_verdict, regroup_verdict, hist_valid;                                             /* tile alternative / stretches of MPC steps: 1 on, -1 off, 0 open */
+    double auto_plain_rate, auto_split_rate, auto_gain, tile_rate, lockstep_ratio;             /* the clock readings behind the verdicts (ms per instance-iteration) */
+    unsigned hist[1024];                                                                       /* iteration histogram the schedule came from */
+} TinyBatchPlan;
+int tiny_batch_get_plan(TinyBatch* b, TinyBatchPlan* out);
+int tiny_batch_set_plan(TinyBatch* b, const TinyBatchPlan* in);
 /* the cost model behind "repack_after" = -1 by itself (host arithmetic, no GPU): hist[1024], hist[i] = instances whose solve takes
  * i iterations; returns the proposed K (0 = plain launch), *ratio = predicted time of the best split / of the plain launch */
 int tiny_predict_split(const unsigned* hist, int nx, int nu, int N, int max_iter, int check_termination, int num_cus, double* ratio);

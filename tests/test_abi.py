@@ -273,3 +273,16 @@ int main(void) {
                            "-L", libdir, "-ltinympc_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok 1328", (out.returncode, out.stdout, out.stderr)
+
+
+def test_plan_struct_is_a_pointer_free_pod_of_the_size_the_python_mirror_assumes(tmp_path):
+    """TinyBatchPlan (tiny_batch_get_plan / tiny_batch_set_plan) crosses processes as raw bytes: its size and the offsets the ctypes
+    mirror unpacks must be what a C99 compiler lays out"""
+    import tinympc_amd as tm
+    src = tmp_path / "plan.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tinympc_amd.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(TinyBatchPlan), '
+                   'offsetof(TinyBatchPlan, auto_verdict), offsetof(TinyBatchPlan, auto_plain_rate), offsetof(TinyBatchPlan, hist));return 0;}\n')
+    exe = tmp_path / "plan"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, off_verdict, off_rates, off_hist = map(int, subprocess.check_output([str(exe)]).split())
+    assert size == tm.PLAN_BYTES and off_verdict == 40 and off_rates == 80 and off_hist == 120 and size == off_hist + 4096

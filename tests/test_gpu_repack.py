@@ -259,3 +259,75 @@ def test_a_launch_after_reset_does_not_read_the_zero_state_and_nothing_changes(n
     assert np.array_equal(outs[0][0]["iter"], ref["iter"].astype(int))
     for k in ("x", "u", "vnew", "znew", "g", "y"):
         assert np.max(np.abs(outs[0][0][k] - ref[k])) <= 1e-9 * max(1.0, np.max(np.abs(ref[k]))), k
+
+
+def test_an_imported_plan_gives_the_settled_launch_form_on_the_first_solve():
+    """tiny_batch_get_plan / tiny_batch_set_plan.  A handle that has settled its launch form over its probe solves
+    (config 3's recipe at 262 144 instances: plain or split, K, stage schedule) exports the plan; a FRESH handle that imports it
+    launches that form on its very first solve -- same K, no probe, the settled kernel time -- and leaves bit-identical results.  A
+    forced verdict shows the plan is what decides: with the split imported as KEPT the first solve of a fresh handle is a split
+    solve, imported as REJECTED it is a plain launch; the results never change."""
+    base = sc.tracking_random_suite(B=2048, seed=321)
+    rep = 128
+    cases = {k: np.concatenate([v] * rep, axis=0) for k, v in base["cases"].items()}
+    suite = dict(base, cases=cases)
+
+    def cold_solve(s, timed=True):
+        s.reset()
+        s.set_x0(cases["x0"]); s.set_x_ref(cases["Xref"]); s.set_u_ref(cases["Uref"])
+        if timed:
+            s.set_option("timing", 1)
+        s.solve()
+        return float(np.sum(s.timing_ms())) if timed else None
+
+    def results(s):
+        st = s.status()
+        return dict(iter=st["iter"], solved=st["solved"], x=s.get("x"), u=s.get("u"), g=s.get("g"), v=s.get("v"))
+
+    a = make_batch(suite)
+    ms_a = [cold_solve(a) for _ in range(14)]
+    plan = a.get_plan()
+    f = tm.TinyBatchSolver.plan_fields(plan)
+    assert f["magic"] == 0x4e4c5054 and f["bytes"] == len(plan) == tm.PLAN_BYTES and (f["nx"], f["nu"], f["N"], f["batch"]) == (12, 4, 10, 2048 * rep)
+    assert f["open_questions"] == 0 and f["auto_verdict"] in (1, -1) and f["auto_cap"] == a.get_option("auto_split_k") and f["hist_valid"] == 1
+    assert f["auto_plain_rate"] > 0
+    ref = results(a)
+    settled = float(np.median(ms_a[8:]))
+    a.close()
+
+    b = make_batch(suite)
+    b.set_plan(plan)
+    first = cold_solve(b)
+    same(ref, results(b), "imported plan")
+    assert b.get_option("auto_split_k") == f["auto_cap"] and b.get_option("auto_split_verdict") == f["auto_verdict"]
+    assert b.get_plan()[:80] == plan[:80]                     # the first solve did not re-open a question
+    # the settled time on the first call (the unsettled first solves of handle a: plain launch / probes)
+    assert first <= 1.25 * settled, (first, settled, ms_a)
+    b.close()
+
+    # the plan decides the form: forced verdicts
+    import struct
+    names = "magic version bytes nx nu N batch max_iter check_termination open_questions auto_verdict".split()
+    off = 4 * names.index("auto_verdict")
+    times = {}
+    for verdict in (1, -1):
+        forced = bytearray(plan)
+        struct.pack_into("<i", forced, off, verdict)
+        if verdict == 1 and f["auto_cap"] == 0:
+            continue
+        c = make_batch(suite)
+        c.set_plan(bytes(forced))
+        times[verdict] = cold_solve(c)
+        same(ref, results(c), ("forced verdict", verdict))
+        assert c.get_option("auto_split_verdict") == verdict
+        c.close()
+
+    # a plan of another shape, a truncated or foreign buffer: refused
+    d = make_batch(sc.sweep_suite(4, 2, 10, B=8))
+    with pytest.raises(tm.TinyMPCError):
+        d.set_plan(plan)
+    with pytest.raises(tm.TinyMPCError):
+        d.set_plan(plan[:100])
+    with pytest.raises(tm.TinyMPCError):
+        d.set_plan(bytes(tm.PLAN_BYTES))
+    d.close()

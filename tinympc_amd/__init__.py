@@ -33,6 +33,7 @@ FIELDS = ("x0", "Xref", "Uref", "x", "u", "vnew", "znew", "g", "y", "v", "z", "v
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 STATE_FIELDS = {"Xref", "x", "vnew", "g", "v", "vcnew", "gc", "q", "p", "vlnew", "gl", "vlnew_tv", "gl_tv"}
 
+PLAN_BYTES = 19 * 4 + 4 + 5 * 8 + 1024 * 4      # sizeof(TinyBatchPlan): 19 ints, padding, 5 doubles, the histogram
 # every extern "C" symbol include/tinympc_amd.h declares (checked by tests/test_abi_symbols.py)
 BATCH_SYMBOLS = (
     "tiny_batch_device_count", "tiny_batch_setup", "tiny_batch_setup_hetero", "tiny_batch_get_cache_instance",
@@ -44,7 +45,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
     "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
     "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy", "tiny_rccl_comm_count", "tiny_rccl_available", "tiny_reduce_stats_messages",
-    "tiny_batch_get_option", "tiny_predict_split", "tiny_step_regroup_plan", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
+    "tiny_batch_get_option", "tiny_predict_split", "tiny_step_regroup_plan", "tiny_batch_get_plan", "tiny_batch_set_plan", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
     "tiny_group_setup", "tiny_group_destroy", "tiny_group_shards", "tiny_group_shard", "tiny_group_shard_indices",
     "tiny_group_uses_rccl", "tiny_group_last_error", "tiny_group_set_bound_constraints", "tiny_group_set_cone_constraints",
@@ -147,6 +148,8 @@ def lib():
         L.tiny_batch_set_cache.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.tiny_predict_split.argtypes = [C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
         L.tiny_step_regroup_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int]
+        L.tiny_batch_get_plan.argtypes = [C.c_void_p, C.c_void_p]
+        L.tiny_batch_set_plan.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_get_option.argtypes = [C.c_void_p, C.c_char_p]
         L.tiny_batch_get_option.restype = C.c_long
         L.tiny_batch_set_adaptive_rho.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
@@ -479,6 +482,31 @@ class TinyBatchSolver:
 
     def get_option(self, name) -> int:
         return int(lib().tiny_batch_get_option(self._h, name.encode()))
+
+    def get_plan(self) -> bytes:
+        """the settled launch form of this batch (TinyBatchPlan, include/tinympc_amd.h) as bytes: write them to a file, hand them
+        to set_plan of another handle of the same (nx, nu, N) -- it takes the settled form on its first solve"""
+        buf = C.create_string_buffer(PLAN_BYTES)
+        self._check(lib().tiny_batch_get_plan(self._h, buf), "get_plan")
+        return buf.raw
+
+    def set_plan(self, plan: bytes):
+        if len(plan) != PLAN_BYTES:
+            raise TinyMPCError("set_plan: %d bytes, a TinyBatchPlan has %d" % (len(plan), PLAN_BYTES))
+        self._check(lib().tiny_batch_set_plan(self._h, C.create_string_buffer(bytes(plan), PLAN_BYTES)), "set_plan")
+
+    @staticmethod
+    def plan_fields(plan: bytes) -> dict:
+        """the scalar fields of a TinyBatchPlan (diagnostics, tests)"""
+        import struct
+        names = ("magic version bytes nx nu N batch max_iter check_termination open_questions auto_verdict auto_cap auto_cap_max_iter "
+                 "auto_growth growth_verdict auto_probes tile_verdict regroup_verdict hist_valid").split()
+        ints = struct.unpack_from("<%di" % len(names), plan, 0)
+        off = (4 * len(names) + 7) // 8 * 8
+        dbl = struct.unpack_from("<5d", plan, off)
+        d = dict(zip(names, ints))
+        d.update(zip(("auto_plain_rate", "auto_split_rate", "auto_gain", "tile_rate", "lockstep_ratio"), dbl))
+        return d
 
     def stats_message_async(self, device_out):
         """the batch's 64-byte statistics message (8 doubles) -> device memory, on the batch's stream behind the solve"""

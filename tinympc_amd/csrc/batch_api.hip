@@ -1186,45 +1186,39 @@ static int ensure_repack_buffers(TinyBatch* b) {
     return TINY_OK;
 }
 
-int launch_solve(TinyBatch* b) {
-    // records_zero: tiny_batch_reset (or tiny_batch_setup) zeroed every warm-start record and nothing has written one since.  The
-    // one-row kernel then takes its state as zero WITHOUT reading it (SolveArgs::cold) -- bit-identical, 3 of the 4 record reads of a
-    // solve saved (the first solve after a reset: BASELINE configs 3 and 5, every cold start).  Any launch ends that knowledge.
-    const bool zero_state = b->records_zero;
-    b->records_zero = false;
-    if (b->tab_dirty) {                              // something the tables are built from has changed since the last launch
-        b->tab_gen++;
-        if (!b->redispatch) b->tile_soc_failed = false;   // (a failed variant instantiation is retried when the CALLER changed something)
-    }
-    b->redispatch = false;
-    if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
-        return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
-    if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
-        return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous problem data needs the register-resident kernel (nx+nu <= 16, at most 4 half-spaces per knot and family)");
-    if (b->adaptive && !has_regs(b))
-        return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho needs the register-resident kernel (nx+nu <= 16, horizon within the register file)");
-    const int path = use_tile(b) ? 1 : (use_general(b) ? 2 : 0);
-    if (path != b->last_path) { b->tab_dirty = true; b->last_path = path; }   // each path has its own table layout
-    if (path == 1) {
-        const int rc = launch_tile(b);
-        if (rc == TINY_OK) b->tab_dirty = false;
-        return rc;
-    }
-    if (use_general(b)) {
-        const int rc = launch_general(b);
-        if (rc == TINY_OK) b->tab_dirty = false;
-        return rc;
-    }
+// ---- launch_solve in three parts -----------------------------------------------------------------------------
+//   DECIDE   which launch form this solve takes: from the options and from the PLAN, i.e. what earlier solves of the batch left behind
+//            (plain or split and its K / stage schedule, the tile kernel's dynamic form for a one-row shape, stretches of MPC steps);
+//            the plan can be exported and imported (tiny_batch_get_plan / tiny_batch_set_plan) so that a process need not re-probe
+//   ENQUEUE  the launches of that form (enqueue_split_solve / enqueue_plain_or_stretches / launch_tile / launch_general)
+//   LEARN    while a question is open the solve is timed and leaves its iteration histogram behind (learn_from_probe reads them
+//            when the NEXT solve of the batch is decided; a solve never waits)
+enum { MAX_STAGES = 32 };
+struct OneRowLaunch {                                // one launch_solve call on the one-row kernel
+    SolveArgs a;
+    SolveKernel k = nullptr;                         // the compiled-in instantiation, or
+    hipFunction_t jit_fn = nullptr;                  // ... the one hipRTC made
+    JitKey jk;
+    int steps = 1, ipw = 4, grid = 0;
+    bool soc = false;
+    // the decision
+    bool split_ok = false, auto_split = false, growth_probe = false, auto_probe = false;
+    int cap = 0;                                     // > 0: split solve with first stage K = cap
+};
+
+// arguments, variant and kernel of the launch (the tables are uploaded here).  `done`: the launch was handed to another path (a
+// variant that could not be instantiated: coverage kernel) and the value returned is that launch's
+static int build_one_row_launch(TinyBatch* b, const bool zero_state, OneRowLaunch& L, bool& done) {
     b->h_gtab.clear();
     if (int rc = upload_tables(b)) return rc;
-    const bool soc = soc_active(b);
-    SolveArgs a;
+    const bool soc = L.soc = soc_active(b);
+    SolveArgs& a = L.a;
     a.arho = a.aK = a.aP = a.aC1 = a.aC2 = nullptr; a.atab = nullptr; a.arho_min = a.arho_max = 0.0; a.aclip = 0; a.ref_shared = 0; a.work_counter = nullptr; a.reverse = 0;
     a.index = nullptr; a.count = nullptr; a.iter_base = 0; a.next_index = nullptr; a.next_count = nullptr; a.perm = nullptr; a.perm_count = 0;
     a.tab = b->d_tab; a.x0 = b->d_x0; a.ref = b->d_ref; a.prim = b->d_prim; a.slack = b->d_slack;
     a.dual = b->d_dual; a.slack_prev = b->d_slack_prev; a.cslack = b->d_cslack; a.cdual = b->d_cdual;
     a.status = b->d_status; a.resid = b->d_resid;
-    const int steps = b->steps_per_launch > 1 ? b->steps_per_launch : 1;
+    const int steps = L.steps = b->steps_per_launch > 1 ? b->steps_per_launch : 1;
     a.steps = steps;
     a.x0_next = (b->advance_x0 || steps > 1) ? b->d_x0 : nullptr;     // fused steps imply the plant step
     a.iter_log = nullptr; a.u0_log = nullptr;
@@ -1247,7 +1241,8 @@ int launch_solve(TinyBatch* b) {
     a.rho = b->cache.rho; a.tol_pri = b->set.abs_pri_tol; a.tol_dua = b->set.abs_dua_tol;
     a.batch = b->batch; a.max_iter = b->set.max_iter; a.check_termination = b->set.check_termination;
     const int tiles = (b->batch + 3) / 4;
-    int grid = tiles;
+    int& grid = L.grid;
+    grid = tiles;
     if (b->grid_waves_per_cu > 0) {
         const long cap = (long)b->num_cus * b->grid_waves_per_cu;
         if (cap < grid) grid = (int)cap;
@@ -1256,7 +1251,8 @@ int launch_solve(TinyBatch* b) {
     // (every soc x debug x mode; LIN and HET without debug at mode 2); anything else -- an unseen shape, or debug outputs
     // together with half-spaces / per-instance data, or both of those -- is instantiated now (jit.hpp).
     const int mode = (b->dpp_mode >= 0 && b->dpp_mode <= 2) ? b->dpp_mode : 0;
-    JitKey jk = {b->nx, b->nu, b->N, soc ? 1 : 0, b->debug ? 1 : 0, mode, 0, b->hetero ? 1 : 0, LIN_KMAX, 0};
+    JitKey& jk = L.jk;
+    jk = JitKey{b->nx, b->nu, b->N, soc ? 1 : 0, b->debug ? 1 : 0, mode, 0, b->hetero ? 1 : 0, LIN_KMAX, 0};
     a.lslack = a.ldual = a.tlslack = a.tldual = nullptr;
     a.n_lin = a.n_tlin = 0;
     if (const int lv = lin_variant(b)) {
@@ -1279,7 +1275,8 @@ int launch_solve(TinyBatch* b) {
         jk.adapt = 1;
     }
     if (jk.lin || jk.het || jk.adapt) jk.mode = 2;   // those variants exist on the single-chain FMA blocks only
-    SolveKernel k = nullptr;
+    SolveKernel& k = L.k;
+    k = nullptr;
     if (b->kernel) {
         if (jk.adapt) k = jk.soc ? nullptr : b->kernel->kadapt[jk.dbg];
         else if (!jk.lin && !jk.het && !jk.dbg && jk.mode == 2 && b->bounds_uniform && b->use_ub) k = jk.soc ? b->kernel->kubsoc : b->kernel->kub;
@@ -1289,7 +1286,8 @@ int launch_solve(TinyBatch* b) {
     }
     // HALF rows (nx+nu <= 8): the plain box launch of a compiled-in shape takes the form that puts two instances into a DPP row --
     // eight per wave (option "half_rows": -1 / 1 on where the form exists, 0 off).  Bit-identical to the one-row form.
-    int ipw = 4;
+    int& ipw = L.ipw;
+    ipw = 4;
     if (k && b->kernel && b->half_rows != 0 && (k == b->kernel->kub || k == b->kernel->k[0][0][2])) {
         SolveKernel kh = b->kernel->khalf[k == b->kernel->kub ? 1 : 0];
         if (kh) { k = kh; ipw = 8; }
@@ -1299,7 +1297,8 @@ int launch_solve(TinyBatch* b) {
         grid = (b->batch + 7) / 8;
         if (b->grid_waves_per_cu > 0) grid = (int)std::min<long>(grid, (long)b->num_cus * b->grid_waves_per_cu);
     }
-    hipFunction_t jit_fn = nullptr;
+    hipFunction_t& jit_fn = L.jit_fn;
+    jit_fn = nullptr;
     if (!k) {
         std::string why;
         if (b->no_jit) why = "run-time instantiation is switched off (no_jit)";
@@ -1313,7 +1312,7 @@ int launch_solve(TinyBatch* b) {
                 if (general_can && !b->variant_jit_failed) {
                     b->variant_jit_failed = true;
                     b->tab_dirty = true; b->redispatch = true;
-                    return launch_solve(b);
+                    { done = true; return launch_solve(b); }
                 }
                 return fail(b, TINY_ERR_UNSUPPORTED, "this combination of cone / debug outputs / half-spaces / per-instance data / launch form needs hipRTC: %s", why.c_str());
             }
@@ -1322,19 +1321,15 @@ int launch_solve(TinyBatch* b) {
             b->tab_dirty = true; b->redispatch = true;
             if (b->hetero || b->steps_per_launch > 1 || b->d_traj || b->reset_duals || b->one_shot)
                 return fail(b, TINY_ERR_UNSUPPORTED, "no register-resident kernel for (nx,nu,N)=(%d,%d,%d): %s", b->nx, b->nu, b->N, why.c_str());
-            return launch_solve(b);
+            { done = true; return launch_solve(b); }
         }
     }
-    // "repack_after" = -1 (the default): K comes from the iteration histogram of the previous eligible solve of this batch
-    // (collected asynchronously; a solve never waits for it) through the cost model above -- a batch whose iteration
-    // counts are uniform gets K = 0, i.e. the plain launch.
-    enum { MAX_STAGES = 32 };
-    const bool split_ok = steps == 1 && !a.x0_next && !b->one_shot && !b->adaptive && a.check_termination > 0 && a.max_iter >= 16;
-    const bool auto_split = b->repack_after < 0 && split_ok && b->batch >= 8192;
-    if (auto_split) {                                // (not inside a timed probe: the first split solve's clock reading must not pay for a hipMalloc)
-        if (int rc = ensure_repack_buffers(b)) return rc;
-        if (b->repack_sort != 0) { if (int rc = ensure_regroup_buffers(b, false)) return rc; }
-    }
+    return TINY_OK;
+}
+
+// LEARN: the clock's word on the previous eligible solve of this batch (its events and its iteration histogram have arrived)
+static void learn_from_probe(TinyBatch* b, const int max_iter, const bool auto_split) {
+    struct { int max_iter; } a = {max_iter};
     if (auto_split && b->hist_pending && hipEventQuery(b->hist_ev) == hipSuccess) {
         b->hist_pending = false;
         // the clock's word on the previous eligible solve: microseconds per instance-iteration, plain or split
@@ -1366,6 +1361,12 @@ int launch_solve(TinyBatch* b) {
             b->hist_copy.assign(b->h_hist, b->h_hist + TinyBatch::HIST_BINS);
         }
     }
+}
+
+// DECIDE + ENQUEUE, the tile kernel's dynamic form for a one-row shape.  `done`: this solve ran there
+static int try_tile_alternative(TinyBatch* b, const OneRowLaunch& L, bool& done) {
+    const bool auto_split = L.auto_split, soc = L.soc;
+    const JitKey& jk = L.jk;
     // The same batch on the tile kernel's dynamic slot form (its one-row layout, tile_dims.txt): persistent waves whose rows take
     // the next instance off a device-wide counter the moment they are free.  It wins where solves are long and their iteration
     // counts spread (3-32 % on 14 of the 16 N = 10 / 30 config-5 cells) and loses where they are short (config 3: 2.4x), so the
@@ -1399,46 +1400,34 @@ int launch_solve(TinyBatch* b) {
                     if (int rc2 = enqueue_iteration_histogram(b)) return rc2;
                     b->probe_was_tile = true;
                 }
+                done = true;
                 return TINY_OK;
             }
         }
     }
-    b->last_tile_dyn = false;                        // (this launch runs on the one-row kernel)
-    const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
-    if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
-    if (auto_split && b->auto_verdict != 0 && ++b->auto_since >= 32) {      // distributions drift: ask the clock again now and then
-        b->auto_since = 0; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = 0.0; b->tile_verdict = 0;
+    return TINY_OK;
+}
+
+static int enqueue_kernel(TinyBatch* b, const OneRowLaunch& L, const SolveArgs& a, const int g, hipStream_t st) {
+    if (!st) st = b->stream;
+    if (L.jit_fn) {
+        SolveArgs copy = a;
+        void* params[] = {&copy};
+        HIP_TRY(b, hipModuleLaunchKernel(L.jit_fn, (unsigned)g, 1, 1, 64, 1, 1, 0, st, params, nullptr));
+    } else {
+        hipLaunchKernelGGL(L.k, dim3(g), dim3(64), 0, st, a);
+        HIP_TRY(b, hipGetLastError());
     }
-    // this solve is timed and leaves its iteration histogram behind -- while the question is open; a decided batch launches
-    // without the two event records (each costs the next launch a dispatch bubble) and without the histogram pass
-    // a kept split asks ONE more question: the other stage schedule, timed like the split itself was
-    const bool growth_probe = auto_split && !b->hist_pending && b->auto_verdict == 1 && b->growth_verdict == 0 && b->repack_growth < 2 &&
-                              b->auto_cap > 0 && b->auto_cap_max_iter == a.max_iter && b->auto_split_rate > 0.0;
-    const bool auto_probe = (auto_split && !b->hist_pending && b->auto_verdict == 0) || growth_probe;
-    if (auto_probe) {
-        if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
-        HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
-    }
-    auto launch = [&](const int g, hipStream_t st = nullptr) -> int {
-        if (!st) st = b->stream;
-        if (jit_fn) {
-            void* params[] = {&a};
-            HIP_TRY(b, hipModuleLaunchKernel(jit_fn, (unsigned)g, 1, 1, 64, 1, 1, 0, st, params, nullptr));
-        } else {
-            hipLaunchKernelGGL(k, dim3(g), dim3(64), 0, st, a);
-            HIP_TRY(b, hipGetLastError());
-        }
-        return TINY_OK;
-    };
-    // split solve (repack_after = K): the launch stops at iteration K and lists the instances it leaves open (the kernel's
-    // epilogue appends them, one atomic per wave that has any); a launch over that list carries on to 2K, the next one to 4K,
-    // ... max_iter (repack_growth = 2; 4: K, 4K, 16K, ...; 0 = what the cost model picked) -- four open instances per wave at every stage, and within a stage nearly all of them run the same number
-    // of iterations.  K is a multiple of check_termination so that the termination countdown of every stage is in phase.
-    // Two index lists alternate; every stage has its own counter, all of them zeroed by one memset.
-    int cap = b->repack_after > 0 ? b->repack_after
-            : ((auto_split && b->auto_cap_max_iter == a.max_iter && b->auto_verdict >= 0 && b->auto_plain_rate > 0.0) ? b->auto_cap : 0);
-    if (a.check_termination > 1) cap -= cap % a.check_termination;
-    if (cap > 0 && cap < a.max_iter && split_ok) {
+    return TINY_OK;
+}
+
+// ENQUEUE, split solve: stage 1 to iteration K = L.cap, follow-up stages over the lists of open instances
+static int enqueue_split_solve(TinyBatch* b, OneRowLaunch& L) {
+    SolveArgs& a = L.a;
+    const int cap = L.cap, grid = L.grid;
+    const bool growth_probe = L.growth_probe, soc = L.soc;
+    auto launch = [&](const int g, hipStream_t st = nullptr) -> int { return enqueue_kernel(b, L, a, g, st); };
+    {
         if (int rc = ensure_repack_buffers(b)) return rc;
         if (b->repack_sort != 0) { if (int rc = ensure_regroup_buffers(b, false)) return rc; }
         b->last_sorted_stages = 0;
@@ -1483,7 +1472,18 @@ int launch_solve(TinyBatch* b) {
             if (int rc = launch(std::min(grid, b->num_cus * b->repack_waves_per_cu))) return rc;
             if (last) break;
         }
-    } else {
+    }
+    return TINY_OK;
+}
+
+// ENQUEUE, one launch -- or, for a fused closed-loop launch whose rows disagree, stretches of K MPC steps (step_regroup)
+static int enqueue_plain_or_stretches(TinyBatch* b, OneRowLaunch& L) {
+    SolveArgs& a = L.a;
+    const int steps = L.steps, ipw = L.ipw, grid = L.grid;
+    const bool soc = L.soc;
+    const JitKey& jk = L.jk;
+    auto launch = [&](const int g, hipStream_t st = nullptr) -> int { return enqueue_kernel(b, L, a, g, st); };
+    {
         // option "launch_order" = 1: successive plain launches walk the batch in alternating directions (SolveArgs::reverse)
         a.reverse = (b->launch_order == 2 || (b->launch_order == 1 && b->order_flip)) ? 1 : 0;
         b->order_flip = !b->order_flip;
@@ -1558,6 +1558,89 @@ int launch_solve(TinyBatch* b) {
         }
         if (regroup_auto && b->regroup_verdict == 0 && !b->ls_pending) { if (int rc = enqueue_lockstep_estimate(b)) return rc; }
     }
+    return TINY_OK;
+}
+
+int launch_solve(TinyBatch* b) {
+    // records_zero: tiny_batch_reset (or tiny_batch_setup) zeroed every warm-start record and nothing has written one since.  The
+    // one-row kernel then takes its state as zero WITHOUT reading it (SolveArgs::cold) -- bit-identical, 3 of the 4 record reads of a
+    // solve saved (the first solve after a reset: BASELINE configs 3 and 5, every cold start).  Any launch ends that knowledge.
+    const bool zero_state = b->records_zero;
+    b->records_zero = false;
+    if (b->tab_dirty) {                              // something the tables are built from has changed since the last launch
+        b->tab_gen++;
+        if (!b->redispatch) b->tile_soc_failed = false;   // (a failed variant instantiation is retried when the CALLER changed something)
+    }
+    b->redispatch = false;
+    if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
+        return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
+    if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
+        return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous problem data needs the register-resident kernel (nx+nu <= 16, at most 4 half-spaces per knot and family)");
+    if (b->adaptive && !has_regs(b))
+        return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho needs the register-resident kernel (nx+nu <= 16, horizon within the register file)");
+    const int path = use_tile(b) ? 1 : (use_general(b) ? 2 : 0);
+    if (path != b->last_path) { b->tab_dirty = true; b->last_path = path; }   // each path has its own table layout
+    if (path == 1) {
+        const int rc = launch_tile(b);
+        if (rc == TINY_OK) b->tab_dirty = false;
+        return rc;
+    }
+    if (use_general(b)) {
+        const int rc = launch_general(b);
+        if (rc == TINY_OK) b->tab_dirty = false;
+        return rc;
+    }
+    OneRowLaunch L;
+    bool done = false;
+    {
+        const int rc = build_one_row_launch(b, zero_state, L, done);
+        if (rc != TINY_OK || done) return rc;
+    }
+    SolveArgs& a = L.a;
+    const int steps = L.steps;
+    // ---- DECIDE
+    // "repack_after" = -1 (the default): K comes from the iteration histogram of the previous eligible solve of this batch
+    // (collected asynchronously; a solve never waits for it) through the cost model above -- a batch whose iteration
+    // counts are uniform gets K = 0, i.e. the plain launch.
+    const bool split_ok = L.split_ok = steps == 1 && !a.x0_next && !b->one_shot && !b->adaptive && a.check_termination > 0 && a.max_iter >= 16;
+    const bool auto_split = L.auto_split = b->repack_after < 0 && split_ok && b->batch >= 8192;
+    if (auto_split) {                                // (not inside a timed probe: the first split solve's clock reading must not pay for a hipMalloc)
+        if (int rc = ensure_repack_buffers(b)) return rc;
+        if (b->repack_sort != 0) { if (int rc = ensure_regroup_buffers(b, false)) return rc; }
+    }
+    learn_from_probe(b, a.max_iter, auto_split);
+    {
+        const int rc = try_tile_alternative(b, L, done);
+        if (rc != TINY_OK || done) return rc;
+    }
+    b->last_tile_dyn = false;                        // (this launch runs on the one-row kernel)
+    const bool timed = b->timing_left > 0 && b->timing_n < (int)b->ev_start.size();
+    if (timed) HIP_TRY(b, hipEventRecord(b->ev_start[b->timing_n], b->stream));
+    if (auto_split && b->auto_verdict != 0 && ++b->auto_since >= 32) {      // distributions drift: ask the clock again now and then
+        b->auto_since = 0; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = 0.0; b->tile_verdict = 0;
+    }
+    // this solve is timed and leaves its iteration histogram behind -- while the question is open; a decided batch launches
+    // without the two event records (each costs the next launch a dispatch bubble) and without the histogram pass
+    // a kept split asks ONE more question: the other stage schedule, timed like the split itself was
+    const bool growth_probe = L.growth_probe = auto_split && !b->hist_pending && b->auto_verdict == 1 && b->growth_verdict == 0 && b->repack_growth < 2 &&
+                              b->auto_cap > 0 && b->auto_cap_max_iter == a.max_iter && b->auto_split_rate > 0.0;
+    const bool auto_probe = L.auto_probe = (auto_split && !b->hist_pending && b->auto_verdict == 0) || growth_probe;
+    if (auto_probe) {
+        if (!b->auto_ev0) { HIP_TRY(b, hipEventCreate(&b->auto_ev0)); HIP_TRY(b, hipEventCreate(&b->auto_ev1)); }
+        HIP_TRY(b, hipEventRecord(b->auto_ev0, b->stream));
+    }
+    // split solve (repack_after = K): the launch stops at iteration K and lists the instances it leaves open (the kernel's
+    // epilogue appends them, one atomic per wave that has any); a launch over that list carries on to 2K, the next one to 4K,
+    // ... max_iter (repack_growth = 2; 4: K, 4K, 16K, ...; 0 = what the cost model picked) -- four open instances per wave at every stage, and within a stage nearly all of them run the same number
+    // of iterations.  K is a multiple of check_termination so that the termination countdown of every stage is in phase.
+    // Two index lists alternate; every stage has its own counter, all of them zeroed by one memset.
+    int& cap = L.cap;
+    cap = b->repack_after > 0 ? b->repack_after
+            : ((auto_split && b->auto_cap_max_iter == a.max_iter && b->auto_verdict >= 0 && b->auto_plain_rate > 0.0) ? b->auto_cap : 0);
+    if (a.check_termination > 1) cap -= cap % a.check_termination;
+    // ---- ENQUEUE
+    if (int rc = (cap > 0 && cap < a.max_iter && split_ok) ? enqueue_split_solve(b, L) : enqueue_plain_or_stretches(b, L)) return rc;
+    // ---- LEARN: what this solve leaves behind for the next decision
     b->status_valid = true;
     if (timed) {
         HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream));
@@ -2348,6 +2431,63 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
         return name[0] == 's' ? (long)b->regroup_verdict : (long)(b->lockstep_ratio * 1000.0 + 0.5);
     }
     return fail(b, TINY_ERR_ARG, "unknown option %s", name);
+}
+
+// ---- the settled launch form of a batch as plain data -----------------------------------------------------------
+// What the clock-checked dispatch has learnt about a batch -- plain or split solve and its K / stage schedule, the histogram the
+// schedule came from (repack_sort's stage predictions), the tile kernel's dynamic form for a one-row shape, stretches of MPC steps
+// for a fused launch -- leaves the process as one POD and enters another one: the importing handle takes the settled form on its
+// FIRST solve instead of spending six solves on probes, and two boxes given the same plan launch the same way.
+int tiny_batch_get_plan(TinyBatch* b, TinyBatchPlan* out) {
+    if (!b || !out) return TINY_ERR_NULL;
+    HIP_TRY(b, hipSetDevice(b->device));
+    // (a diagnostic may wait for what the last solve left behind; a solve never does)
+    if (b->hist_pending && hipEventSynchronize(b->hist_ev) == hipSuccess) learn_from_probe(b, b->set.max_iter, true);
+    if (b->ls_pending && hipEventSynchronize(b->ls_ev) == hipSuccess) read_lockstep_estimate(b);
+    memset(out, 0, sizeof(*out));
+    out->magic = TINY_PLAN_MAGIC; out->version = TINY_PLAN_VERSION; out->bytes = (int)sizeof(TinyBatchPlan);
+    out->nx = b->nx; out->nu = b->nu; out->N = b->N; out->batch = b->batch;
+    out->max_iter = b->set.max_iter; out->check_termination = b->set.check_termination;
+    out->auto_verdict = b->auto_verdict; out->auto_cap = b->auto_cap; out->auto_cap_max_iter = b->auto_cap_max_iter;
+    out->auto_growth = b->auto_growth; out->growth_verdict = b->growth_verdict; out->auto_probes = b->auto_probes;
+    out->auto_plain_rate = b->auto_plain_rate; out->auto_split_rate = b->auto_split_rate; out->auto_gain = b->auto_gain;
+    out->tile_verdict = b->tile_verdict; out->tile_rate = b->tile_rate;
+    out->regroup_verdict = b->regroup_verdict; out->lockstep_ratio = b->lockstep_ratio;
+    out->hist_valid = b->hist_copy.size() == (size_t)TinyBatch::HIST_BINS ? 1 : 0;
+    if (out->hist_valid) memcpy(out->hist, b->hist_copy.data(), sizeof(out->hist));
+    // open questions: plain-or-split undecided (while a split is on the table), the other stage schedule of a kept split untried
+    out->open_questions = ((b->auto_verdict == 0 && !(b->auto_plain_rate > 0.0 && b->auto_cap == 0)) ? 1 : 0) +
+                          ((b->auto_verdict == 1 && b->growth_verdict == 0 && b->repack_growth < 2) ? 1 : 0);
+    return TINY_OK;
+}
+
+int tiny_batch_set_plan(TinyBatch* b, const TinyBatchPlan* in) {
+    if (!b || !in) return TINY_ERR_NULL;
+    if (in->magic != TINY_PLAN_MAGIC || in->version != TINY_PLAN_VERSION || in->bytes != (int)sizeof(TinyBatchPlan))
+        return fail(b, TINY_ERR_ARG, "not a TinyBatchPlan of this library version");
+    if (in->nx != b->nx || in->nu != b->nu || in->N != b->N)
+        return fail(b, TINY_ERR_DIM, "the plan was made for (nx,nu,N)=(%d,%d,%d), this batch is (%d,%d,%d)", in->nx, in->nu, in->N, b->nx, b->nu, b->N);
+    if (in->auto_verdict < -1 || in->auto_verdict > 1 || in->tile_verdict < -1 || in->tile_verdict > 1 || in->regroup_verdict < -1 || in->regroup_verdict > 1 ||
+        in->auto_cap < 0 || in->auto_cap >= TinyBatch::HIST_BINS || (in->auto_growth != 2 && in->auto_growth != 4) || !(in->auto_plain_rate >= 0.0) || !(in->auto_split_rate >= 0.0))
+        return fail(b, TINY_ERR_ARG, "TinyBatchPlan: field out of range");
+    HIP_TRY(b, hipSetDevice(b->device));
+    // (a plan is advice about launch forms, never about results: every form is bit-identical.  It applies to solves with the
+    // max_iter it was made for -- auto_cap_max_iter -- exactly as a plan learnt in this process would)
+    b->auto_verdict = in->auto_verdict; b->auto_cap = in->auto_cap; b->auto_cap_max_iter = in->auto_cap_max_iter;
+    b->auto_growth = in->auto_growth; b->growth_verdict = in->growth_verdict; b->auto_probes = std::max(2, in->auto_probes);
+    b->auto_plain_rate = in->auto_plain_rate; b->auto_split_rate = in->auto_split_rate; b->auto_gain = in->auto_gain;
+    b->tile_verdict = in->tile_verdict; b->tile_rate = in->tile_rate;
+    b->regroup_verdict = in->regroup_verdict; b->lockstep_ratio = in->lockstep_ratio;
+    if (in->hist_valid) b->hist_copy.assign(in->hist, in->hist + TinyBatch::HIST_BINS); else b->hist_copy.clear();
+    b->auto_since = b->tile_since = b->regroup_since = 0;
+    b->hist_pending = false; b->ls_pending = false; b->probe_was_tile = false; b->probe_was_growth = false; b->auto_last_cap = 0;
+    // what the first launch of an imported form would otherwise allocate inside its solve call
+    if (b->auto_verdict == 1 && b->auto_cap > 0) {
+        if (int rc = ensure_repack_buffers(b)) return rc;
+        if (b->repack_sort != 0) { if (int rc = ensure_regroup_buffers(b, false)) return rc; }
+    }
+    if (b->regroup_verdict == 1) { if (int rc = ensure_regroup_buffers(b, true)) return rc; }
+    return TINY_OK;
 }
 
 int tiny_batch_kernel_path(TinyBatch* b) {

@@ -112,6 +112,29 @@ def config3(B=262144, device=0):
                plain_launch_ms=float(np.median(plain)), plain_launch_ms_min=float(np.min(plain)),
                automatic_split_k=s.get_option("auto_split_k"), automatic_split_growth=s.get_option("auto_split_growth"),
                automatic_split_verdict=s.get_option("auto_split_verdict"), solved_fraction=st[1] / B)
+    # what a caller's FIRST solves of a batch cost (probes: plain / split / other stage schedule / tile alternative), and what the
+    # first solve of a fresh handle costs when it imports the settled plan (tiny_batch_get_plan / tiny_batch_set_plan)
+    e["unsettled_ms"] = [float(v) for v in auto[:6]]
+    e["first_call_ms"] = float(auto[0])
+    try:
+        plan = s.get_plan()
+        s2 = tm.TinyBatchSolver.from_problem(prob, B, device=device)
+        s2.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+        s2.update_settings(max_iter=100)
+        s2.set_x_ref(Xref)
+        s2.set_u_ref(Uref)
+        s2.set_x0(x0)
+        s2.set_plan(plan)
+        planned = _cold_solves(s2, 3)
+        st3 = s2.reduce_stats()
+        assert st3[0] == st[0] and st3[1] == st[1], "a solve under an imported plan must reproduce the plain one"
+        e["planned_first_call_ms"] = float(planned[0])
+        e["planned_ms"] = [float(v) for v in planned]
+        e["plan"] = {k: v for k, v in tm.TinyBatchSolver.plan_fields(plan).items() if k in ("open_questions", "auto_verdict", "auto_cap", "auto_growth", "tile_verdict")}
+        s2.close()
+    except Exception as ex:                            # noqa: BLE001
+        e["planned_first_call_ms"] = None
+        e["plan_error"] = repr(ex)
     idx = _sample_idx(B)
     stt = s.status()
     it = np.where(stt["solved"][idx] != 0, stt["iter"][idx], -stt["iter"][idx])
