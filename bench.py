@@ -168,7 +168,7 @@ def compact_line(out, details_path=None):
                                     "vs_baseline", "dtype", "data")}
     line["value"], line["ms_per_step"] = _r(out.get("value"), 7), _r(out.get("ms_per_step"), 6)
     cfg = out.get("config") or {}
-    line["config"] = {k: cfg.get(k) for k in ("workload", "batch_per_gpu", "total_batch", "parallelism", "mpc_steps_per_launch", "stats_exchange")
+    line["config"] = {k: cfg.get(k) for k in ("workload", "batch_per_gpu", "total_batch", "parallelism", "mpc_steps_per_launch", "stats_exchange", "launcher")
                       if k in cfg}
     if "error" in out:
         line["error"] = str(out["error"])[:600]
@@ -231,7 +231,8 @@ def compact_line(out, details_path=None):
         optional[:0] = ["configs"]
     if "strong_scaling" in out and isinstance(out["strong_scaling"], dict):
         ss = out["strong_scaling"]
-        line["strong_scaling"] = {"total_batch": ss.get("total_batch"), "value": _r(ss.get("value"), 7), "ms_per_step": _r(ss.get("ms_per_step"), 6)}
+        line["strong_scaling"] = {"total_batch": ss.get("total_batch"), "batch_this_rank": ss.get("batch_this_rank"), "value": _r(ss.get("value"), 7),
+                                  "ms_per_step": _r(ss.get("ms_per_step"), 6)}
         optional.append("strong_scaling")
     if "wall_seconds" in out:
         line["wall_seconds"] = out["wall_seconds"]

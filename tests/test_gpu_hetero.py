@@ -44,9 +44,11 @@ def test_identical_instances_reproduce_the_host_cache():
     hom.close()
 
 
-@pytest.mark.parametrize("nx,nu,N", [(12, 4, 10), (6, 3, 10), (4, 2, 30)])
+@pytest.mark.parametrize("nx,nu,N", [(12, 4, 10), (6, 3, 10), (4, 2, 30),
+                                     # round 5: wide and long shapes, the tile kernel's per-instance form
+                                     (12, 8, 10), (20, 8, 10), (20, 4, 30), (8, 4, 50), (20, 8, 50)])
 def test_every_instance_matches_its_own_oracle(nx, nu, N):
-    B = 11
+    B = 11 if nx * N < 600 else 5
     fams = [random_family(nx, nu, N, 900 + 17 * i + nx) for i in range(B)]
     rng = np.random.default_rng(5)
     x0 = rng.uniform(-1, 1, (B, nx))
@@ -60,6 +62,7 @@ def test_every_instance_matches_its_own_oracle(nx, nu, N):
     s.set_x0(x0)
     s.set_x_ref(Xref)
     s.set_u_ref(Uref)
+    assert s.kernel_path() == ("regs" if nx + nu <= 16 and N <= 30 else "tile")      # no shape of BASELINE's sweep lands on the coverage kernel
     s.solve()
     st = s.status()
     out = {k: s.get(k) for k in ("x", "u", "vnew", "znew", "g", "y", "v", "z")}
@@ -108,3 +111,89 @@ def test_hetero_large_batch_precompute():
     st = s.reduce_stats()
     assert st[0] > 0 and np.all(np.isfinite(s.get("u")))
     s.close()
+
+
+@pytest.mark.parametrize("dims,hetero", [((20, 8, 10), False), ((20, 8, 10), True), ((12, 8, 30), False), ((8, 2, 50), True)])
+def test_fused_tracking_episode_on_wide_and_long_shapes_runs_on_the_tile_kernel(dims, hetero):
+    """VERDICT r04 item 6 (f2 on wide shapes): the caller pattern of examples/quadrotor_tracking.cpp:77-106 -- a shared reference
+    trajectory whose N-knot window moves one knot per MPC step (per-instance offsets), y = 0, g = 0 before every solve, the plant
+    stepped on the device, several MPC steps fused into one launch -- on shapes the one-row kernel does not hold: kernel path 1
+    (the tile kernel's EXT form), per-step iteration counts and the final state of every instance against its own oracle loop;
+    then the same episode one launch per step (bit-identical), and a one-shot launch against a solve from the reset state."""
+    nx, nu, N = dims
+    B, T, launches = 7, 4, 3
+    rng = np.random.default_rng(77 + nx + N)
+    fams = [random_family(nx, nu, N, 4000 + 31 * i + nx + N) for i in range(B if hetero else 1)]
+    box = dict(x_min=np.full((nx, 1), -2.0), x_max=np.full((nx, 1), 2.0), u_min=np.full((nu, 1), -0.4), u_max=np.full((nu, 1), 0.4))
+    x0 = rng.uniform(-0.5, 0.5, (B, nx))
+    Uref = rng.normal(0, 0.05, (B, nu, N - 1))
+    n_pts = N + T * launches + 2                           # (the window runs off the end of the trajectory: the last point repeats)
+    traj = rng.normal(0, 0.3, (n_pts, nx))
+    offs = rng.integers(0, 4, B).astype(np.int32)
+
+    def make():
+        if hetero:
+            s = tm.TinyBatchSolver.hetero(*[np.stack([f[k] for f in fams]) for k in ("A", "B", "f", "Q", "R")], np.array([f["rho"] for f in fams]), N)
+        else:
+            s = tm.TinyBatchSolver.from_problem(fams[0], B)
+        s.set_bound_constraints(box["x_min"], box["x_max"], box["u_min"], box["u_max"])
+        s.update_settings(max_iter=40)
+        s.set_x0(x0); s.set_u_ref(Uref)
+        s.set_reference_trajectory(traj, offs)
+        s.set_option("reset_duals", 1)
+        s.set_option("advance_x0", 1)
+        s.set_option("step_log", 1)
+        return s
+    s = make()
+    s.set_option("steps_per_launch", T)
+    assert s.kernel_path() == "tile"
+    its = []
+    for _ in range(launches):
+        s.solve_async()
+        its.append(np.abs(s.step_log(T)[0]))
+    its = np.concatenate(its)
+    assert s.kernel_path() == "tile"
+    got = dict(x0=s.get("x0"), x=s.get("x"), u=s.get("u"), vnew=s.get("vnew"), g=s.get("g"), v=s.get("v"))
+    s.close()
+    for b in range(B):
+        fam = fams[b if hetero else 0]
+        o = sc.make_solver(OracleSolver, fam, sc.default_config(fam, max_iter=40, **box))
+        o["Uref"] = Uref[b]
+        xb = x0[b].copy()
+        for k in range(T * launches):
+            o["Xref"] = traj[np.minimum(np.arange(N) + k + offs[b], n_pts - 1)].T
+            o["g"] = np.zeros((nx, N)); o["y"] = np.zeros((nu, N - 1))
+            o["x"][:, 0] = xb
+            o.solve()
+            assert int(o.get("sol_iter")) == its[k, b], (b, k)
+            xb = fam["A"] @ xb + fam["B"] @ o["u"][:, 0] + fam["f"]
+        for k, ref in dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"]).items():
+            assert rel_err(got[k][b], ref) < 1e-7, (b, k)         # (per-solve 1e-13 compounds through twelve plant steps)
+        o.close()
+    # one launch per MPC step: the same episode bit for bit
+    s1 = make()
+    s1.set_option("steps_per_launch", 1)
+    for _ in range(T * launches):
+        s1.solve_async()
+    for k in got:
+        assert np.array_equal(s1.get(k), got[k]), k
+    # one-shot launches (cold state assumed, garbage in the records not read): x | u (+ vnew | znew) of a solve from the reset state
+    s1.set_option("reset_duals", 0)
+    s1.set_reference_trajectory(None)
+    s1.set_option("advance_x0", 0)
+    Xref = np.repeat(rng.uniform(-0.3, 0.3, (B, nx, 1)), N, axis=2)
+    s1.reset()
+    s1.set_x0(x0); s1.set_x_ref(Xref); s1.set_u_ref(Uref)
+    s1.solve()
+    ref = dict(x=s1.get("x"), u=s1.get("u"), vnew=s1.get("vnew"), it=s1.status()["iter"].copy())
+    for mode in (1, 2):
+        for f in ("vnew", "znew", "g", "y", "v", "z", "x", "u"):
+            s1.set(f, rng.normal(0, 5.0, s1.get(f).shape))
+        s1.set_x0(x0)
+        s1.set_option("one_shot", mode)
+        assert s1.kernel_path() == "tile"
+        s1.solve()
+        assert np.array_equal(s1.status()["iter"], ref["it"]) and np.array_equal(s1.get("x"), ref["x"]) and np.array_equal(s1.get("u"), ref["u"])
+        if mode == 1:
+            assert np.array_equal(s1.get("vnew"), ref["vnew"])
+    s1.close()

@@ -71,7 +71,8 @@ def test_bench_control_flow_with_two_ranks_on_this_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and "SMOKE RUN" in d["data"]
     assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9               # 691 iterations over the first 20 steps, on BOTH ranks' instances
     assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["stats_exchange"] == "torch.distributed"
-    assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 2 * 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-5 * d["value"]      # (the line rounds to 6-7 digits)
+    assert len(lines[0]) <= 4096
 
 
 def test_bench_plain_process_spawns_its_own_ranks_weak_and_strong():
@@ -95,12 +96,12 @@ def test_bench_plain_process_spawns_its_own_ranks_weak_and_strong():
     assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9
     ss = d["strong_scaling"]
     assert ss["total_batch"] == 8192 and ss["batch_this_rank"] == 4096
-    assert abs(ss["value"] - 8192 * 20 / (ss["ms_per_step"] * 20 * 1e-3)) < 1e-6 * ss["value"]
+    assert abs(ss["value"] - 8192 * 20 / (ss["ms_per_step"] * 20 * 1e-3)) < 1e-5 * ss["value"]
     p = subprocess.run(base + ["--scaling", "strong"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 4096 and d["config"]["total_batch"] == 8192 and "strong_scaling" not in d
-    assert abs(d["value"] - 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 8192 * 20 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-5 * d["value"]
     assert abs(d["admm_iters_per_solve"] - 34.55) < 1e-9
 
 
@@ -128,24 +129,40 @@ def test_bench_with_a_lost_rank_still_prints_one_json_line(fault):
     assert d["metric"].startswith("QP solves/sec") and d["steps"] == 20
 
 
-def test_bench_line_carries_the_other_configs_and_honest_hbm_fields():
-    """the 1-GPU line holds `configs` (BASELINE configs 3, 4 and six sweep cells, each with a
-    roofline that recomputes from its own fields), `regimes` with hbm_frac from the bytes really moved next to the formula
-    figure and the per-instance-reference regime, `traffic_source`, and the CPU baseline measured AFTER the GPU legs."""
+def test_bench_line_carries_the_other_configs_and_honest_hbm_fields(tmp_path):
+    """the 1-GPU run prints ONE compact line (<= 4 KiB of strict JSON: the contract's keys,
+    `roofline`, `cpu_baseline`, a few numbers per regime and `configs` entry, the warm regime beyond the Infinity Cache as
+    `roofline_hbm`) and writes the full record -- `configs` (BASELINE configs 3, 4 and six sweep cells, each with a roofline that
+    recomputes from its own fields), `regimes` with hbm_frac from the bytes really moved next to the formula figure -- to the details
+    file the line names."""
     import json
     import subprocess
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.3", "--cpu-seconds", "0.5"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    details = str(tmp_path / "bench_details.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.3", "--cpu-seconds", "0.5",
+                        "--details", details], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["launcher"] == "plain process"
+    assert p.stdout.count("\n") == 1 and p.stdout.startswith("{")      # stdout IS the one line
+
+    def reject(name):
+        raise ValueError(name)
+    line = json.loads(p.stdout, parse_constant=reject)
+    assert len(p.stdout) <= 4096 and "truncated" not in line
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["config"]["launcher"] == "plain process" and line["dtype"] == "f64"
+    assert line["roofline"]["bound"] == "fp64-valu" and 0.5 < line["roofline"]["frac"] < 1.0 and line["roofline"]["avg_launch_ms"] > 0
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    assert line["roofline_hbm"]["beyond_L3"] is True and line["roofline_hbm"]["batch"] >= 262144
+    assert 0.2 < line["roofline_hbm"]["own_refs"]["hbm_frac"] < 1.0 and 0.2 < line["warm_regime"]["own_refs"]["hbm_frac"] < 1.0
+    assert line["parity"] == {"entries_checked": 10, "mismatches": 0}
+    assert line["configs"]["config3"]["planned_first_call_ms"] <= 1.25 * line["configs"]["config3"]["ms"]      # an imported plan: settled on the first call
+    assert os.path.samefile(os.path.join(ROOT, line["details"]), details)
+    d = json.load(open(details))
+    assert abs(d["value"] / line["value"] - 1) < 1e-6
     assert d["roofline"]["traffic_source"] is None or "traffic.json" in d["roofline"]["traffic_source"]
     cf = d["configs"]
+    assert set(cf) == set(line["configs"])
     assert set(cf) == {"config3", "config4", "config4_state_cone", "config4_both_cones", "sweep_4_2_10", "sweep_12_4_30", "sweep_4_2_50",
                        "sweep_12_8_30", "sweep_20_8_10", "sweep_20_8_50"}
     for name, e in cf.items():
@@ -164,6 +181,8 @@ def test_bench_line_carries_the_other_configs_and_honest_hbm_fields():
     assert cf["config3"]["solves"] == 262144 and cf["config4"]["solves"] == 65536 * 90 and cf["sweep_20_8_50"]["kernel"] == "tile"
     assert cf["config4_both_cones"]["en_state_soc"] == 1 and cf["config4_both_cones"]["en_input_soc"] == 1
     rg = d["regimes"]
+    big = rg["beyond_l3"]
+    assert big["batch"] == 262144 and big["working_set_bytes"] > 3 * 256 * 2 ** 20          # several times the 256 MiB Infinity Cache
     for k in ("steady_state", "steady_state_per_instance_refs", "steady_state_no_primal_store", "steady_state_first_knot_store"):
         assert rg[k]["bytes_moved_per_solve"] <= rg[k]["algorithmic_bytes_per_solve"] and rg[k]["hbm_frac"] <= rg[k]["hbm_frac_formula"] + 1e-12
     assert rg["steady_state_per_instance_refs"]["bytes_moved_per_solve"] > rg["steady_state"]["bytes_moved_per_solve"]

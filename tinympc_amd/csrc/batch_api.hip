@@ -465,6 +465,11 @@ static int tile_lin_variant(const TinyBatch* b) {
 }
 static bool cones_overlap(const TinyBatch* b);
 static int lin_variant(const TinyBatch* b);
+// EXT template value of the tile kernel form this batch's launches need (tile_kernel.hip.h): bit 0 a reference-trajectory window /
+// reset_duals / one_shot, bit 1 per-instance problem data; 0: the plain forms
+static int tile_ext_variant(const TinyBatch* b) {
+    return ((b->d_traj || b->reset_duals || b->one_shot) ? 1 : 0) | (b->hetero ? 2 : 0);
+}
 static bool use_tile(const TinyBatch* b) {
     if (cones_overlap(b)) return false;
     if (linear_active(b) && (tile_lin_variant(b) == 0 || b->no_jit || b->tile_soc_failed)) return false;
@@ -474,8 +479,11 @@ static bool use_tile(const TinyBatch* b) {
     const int lvr = linear_active(b) ? lin_variant(b) : 0;
     const bool regs_cannot = linear_active(b) && !b->force_general &&
                              (lvr == 0 || !solve_kernel_lin_planes(b->nx, b->nu, b->N, soc_active(b), lvr, lin_kmax(b), false));   // (the one-row half-space variants are instantiated without UB)
-    return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile || regs_cannot) && !b->no_tile && !b->hetero && !b->adaptive && !b->force_general && !b->debug &&
-           !b->d_traj && !b->reset_duals && !b->one_shot;
+    // per-instance problem data, reference-trajectory windows, reset_duals, one_shot: the tile kernel's EXT forms (run-time instantiated
+    // like its cone / half-space variants, round 5) -- for the shapes the one-row kernel does not hold; a shape it holds keeps them there
+    const int ext = tile_ext_variant(b);
+    if (ext && (b->no_jit || b->tile_soc_failed || has_regs(b))) return false;
+    return b->tile && !((b->tile_is_jit || soc_active(b) || linear_active(b)) && (b->no_jit || b->tile_soc_failed)) && (!has_regs(b) || b->prefer_tile || regs_cannot) && !b->no_tile && !b->adaptive && !b->force_general && !b->debug;
 }
 
 // per-step iteration counts / applied controls of a fused launch (option "step_log")
@@ -514,7 +522,8 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
         HIP_TRY(b, hipMemcpyAsync(b->d_ttab, b->h_ttab.data(), b->h_ttab.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
     const bool ub = b->tile_bounds_uniform && b->use_ub;
-    if (b->tile_is_jit || soc || lv) {               // a tile shape outside tile_dims.txt, or a cone / half-space variant: instantiate it now (jit.hpp)
+    const int ext = tile_ext_variant(b);
+    if (b->tile_is_jit || soc || lv || ext) {        // a tile shape outside tile_dims.txt, or a cone / half-space / EXT variant: instantiate it now (jit.hpp)
         std::string why;
         // (the cone / half-space variants keep all their arrays in registers and the trajectory in LDS: their R comes from the
         // register / LDS budget of THAT form, not from the compiled-in plain form's entry)
@@ -522,18 +531,23 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
             vR = budget_variant_tile_r(b, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, ub);
             if (vR == 0) vR = variant_tile_r(b);
         }
-        if (b->tile_r > 0 && (soc || lv)) vR = b->tile_r;           // (option "tile_r": experiments)
+        if (b->tile_r > 0 && (soc || lv || ext)) vR = b->tile_r;    // (option "tile_r": experiments)
         // a shape outside tile_dims.txt with plain box constraints: large batches of more than one instance per wave take the dynamic
         // slot form too (instantiated on first use like the static one; a failure falls back to the static form)
         const int jipw = 4 / (std::max(1, b->tile->W) * vR);
-        jit_dyn = b->tile_is_jit && !soc && !lv && b->tile_dyn_opt != 0 && jipw >= 2 && b->grid_waves_per_cu <= 0 &&
+        jit_dyn = b->tile_is_jit && !soc && !lv && !ext && b->tile_dyn_opt != 0 && jipw >= 2 && b->grid_waves_per_cu <= 0 &&
                   (b->tile_dyn_opt > 0 || (long)((b->batch + jipw - 1) / jipw) >= 16L * b->num_cus);
         if (jit_dyn) {
             jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, LIN_KMAX, &why, true);
             if (!jit_fn) { jit_dyn = false; why.clear(); }
         }
-        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, &why, false, ub && (soc || lv));
+        if (!jit_fn) jit_fn = jit_tile_kernel(b->nx, b->nu, b->N, std::max(1, b->tile->W), vR, socm, lv, lv ? lin_kmax(b) : LIN_KMAX, &why, false, ub && (soc || lv || ext), ext);
         if (!jit_fn) {                               // the coverage kernel takes over
+            if (ext) {                               // ... but not these launch forms: no other kernel runs them for this shape
+                b->tile_soc_failed = true;
+                return fail(b, TINY_ERR_UNSUPPORTED, "the tile kernel's form for per-instance data / reference windows / reset_duals / one_shot could not be instantiated for (%d,%d,%d): %s",
+                            b->nx, b->nu, b->N, why.c_str());
+            }
             if ((soc || lv) && !b->tile_is_jit) b->tile_soc_failed = true;
             else { b->tile = nullptr; b->tile_is_jit = false; }
             b->tab_dirty = true; b->redispatch = true;
@@ -557,6 +571,14 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
     a.x0_next = (b->advance_x0 || steps > 1) ? b->d_x0 : nullptr;     // fused steps imply the plant step
     a.rho = b->cache.rho; a.tol_pri = b->set.abs_pri_tol; a.tol_dua = b->set.abs_dua_tol;
     a.batch = dry ? 0 : b->batch; a.max_iter = b->set.max_iter; a.check_termination = b->set.check_termination; a.steps = steps;
+    a.store_mask = 31;
+    if (ext) {                                       // what the EXT forms read (as launch_solve sets them for the one-row kernel)
+        a.het_tabs = b->hetero ? b->d_het_tabs : nullptr;
+        a.traj = b->d_traj; a.traj_offsets = b->d_traj_offsets; a.traj_points = b->traj_points; a.traj_step0 = (int)b->traj_step;
+        a.reset_duals = b->reset_duals ? 1 : 0;
+        a.cold = b->one_shot ? 1 : 0;
+        a.store_mask = b->one_shot == 2 ? 1 : (b->one_shot == 1 ? 3 : 31);
+    }
     if (steps > 1 && b->step_log) {
         if (int rc = ensure_step_logs(b, steps)) return rc;
         a.iter_log = b->d_iter_log; a.u0_log = b->d_u0_log;
@@ -611,6 +633,10 @@ static int launch_tile(TinyBatch* b, bool dry = false) {
     }
     b->last_tile_form = te ? (te->W * 1000000 + te->R * 1000 + te->lm) : -1;      // which tile_dims.txt entry ran (-1: run-time instantiated)
     if (timed) { HIP_TRY(b, hipEventRecord(b->ev_stop[b->timing_n], b->stream)); b->timing_n++; b->timing_left--; }
+    if (!dry) {
+        b->status_valid = true;
+        if (b->d_traj) b->traj_step += steps;        // the window moves one knot per MPC step
+    }
     return TINY_OK;
 }
 
@@ -1574,8 +1600,8 @@ int launch_solve(TinyBatch* b) {
     b->redispatch = false;
     if (cones_overlap(b) && (b->hetero || b->adaptive || b->d_traj || b->one_shot || b->steps_per_launch > 1))
         return fail(b, TINY_ERR_UNSUPPORTED, "overlapping cones run on the coverage kernel: no per-instance data, adaptive rho, reference window, one-shot or fused steps with them");
-    if (b->hetero && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
-        return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous problem data needs the register-resident kernel (nx+nu <= 16, at most 4 half-spaces per knot and family)");
+    if (b->hetero && !use_tile(b) && (!has_regs(b) || (linear_active(b) && lin_variant(b) == 0)))
+        return fail(b, TINY_ERR_UNSUPPORTED, "heterogeneous problem data needs a register-resident kernel (the one-row kernel with at most 4 half-spaces per knot and family, or the tile kernel's per-instance form)");
     if (b->adaptive && !has_regs(b))
         return fail(b, TINY_ERR_UNSUPPORTED, "adaptive rho needs the register-resident kernel (nx+nu <= 16, horizon within the register file)");
     const int path = use_tile(b) ? 1 : (use_general(b) ? 2 : 0);
@@ -1789,17 +1815,22 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
 int tiny_batch_setup_hetero(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn, const double* Qdiag,
                             const double* Rdiag, const double* rho, int nx, int nu, int N, int batch, int device, int verbose) {
     if (!out || !Adyn || !Bdyn || !Qdiag || !Rdiag || !rho) return TINY_ERR_NULL;
-    if (nx <= 0 || nu <= 0 || nx + nu > 16) return TINY_ERR_UNSUPPORTED;
+    if (nx <= 0 || nu <= 0 || nx + nu > 32 || nu > 16) return TINY_ERR_UNSUPPORTED;
     // instance 0 builds the ordinary handle (records, shared tables for bounds / cones / masks, settings)
     int rc = tiny_batch_setup(out, Adyn, Bdyn, fdyn, Qdiag, Rdiag, rho[0], nx, nu, N, batch, device, verbose);
     if (rc) return rc;
     TinyBatch* b = *out;
-    if (!has_regs(b)) { tiny_batch_destroy(b); *out = nullptr; return TINY_ERR_UNSUPPORTED; }
+    // the kernel that will read the per-instance tables decides their layout: the one-row kernel where it holds the shape, else the
+    // tile kernel's per-instance form (wide and long shapes: round 5); neither: unsupported
+    if (!has_regs(b) && !(b->tile && !b->no_jit)) { tiny_batch_destroy(b); *out = nullptr; return TINY_ERR_UNSUPPORTED; }
+    const bool tile_layout = !has_regs(b);
+    const int tab_cols = tile_layout ? 32 : 16, tab_lw = tile_layout ? 16 * std::max(1, b->tile->W) : 16;
+    static_assert(het_tab_doubles(16, 16) == (int)HET_TAB_DOUBLES && het_tab_doubles(32, 16) == TileTab<1>::BOUNDS && het_tab_doubles(32, 32) == TileTab<2>::BOUNDS, "per-instance table layouts");
     auto bail = [&](int code) { tiny_batch_destroy(b); *out = nullptr; return code; };
     const size_t xx = (size_t)nx * nx, xu = (size_t)nx * nu, uu = (size_t)nu * nu, B = batch;
     struct { double** p; size_t n; } bufs[] = {{&b->d_hA, B * xx}, {&b->d_hB, B * xu}, {&b->d_hf, B * nx}, {&b->d_hQw, B * nx},
         {&b->d_hRw, B * nu}, {&b->d_hrho, B}, {&b->d_hK, B * xu}, {&b->d_hP, B * xx}, {&b->d_hQuu, B * uu}, {&b->d_hAmBKt, B * xx},
-        {&b->d_hAPf, B * nx}, {&b->d_hBPf, B * nu}, {&b->d_het_tabs, B * (size_t)HET_TAB_DOUBLES}};
+        {&b->d_hAPf, B * nx}, {&b->d_hBPf, B * nu}, {&b->d_het_tabs, B * (size_t)het_tab_doubles(tab_cols, tab_lw)}};
     for (auto& u : bufs)
         if (hipMalloc(u.p, u.n * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
     if (hipMalloc(&b->d_hiters, B * sizeof(int)) != hipSuccess) return bail(TINY_ERR_HIP);
@@ -1817,7 +1848,7 @@ int tiny_batch_setup_hetero(TinyBatch** out, const double* Adyn, const double* B
     RiccatiArgs r;
     r.A = b->d_hA; r.B = b->d_hB; r.f = b->d_hf; r.Qw = b->d_hQw; r.Rw = b->d_hRw; r.rho = b->d_hrho;
     r.Kinf = b->d_hK; r.Pinf = b->d_hP; r.Quu_inv = b->d_hQuu; r.AmBKt = b->d_hAmBKt; r.APf = b->d_hAPf; r.BPf = b->d_hBPf;
-    r.iters = b->d_hiters; r.tabs = b->d_het_tabs; r.nx = nx; r.nu = nu; r.batch = batch;
+    r.iters = b->d_hiters; r.tabs = b->d_het_tabs; r.nx = nx; r.nu = nu; r.batch = batch; r.tab_cols = tab_cols; r.tab_lw = tab_lw;
     const size_t lds = (7 * xx + 7 * xu + 3 * uu + 2 * nx + nu) * sizeof(double);
     int grid = batch < b->num_cus * 8 ? batch : b->num_cus * 8;
     hipLaunchKernelGGL(riccati_kernel, dim3(grid), dim3(64), lds, b->stream, r);

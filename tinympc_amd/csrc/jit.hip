@@ -240,8 +240,13 @@ hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
     return get(name, false, err);
 }
 
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn, bool ub) {
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn, bool ub, int ext) {
     char name[256];
+    // (ext: the EXT forms -- reference window / reset_duals / cold starts / store masks, per-instance problem data; static tiles, LM = 0)
+    if (ext) {
+        snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, 0, false, %d>", nx, nu, N, W, R, soc, lin, kmax, ub ? "true" : "false", ext);
+        return get(name, true, err);
+    }
     // (dyn: the dynamic slot form -- persistent grid, slots draw instances from SolveArgs::work_counter; plain variants only)
     if (dyn) snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d, false, 0, true>", nx, nu, N, W, R, soc, lin, kmax);
     else snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d%s>", nx, nu, N, W, R, soc, lin, kmax, ub ? ", true" : "");

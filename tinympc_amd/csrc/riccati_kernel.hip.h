@@ -20,9 +20,14 @@ struct RiccatiArgs {
     const double *A, *B, *f, *Qw, *Rw, *rho;        // [batch][nx*nx], [batch][nx*nu], [batch][nx], [batch][nx], [batch][nu], [batch]
     double *Kinf, *Pinf, *Quu_inv, *AmBKt, *APf, *BPf;
     int* iters;                                      // Riccati steps taken (1000 = not converged)
-    double* tabs;                                    // [batch][HET_TAB_DOUBLES] lane tables
+    double* tabs;                                    // [batch][tab_doubles] lane tables
     int nx, nu, batch;
+    // layout of the lane tables: matrices [column k (0 .. tab_cols-1)][tab_lw lanes] at 0 (MB), cols*lw (MF1), 2 cols*lw (MF2), 3 cols*lw
+    // (PT), the 16 lane vectors at 4 cols*lw.  One-row kernel (admm_kernel.hip.h TAB_*): cols = lw = 16; tile kernel
+    // (tile_kernel.hip.h TileTab<W>): cols = 32, lw = 16 W
+    int tab_cols, tab_lw;
 };
+constexpr int het_tab_doubles(int cols, int lw) { return 4 * cols * lw + 16 * lw; }
 
 // per-instance table = the matrix + vector part of the shared table (bounds / cones / masks stay shared)
 enum : int { HET_TAB_DOUBLES = TAB_BOUNDS, VEC_RHO = 8 };
@@ -151,14 +156,16 @@ __global__ __launch_bounds__(64) void riccati_kernel(const RiccatiArgs P) {
         for (int e = lane; e < nu; e += 64) P.BPf[(size_t)b * nu + e] = T2[e];
         if (lane == 0) P.iters[b] = fail ? -1 : iters;
 
-        // ---- lane tables of this instance (layout of admm_kernel.hip.h; see batch_api.hip:build_tables)
+        // ---- lane tables of this instance (layout of admm_kernel.hip.h / tile_kernel.hip.h; see batch_api.hip:build_tables, build_tile_tables_w)
         w_mm(nu, nu, nx, Gi, Bt, T1, lane);                                    // Quu_inv B'
         w_mm(nu, nu, 1, Gi, T2, G, lane);                                      // Quu_inv BPf  (BPf is in T2)
-        double* tab = P.tabs + (size_t)b * HET_TAB_DOUBLES;
-        for (int e = lane; e < HET_TAB_DOUBLES; e += 64) tab[e] = 0.0;
+        const int cols = P.tab_cols, lw = P.tab_lw, tdoubles = het_tab_doubles(cols, lw);
+        const int o_mb = 0, o_mf1 = cols * lw, o_mf2 = 2 * cols * lw, o_pt = 3 * cols * lw, o_vec = 4 * cols * lw;
+        double* tab = P.tabs + (size_t)b * tdoubles;
+        for (int e = lane; e < tdoubles; e += 64) tab[e] = 0.0;
         __syncthreads();
-        for (int e = lane; e < 16 * 16; e += 64) {
-            const int k = e / 16, j = e % 16;              // column k, lane j
+        for (int e = lane; e < cols * lw; e += 64) {
+            const int k = e / lw, j = e % lw;              // column k, lane j
             double mb = 0.0, mf1 = 0.0, mf2 = 0.0, pt = 0.0;
             if (j < nx) {
                 if (k < nx) { mb = T3[j + nx * k]; mf1 = A[j + nx * k]; pt = Pn[k + nx * j]; }
@@ -168,16 +175,16 @@ __global__ __launch_bounds__(64) void riccati_kernel(const RiccatiArgs P) {
                 if (k < nx) { mb = T1[a + nu * k]; mf1 = -K[a + nu * k]; }
                 else if (k < nx + nu) mb = Gi[a + nu * (k - nx)];
             }
-            tab[TAB_MB + e] = mb; tab[TAB_MF1 + e] = mf1; tab[TAB_MF2 + e] = mf2; tab[TAB_PT + e] = pt;
+            tab[o_mb + e] = mb; tab[o_mf1 + e] = mf1; tab[o_mf2 + e] = mf2; tab[o_pt + e] = pt;
         }
-        if (lane < 16) {
+        if (lane < lw) {
             const int j = lane;
             // APf was overwritten in T1 by Quu_inv B': re-read it from the output array written above
             double cb = 0.0, cf = 0.0, qr = 0.0;
             if (j < nx) { cb = P.APf[(size_t)b * nx + j]; cf = fv[j]; qr = P.Qw[(size_t)b * nx + j]; }
             else if (j < nx + nu) { cb = G[j - nx]; qr = P.Rw[(size_t)b * nu + (j - nx)]; }
-            tab[TAB_VEC + VEC_CB * 16 + j] = cb; tab[TAB_VEC + VEC_CF * 16 + j] = cf;
-            tab[TAB_VEC + VEC_QR * 16 + j] = qr; tab[TAB_VEC + VEC_RHO * 16 + j] = rho;
+            tab[o_vec + VEC_CB * lw + j] = cb; tab[o_vec + VEC_CF * lw + j] = cf;
+            tab[o_vec + VEC_QR * lw + j] = qr; tab[o_vec + VEC_RHO * lw + j] = rho;
         }
         __syncthreads();
     }

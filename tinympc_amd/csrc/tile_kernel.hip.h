@@ -102,6 +102,8 @@ constexpr long tile_soc_lds_bytes(int nx, int nu, int n, int w, int r, int soc, 
     return 8L * (2L * (ub ? 2 : n) * 16 * w + (n / r) * 64 + (long)(ipw * n + 1) * 3 * csr);
 }
 template <int V> struct TileIntTag { static constexpr int value = V; };
+template <bool C, class A, class B> struct TileSelect { typedef A type; };
+template <class A, class B> struct TileSelect<false, A, B> { typedef B type; };
 #ifndef TINYMPC_TILE_SOC_WAVES
 #define TINYMPC_TILE_SOC_WAVES 0                   // (experiments: 1 / 2 instead of the rule)
 #endif
@@ -124,13 +126,20 @@ constexpr int tile_soc_waves(int nx, int nu, int n, int w, int r, int soc, bool 
 // W = 1 shapes compiled with TINYMPC_FUSED_NX / _NU (csrc/Makefile) run the sweeps on the one-row kernel's fused step blocks
 // (fused_backward_step / fused_forward_step: the lane-local instructions of a step sit in front of its DPP chain, no s_nop)
 // and take that kernel's placement of the forward constant (d <- fma(res, nim, cf)).
-template <int NX, int NU, int N, int W, int R, int SOC = 0, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false>
+// EXT (run-time instantiated like SOC / LIN; round 5): bit 0 = the launch forms the one-row kernel offers a closed-loop caller -- a
+// reference-trajectory window per MPC step (SolveArgs::traj: work->Xref = Xref_total.block(0, k, nx, N),
+// examples/quadrotor_tracking.cpp:85-88), reset_duals (work->y = 0, work->g = 0 before every solve, :92-93), cold starts that
+// do not read the warm-start records and the store masks of one_shot; bit 1 = per-instance problem data (HET: the matrix rows
+// and rho of the instance's own cache, riccati_kernel.hip.h, in the tile table layout).  All arrays in registers (LM = 0).
+template <int NX, int NU, int N, int W, int R, int SOC = 0, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false, int EXT = 0>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : tile_waves_per_simd(NX, NU, N, R, LM, W)),
                                    LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : tile_waves_per_simd(NX, NU, N, R, LM, W)))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr bool HR = W == 0;                                        // half rows: two instances per DPP row (nx+nu <= 8)
+    constexpr bool EXTF = (EXT & 1) != 0, HETX = (EXT & 2) != 0;
+    static_assert(EXT == 0 || (LM == 0 && !DYN && W >= 1), "EXT forms: all arrays in registers, static tiles");
     constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
     constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
@@ -178,9 +187,10 @@ void admm_tile_kernel(const SolveArgs P) {
     for (int k = 0; k < NX; ++k) mf1[k] = P.tab[T::MF1 + k * LW + jj];
 #pragma unroll
     for (int k = 0; k < NU; ++k) mf2[k] = P.tab[T::MF2 + (NX + k) * LW + jj];
-    const double cb = P.tab[T::VEC + VEC_CB * LW + jj];
-    const double cf = P.tab[T::VEC + VEC_CF * LW + jj];
-    const double qr = P.tab[T::VEC + VEC_QR * LW + jj];
+    typedef typename TileSelect<HETX, double, const double>::type FamilyScalar;   // (HETX: replaced by the instance's own at every load)
+    FamilyScalar cb = P.tab[T::VEC + VEC_CB * LW + jj];
+    FamilyScalar cf = P.tab[T::VEC + VEC_CF * LW + jj];
+    FamilyScalar qr = P.tab[T::VEC + VEC_QR * LW + jj];
     const double smask = P.tab[T::VEC + VEC_SMASK * LW + jj];
     const double nim = P.tab[T::VEC + VEC_NIM * LW + jj];
     double socmask = 0.0;
@@ -284,7 +294,7 @@ void admm_tile_kernel(const SolveArgs P) {
             if (__builtin_amdgcn_ballot_w64(!p2) != 0ull) mu_pow2 = false;
         }
     }
-    const double rho = P.rho;
+    FamilyScalar rho = P.rho;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const double lo_u = sLo[LW + jj], hi_u = sHi[LW + jj], lo_u0 = sLo[jj], hi_u0 = sHi[jj];     // UB (N >= 2 always)
@@ -313,6 +323,41 @@ void admm_tile_kernel(const SolveArgs P) {
     //   dynamic (DYN = true, persistent grid): a slot takes the next instance off ONE device-wide counter the moment it is free
     //     (one atomic per wave and pass that needs any) -- rows only idle in the tail of the launch.  Instances are independent, so
     //     who solves which changes nothing in the results.
+    // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292); every lane of the instance takes part in the chain
+    // (EXT forms only: the others keep their inline copy in the load and capture nothing here)
+    auto terminal_term = [&]() {
+        if constexpr (EXT != 0) {
+            double pt[NX];
+            const double* const tp = HETX ? P.het_tabs + (size_t)b * T::BOUNDS : P.tab;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) pt[k] = tp[T::PT + k * LW + jj];
+            const double xp = tile_matvec<W, 0, NX>(0.0, ref_last, pt);
+            if (hrow == R - 1 && is_state) QX[L - 1] = -xp;
+        }
+    };
+    // EXT bit 0, at the start of every solve (MPC step `step` of this launch): the reference window and the dual reset
+    auto ext_begin_solve = [&]() {
+        if constexpr (EXTF) {
+            if (P.traj) {                                               // work->Xref = Xref_total.block(0, k, nx, N)
+                const int k0 = P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0) + step + g0;
+                if (is_state) {
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        int kk = k0 + l;
+                        kk = kk < P.traj_points ? kk : P.traj_points - 1;
+                        const double r = P.traj[(size_t)kk * NX + jj];
+                        QX[l] = -(r * qr);                              // admm.cpp:266 / :279
+                        if (l == L - 1) ref_last = r;
+                    }
+                }
+                terminal_term();
+            }
+            if (P.reset_duals) {                                        // work->y = 0; work->g = 0
+#pragma unroll
+                for (int l = 0; l < L; ++l) G[l] = 0.0;
+            }
+        }
+    };
     for (;;) {
         bool fresh = false;
         if constexpr (DYN) {
@@ -335,27 +380,42 @@ void admm_tile_kernel(const SolveArgs P) {
             }
         }
         if (fresh) {
+            if constexpr (HETX) {                                  // this instance's own cache (A, B, Q, R, rho differ per instance)
+                const double* het = P.het_tabs + (size_t)b * T::BOUNDS;
+#pragma unroll
+                for (int k = 0; k < NZ; ++k) mb[k] = het[T::MB + k * LW + jj];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) mf1[k] = het[T::MF1 + k * LW + jj];
+#pragma unroll
+                for (int k = 0; k < NU; ++k) mf2[k] = het[T::MF2 + (NX + k) * LW + jj];
+                cb = het[T::VEC + VEC_CB * LW + jj];
+                cf = het[T::VEC + VEC_CF * LW + jj];
+                qr = het[T::VEC + VEC_QR * LW + jj];
+                rho = het[T::VEC + 8 * LW + jj];                   // VEC_RHO (riccati_kernel.hip.h)
+            }
             // ---- load the instance record
+            [[maybe_unused]] const bool cold = EXTF && P.cold;     // the warm-start records are known to be zero: not read
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const int g = g0 + l;
                 const bool valid = is_state || (is_input && g >= 1);
+                const bool warm = valid && !cold;
                 const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
                 const double r = valid ? P.ref[off] : 0.0;
-                VN[l] = valid ? P.slack[off] : 0.0;
-                G[l] = valid ? P.dual[off] : 0.0;
-                if constexpr (VL_) sV[l * SLOT + li] = valid ? P.slack_prev[off] : 0.0; else if constexpr (!VG) VP[l] = valid ? P.slack_prev[off] : 0.0;
+                VN[l] = warm ? P.slack[off] : 0.0;
+                G[l] = warm ? P.dual[off] : 0.0;
+                if constexpr (VL_) sV[l * SLOT + li] = warm ? P.slack_prev[off] : 0.0; else if constexpr (!VG) VP[l] = warm ? P.slack_prev[off] : 0.0;
                 if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else if constexpr (!QR) QX[l] = -(r * qr);
                 if constexpr (DL) sD[l * SLOT + li] = 0.0; else Dn[l] = 0.0;
                 if constexpr (SOC) {
-                    const double vc0 = (valid && soc_lane) ? P.prim[off] : 0.0;         // vcnew = x, zcnew = u (admm.cpp:352-357)
-                    const double gc0 = (valid && soc_lane) ? P.cdual[off] : 0.0;
+                    const double vc0 = (warm && soc_lane) ? P.prim[off] : 0.0;          // vcnew = x, zcnew = u (admm.cpp:352-357)
+                    const double gc0 = (warm && soc_lane) ? P.cdual[off] : 0.0;
                     sC[cw0 + l * SLOT_C] = vc0 - gc0;
                     sC[cw0 + l * SLOT_C + PL_GC] = gc0;
                     sC[cw0 + l * SLOT_C + PL_VC] = vc0;
                 }
-                if constexpr (LS) { sLV[cl0 + l * CSL] = (valid && lin_lane) ? P.prim[off] : 0.0; sLG[cl0 + l * CSL] = (valid && lin_lane) ? P.ldual[off] : 0.0; }     // :361-365
-                if constexpr (LT) { sTV[cl0 + l * CSL] = (valid && tlin_lane) ? P.prim[off] : 0.0; sTG[cl0 + l * CSL] = (valid && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
+                if constexpr (LS) { sLV[cl0 + l * CSL] = (warm && lin_lane) ? P.prim[off] : 0.0; sLG[cl0 + l * CSL] = (warm && lin_lane) ? P.ldual[off] : 0.0; }     // :361-365
+                if constexpr (LT) { sTV[cl0 + l * CSL] = (warm && tlin_lane) ? P.prim[off] : 0.0; sTG[cl0 + l * CSL] = (warm && tlin_lane) ? P.tldual[off] : 0.0; }  // :370-374
                 if (l == L - 1) ref_last = r;                          // only meaningful on the last horizon row
             }
             x0v = (hrow == 0 && is_state) ? P.x0[(size_t)b * NX + jj] : 0.0;
@@ -367,14 +427,14 @@ void admm_tile_kernel(const SolveArgs P) {
                 vpp0 = (hrow == 0 && is_input) ? pad : vpp;
                 if constexpr (QR) { rpp = P.ref + (vpp - P.slack_prev); rpp0 = P.ref + (vpp0 - P.slack_prev); }
             }
-            {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
+            if constexpr (EXT == 0) {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
                 double pt[NX];
 #pragma unroll
                 for (int k = 0; k < NX; ++k) pt[k] = P.tab[T::PT + k * LW + jj];
                 const double xp = tile_matvec<W, 0, NX>(0.0, ref_last, pt);
                 if constexpr (QR) qx_term = -xp;
                 else if (hrow == R - 1 && is_state) { if constexpr (QL) sQ[(L - 1) * SLOT + li] = -xp; else QX[L - 1] = -xp; }
-            }
+            } else if (!(EXTF && P.traj)) terminal_term();          // (a reference window: formed at the start of every solve, below)
             if constexpr (QL || DL || VL_) {                           // (each lane only ever reads its own entries back: no barrier needed,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the fence keeps the compiler from moving LDS reads above these writes)
             }
@@ -388,6 +448,7 @@ void admm_tile_kernel(const SolveArgs P) {
             if (start) {
                 iter = 0; solved = 0; countdown = P.check_termination;
                 x0_last = x0v;
+                ext_begin_solve();
                 if constexpr (SOC) {
                     if (hrow == 0 && is_state && soc_lane) {               // x[:,0] = x0
                         sC[cw0] = x0v - sC[cw0 + PL_GC];
@@ -715,6 +776,7 @@ void admm_tile_kernel(const SolveArgs P) {
                     // the next fused MPC step of the same instance starts in the next pass
                     iter = 0; solved = 0; countdown = P.check_termination;
                     x0_last = x0v;
+                    ext_begin_solve();
                     if constexpr (SOC) {
                         if (soc_lane) {                                    // vcnew = x, zcnew = u of the previous solve (admm.cpp:352-357); x[:,0] = x0
 #pragma unroll
@@ -781,23 +843,27 @@ void admm_tile_kernel(const SolveArgs P) {
                     const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
                     if (valid) {
                         // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
+                        // EXT: SolveArgs::store_mask as in the one-row kernel (bit 0 x|u, 5 its first knot only, 1 vnew|znew, 2 g|y, 3 v|z, 4 the slacks)
+                        const int sm = EXTF ? P.store_mask : 63;
                         if constexpr (KEEPX) {
+                        if ((sm & 1) || ((sm & 32) && g <= 1)) {
                         if (iter > 0) P.prim[off] = sX[l * 64 + lane];
                         else if (g == 0 && is_state) P.prim[off] = x0v;
                         }
-                        P.slack[off] = VN[l];
-                        P.dual[off] = G[l];
-                        if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else if constexpr (!VG) P.slack_prev[off] = VP[l];
+                        }
+                        if (sm & 2) P.slack[off] = VN[l];
+                        if (sm & 4) P.dual[off] = G[l];
+                        if (sm & 8) { if constexpr (VL_) P.slack_prev[off] = sV[l * SLOT + li]; else if constexpr (!VG) P.slack_prev[off] = VP[l]; }
                         if constexpr (SOC) {
                             // vcnew: the VC plane where the cell belongs to an item (or no iteration ran: what the solve started from),
                             // else what the last forward sweep left in the W plane
-                            if (soc_lane) {
+                            if (soc_lane && (sm & 16)) {
                                 P.cslack[off] = sC[cw0 + l * SLOT_C + ((proj_lane || iter == 0) ? PL_VC : 0)];
                                 P.cdual[off] = sC[cw0 + l * SLOT_C + PL_GC];
                             }
                         }
-                        if constexpr (LS) { if (lin_lane) { P.lslack[off] = sLV[cl0 + l * CSL]; P.ldual[off] = sLG[cl0 + l * CSL]; } }
-                        if constexpr (LT) { if (tlin_lane) { P.tlslack[off] = sTV[cl0 + l * CSL]; P.tldual[off] = sTG[cl0 + l * CSL]; } }
+                        if constexpr (LS) { if (lin_lane && (sm & 16)) { P.lslack[off] = sLV[cl0 + l * CSL]; P.ldual[off] = sLG[cl0 + l * CSL]; } }
+                        if constexpr (LT) { if (tlin_lane && (sm & 16)) { P.tlslack[off] = sTV[cl0 + l * CSL]; P.tldual[off] = sTG[cl0 + l * CSL]; } }
                     }
                 }
                 if (P.x0_next && iter > 0 && hrow == 0 && is_state) P.x0_next[(size_t)b * NX + jj] = x1v;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the closed-loop surfaces against the oracle, instance by instance: fused MPC steps
 (steps_per_launch), the plant step, the moving reference window with per-instance offsets, reset_duals, heterogeneous
-problem families and one-shot launches, on random register-resident shapes with random bounds / cones / settings.
+problem families and one-shot launches, on random register-resident shapes (one-row kernel; a quarter of the trials: the tile
+kernel's wide / long shapes and their EXT forms) with random bounds / cones / settings.
     python tools/fuzz_closed_loop.py [n_trials] [seed]"""
 import os, sys
 import numpy as np
@@ -63,6 +64,19 @@ def draw(seed):
     n_pts = N + T * launches + 3
     traj = rng.normal(0, 0.3, (n_pts, nx))
     offs = rng.integers(0, 3, B).astype(np.int32)
+    if slow:
+        # round 5: the tile kernel's EXT forms -- per-instance problem data, reference windows, reset_duals, one-shot launches on wide /
+        # long shapes.  Drawn from a stream of their own so that every earlier seed keeps the trial it always had.
+        r2 = np.random.default_rng(seed + 7919)
+        hetero = r2.random() < 0.35
+        if hetero:
+            fams = [fams[0]] + [family(r2, nx, nu, N) for _ in range(B - 1)]
+        use_traj = r2.random() < 0.4
+        reset_duals = bool(use_traj and r2.random() < 0.5)
+        one_shot = 0 if (use_traj or r2.random() < 0.6) else int(r2.integers(1, 3))
+        n_pts = N + T * launches + 3
+        traj = r2.normal(0, 0.3, (n_pts, nx))
+        offs = r2.integers(0, 3, B).astype(np.int32)
     return dict(nx=nx, nu=nu, N=N, B=B, hetero=hetero, fams=fams, slow=slow, T=T, launches=launches, use_traj=use_traj, reset_duals=reset_duals,
                 one_shot=one_shot, kw=kw, debug=debug, cfg=cfg, x0=x0, Xref=Xref, Uref=Uref, n_pts=n_pts, traj=traj, offs=offs)
 
