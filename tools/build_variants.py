@@ -84,6 +84,16 @@ VARIANTS = {
                                       ("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                            } else dmax", "} else dmax")]),
     "vpg_nt": ("u_20_8_50", [], [("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                        } else dmax", "__builtin_nontemporal_store(VN[l], (l == 0 ? vpp0 : vpp) + l * NZ);\n                        } else dmax"),
                                  ("(l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];\n                            } else dmax", "__builtin_nontemporal_store(VN[l], (l == 0 ? vpp0 : vpp) + l * NZ);\n                            } else dmax")]),
+    # round 5, the warm regime beyond the Infinity Cache (batch 262 144): the warm-start record stores / loads issued nontemporal too
+    # (results unchanged) -- beyond L3 nothing a launch stores is still cached when the next launch wants it
+    "ntst": ("u_12_4_10", [], [("                    if (P.store_mask & 2) P.slack[off] = VN[s];\n                    if (P.store_mask & 4) P.dual[off] = G[s];\n                    if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];",
+                                "                    if (P.store_mask & 2) __builtin_nontemporal_store(VN[s], P.slack + off);\n                    if (P.store_mask & 4) __builtin_nontemporal_store(G[s], P.dual + off);\n                    if ((P.store_mask & 8) && vp_touched) __builtin_nontemporal_store(VP[s], P.slack_prev + off);")]),
+    "ntld": ("u_12_4_10", [], [("                VN[s] = warm ? P.slack[off] : 0.0;\n                G[s] = warm ? P.dual[off] : 0.0;\n                VP[s] = warm ? P.slack_prev[off] : 0.0;",
+                                "                VN[s] = warm ? __builtin_nontemporal_load(P.slack + off) : 0.0;\n                G[s] = warm ? __builtin_nontemporal_load(P.dual + off) : 0.0;\n                VP[s] = warm ? __builtin_nontemporal_load(P.slack_prev + off) : 0.0;")]),
+    "ntboth": ("u_12_4_10", [], [("                    if (P.store_mask & 2) P.slack[off] = VN[s];\n                    if (P.store_mask & 4) P.dual[off] = G[s];\n                    if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];",
+                                  "                    if (P.store_mask & 2) __builtin_nontemporal_store(VN[s], P.slack + off);\n                    if (P.store_mask & 4) __builtin_nontemporal_store(G[s], P.dual + off);\n                    if ((P.store_mask & 8) && vp_touched) __builtin_nontemporal_store(VP[s], P.slack_prev + off);"),
+                                 ("                VN[s] = warm ? P.slack[off] : 0.0;\n                G[s] = warm ? P.dual[off] : 0.0;\n                VP[s] = warm ? P.slack_prev[off] : 0.0;",
+                                  "                VN[s] = warm ? __builtin_nontemporal_load(P.slack + off) : 0.0;\n                G[s] = warm ? __builtin_nontemporal_load(P.dual + off) : 0.0;\n                VP[s] = warm ? __builtin_nontemporal_load(P.slack_prev + off) : 0.0;")]),
     # timing-only ablations of the cone kernel (results are WRONG by construction)
     "abl_fwd_nogc": ("u_6_3_10", [], [("gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC];", "gr[(i + 2) % 3] = 0.0;"),
                                      ("                        gr[0] = sC[cw + PL_GC];\n                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];\n",

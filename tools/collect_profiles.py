@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def find(stage, pattern):
@@ -30,6 +30,10 @@ def pmc_per_launch(dirname, counter, kernel="admm_solve_kernel"):
 
 copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", "smoke.txt"),
           ("bench", "bench_driver_flags.json", "bench_driver_flags.json"), ("bench", "bench_default.json", "bench_default.json"),
+          ("bench", "bench_driver_flags_details.json", "bench_driver_flags_details.json"), ("bench", "bench_default_details.json", "bench_default_details.json"),
+          ("bench", "bench_per_step_details.json", "bench_per_step_details.json"), ("bench", "bench_driver_flags.time", "bench_driver_flags.time"),
+          ("hetero", "hetero_bench.txt", "hetero_bench.txt"), ("hetero", "dropin_latency.txt", "dropin_latency.txt"),
+          ("warm5", "warm_beyond_l3.md", "warm_beyond_l3.md"), ("warm5", "warm_traffic.json", "warm_traffic_beyond_l3.json"),
           ("bench", "bench_per_step.json", "bench_per_step.json"), ("bench", "bench_torchrun1.json", "bench_torchrun1.json"),
           ("sweep", "sweep_config5.json", "sweep_config5.json"),
           ("sweep", "sweep_config5.md", "sweep_config5.md"), ("sweep", "sweep_parity.md", "sweep_parity.md"), ("adaptive", "pytest_adaptive.txt", "pytest_adaptive.txt"),

@@ -13,6 +13,8 @@
 #   cfgtraffic   FETCH_SIZE / WRITE_SIZE per solve of every `configs` entry of the bench line -> profiles/traffic.json[configs]
 #   probes       warm-regime launch order table, cone iteration cost, half-row forms (round 4)
 #   probes4      config 4 in stretches (step_regroup) per K and stream count, the tile kernel's cone / half-space variants, the second-stream probe
+#   hetero       round 5: tools/hetero_bench.py (one-row HET variant + the tile kernel's per-instance form) and tools/dropin_latency.py
+#   warm5        round 5: the warm regime beyond the Infinity Cache (batch 262 144), times + FETCH_SIZE / WRITE_SIZE of those launches
 #   exp          whatever tools/gpu_experiment.sh holds (kernel experiments of the moment)
 set +e
 export TMPDIR=/tmp
@@ -29,9 +31,11 @@ for stage in "$@"; do
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharding.py tests/test_gpu_group.py tests/test_gpu_repack.py -m gpu -q > $O/pytest_gpu.txt 2>&1
       echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -6 $O/pytest_gpu.txt ;;
     bench)
-      timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; tail -c 1500 $O/bench_driver_flags.json; echo
-      timeout 600 python bench.py --no-cpu-baseline --no-configs --min-seconds 2 > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
-      timeout 300 python bench.py --steps-per-launch 1 --no-cpu-baseline --no-regimes --no-configs --min-seconds 2 > $O/bench_per_step.json 2> $O/bench_per_step.err
+      # (round 5: stdout is ONE compact line; the full record of each run goes to its own details file)
+      ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --details $R/$O/bench_driver_flags_details.json > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err ) 2> $O/bench_driver_flags.time
+      wc -c $O/bench_driver_flags.json; cat $O/bench_driver_flags.json; grep real $O/bench_driver_flags.time
+      timeout 600 python bench.py --no-cpu-baseline --no-configs --min-seconds 2 --details $R/$O/bench_default_details.json > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
+      timeout 300 python bench.py --steps-per-launch 1 --no-cpu-baseline --no-regimes --no-configs --min-seconds 2 --details $R/$O/bench_per_step_details.json > $O/bench_per_step.json 2> $O/bench_per_step.err
       TINYMPC_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-regimes --min-seconds 2 > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
       tail -c 300 $O/bench_torchrun1.json; echo ;;
     prof)
@@ -85,6 +89,18 @@ for stage in "$@"; do
       for st in 1 2; do timeout 300 python tools/regroup_bench.py --streams $st --cones input --ks 0,15,23,30,45,-1 > $O/regroup_input_s$st.md 2> $O/regroup_input_s$st.err; cat $O/regroup_input_s$st.md; done
       timeout 600 python tools/tile_variants_bench.py > $O/tile_variants_bench.md 2> $O/tile_variants_bench.err; cat $O/tile_variants_bench.md
       timeout 300 python tools/second_stream_probe.py > $O/second_stream_probe.md 2>&1 ;;
+    hetero)
+      # round 5: per-instance problem data on the one-row kernel and on the tile kernel's EXT form (wide / long shapes), single-solver drop-in latency
+      timeout 600 python tools/hetero_bench.py > $O/hetero_bench.txt 2> $O/hetero_bench.err; cat $O/hetero_bench.txt
+      timeout 300 python tools/dropin_latency.py > $O/dropin_latency.txt 2> $O/dropin_latency.err; cat $O/dropin_latency.txt ;;
+    warm5)
+      # round 5: the warm regime beyond the Infinity Cache (batch 262 144): time table + the PMC bytes of the very launches
+      BATCHES=65536,262144 QUICK=1 timeout 600 python tools/warm_order_probe.py 2>&1 | grep -v "per step us" > $O/warm_beyond_l3.md; cat $O/warm_beyond_l3.md
+      cd /tmp
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -o warm -- python $R/tools/warm_traffic.py > $R/$O/warm_traffic_$c.out 2> $R/$O/warm_traffic_$c.err
+      done
+      cd $R; python tools/warm_traffic.py --collect $O > $O/warm_traffic.json 2> $O/warm_traffic.err; cat $O/warm_traffic.json ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;

@@ -45,3 +45,43 @@ def episode(sol, label):
 episode(s, "heterogeneous families (HET variant)")
 s.close()
 episode(tm.TinyBatchSolver.from_problem(prob, B), "one shared family (plain variant)")
+
+
+# ---- round 5: wide and long shapes, the tile kernel's per-instance form (EXT bit 1) against the same shape's plain tile form
+def wide(dims, Bw):
+    wnx, wnu, wN = dims
+    fam, r2 = tm.random_problem(wnx, wnu, wN)
+    A0, B0 = np.asarray(fam["A"]), np.asarray(fam["B"])
+    Aw = A0[None] * (1 + r2.normal(0, 1e-3, (Bw, 1, 1)))
+    Bw_ = B0[None] * (1 + r2.normal(0, 0.05, (Bw, 1, 1)))
+    rho = r2.uniform(0.8, 1.2, Bw) * fam["rho"]
+    t0 = time.perf_counter()
+    het = tm.TinyBatchSolver.hetero(Aw, Bw_, None, np.tile(fam["Q"], (Bw, 1)), np.tile(fam["R"], (Bw, 1)), rho, wN)
+    t_set = time.perf_counter() - t0
+    hom = tm.TinyBatchSolver.from_problem(fam, Bw)
+    x0w = r2.uniform(-1, 1, (Bw, wnx))
+    out = []
+    for sol, label in ((het, "per-instance data"), (hom, "one shared family")):
+        sol.set_bound_constraints(np.full((wnx, 1), -1e17), np.full((wnx, 1), 1e17), np.full((wnu, 1), -0.5), np.full((wnu, 1), 0.5))
+        sol.update_settings(max_iter=500)
+        best = None
+        for _ in range(3):
+            sol.reset()
+            sol.set_x0(x0w)
+            sol.set_option("timing", 1)
+            sol.solve_async()
+            ms = float(np.sum(sol.timing_ms()))
+            best = ms if best is None else min(best, ms)
+        st = sol.reduce_stats()
+        out.append((label, sol.kernel_path(), best, st[0]))
+        sol.close()
+    flw = tm.flops_per_iter(wnx, wnu, wN)
+    print(f"({wnx},{wnu},{wN}) x {Bw}: setup of the families {t_set * 1e3:.0f} ms; " +
+          "; ".join(f"{lb} [{kp}]: {ms:.2f} ms, {it / ms * 1e3:.3e} ADMM it/s, FP64 {it * flw / (ms * 1e-3) / 78.6e12:.3f}" for lb, kp, ms, it in out))
+
+
+for dims, Bw in (((12, 8, 10), 65536), ((20, 8, 10), 32768), ((20, 4, 30), 16384), ((20, 8, 50), 8192)):
+    try:
+        wide(dims, Bw)
+    except Exception as e:                                # noqa: BLE001
+        print(dims, "failed:", repr(e))
