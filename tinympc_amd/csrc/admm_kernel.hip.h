@@ -100,7 +100,8 @@ struct SolveArgs {
     int* iter_log;            // optional [steps][batch]: per-MPC-step iteration count (negative: not converged), steps > 1
     double* u0_log;           // optional [steps][batch][nu]: the applied control u[:,0] of every fused MPC step
     double rho, tol_pri, tol_dua;
-    int batch, max_iter, check_termination;
+    int batch, max_iter, check_termination;   // max_iter: where THIS launch stops (a stage of a split solve: its cap) -- the last termination test
+                                              // before it is always a full one, so the residuals a launch leaves are those of its last check
     int steps;                // closed-loop MPC steps fused into this launch (>= 1; > 1 implies the plant step)
     // Reference-trajectory window (examples/quadrotor_tracking.cpp:65,89): when traj != nullptr the state
     // reference of MPC step k is traj[k + offset_b + 0 .. N-1][nx] (shared by all instances) instead of the
@@ -1438,6 +1439,10 @@ void admm_solve_kernel(const SolveArgs P) {
                             fold &= fold >> 1; fold &= fold >> 2; fold &= fold >> 4;
                             if constexpr (!HALF) fold &= fold >> 8;
                             const bool any_row = (fold & (HALF ? 0x0101010101010101ull : 0x0001000100010001ull)) != 0ull;
+                            // INVARIANT: rp / rd -- what d_resid reports and what repack_sort keys on -- are refreshed only by a
+                            // FULL test: a row passed the probe, or this is the last test the launch's iteration budget allows.  Every launch
+                            // and every stage of a split solve therefore ends on a full test BECAUSE its end is P.max_iter (the stage's cap);
+                            // a caller that stopped a launch any other way would read residuals of an earlier iteration.
                             const bool last_test = (P.max_iter - 1 - it) < P.check_termination;
                             if (last_test || any_row) {
                                 if constexpr (LAZY_RES) {

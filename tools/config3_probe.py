@@ -16,15 +16,18 @@ Xref = traj[k[:, None] + np.arange(N)[None, :]].transpose(0, 2, 1) + rng.normal(
 Uref = rng.normal(0, 0.05, (B, nu, N - 1))
 x0 = Xref[:, :, 0].copy()
 x0[:, :3] += rng.normal(0, 0.1, (B, 3))
-print("| grid waves/CU | repack_after | ms median (settled) | ms min | split K | verdict |")
-print("|---|---|---|---|---|---|")
-for g in (0, 4, 8, 16, 32):
+STAG = [int(v) for v in os.environ.get("STAGGER", "0").split(",")]
+GRIDS = [int(v) for v in os.environ.get("GRIDS", "0,4,8,16,32").split(",")]
+print("| grid waves/CU | stagger | repack_after | ms median (settled) | ms min | split K | verdict |")
+print("|---|---|---|---|---|---|---|")
+for g, stg in [(g, t) for g in GRIDS for t in STAG]:
     for ra in (0, -1):
         s = tm.TinyBatchSolver.from_problem(prob, B)
         s.set_bound_constraints(np.full((nx, 1), -5.0), np.full((nx, 1), 5.0), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
         s.update_settings(max_iter=100)
         s.set_x_ref(Xref); s.set_u_ref(Uref); s.set_x0(x0)
         s.set_option("grid_waves_per_cu", g)
+        s.set_option("stagger", stg)
         s.set_option("repack_after", ra)
         ms = []
         for _ in range(5 if ra == 0 else 14):
@@ -33,5 +36,5 @@ for g in (0, 4, 8, 16, 32):
             s.solve_async()
             ms.append(float(np.sum(s.timing_ms())))
         settled = ms[2:] if ra == 0 else ms[7:]
-        print(f"| {g} | {ra} | {np.median(settled):.4f} | {np.min(settled):.4f} | {s.get_option('auto_split_k')} | {s.get_option('auto_split_verdict')} |", flush=True)
+        print(f"| {g} | {stg} | {ra} | {np.median(settled):.4f} | {np.min(settled):.4f} | {s.get_option('auto_split_k')} | {s.get_option('auto_split_verdict')} |", flush=True)
         s.close()

@@ -15,6 +15,7 @@
 #   probes4      config 4 in stretches (step_regroup) per K and stream count, the tile kernel's cone / half-space variants, the second-stream probe
 #   hetero       round 5: tools/hetero_bench.py (one-row HET variant + the tile kernel's per-instance form) and tools/dropin_latency.py
 #   warm5        round 5: the warm regime beyond the Infinity Cache (batch 262 144), times + FETCH_SIZE / WRITE_SIZE of those launches
+#   fuzz         the four differential fuzzers against the oracle
 #   exp          whatever tools/gpu_experiment.sh holds (kernel experiments of the moment)
 set +e
 export TMPDIR=/tmp
@@ -52,7 +53,7 @@ for stage in "$@"; do
     configs)
       timeout 900 python tools/config_bench.py $O/configs_3_4.json > $O/configs.out 2> $O/configs.err; tail -c 800 $O/configs.out ;;
     sweep)
-      timeout 1500 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json  > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md; tail -3 $O/sweep_parity.md ;;
+      timeout 1500 python tools/sweep_bench.py --reps 8 --out $O/sweep_config5.json --parity $O/sweep_parity.md > $O/sweep_config5.md 2> $O/sweep.err; tail -40 $O/sweep_config5.md; tail -3 $O/sweep_parity.md ;;
     adaptive)
       timeout 600 python -m pytest tests/test_gpu_adaptive.py -m gpu -q > $O/pytest_adaptive.txt 2>&1; tail -5 $O/pytest_adaptive.txt
       timeout 300 python tools/adaptive_bench.py > $O/adaptive_bench_run.txt 2>&1; tail -2 $O/adaptive_bench_run.txt ;;
@@ -101,6 +102,12 @@ for stage in "$@"; do
         timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_$c -o warm -- python $R/tools/warm_traffic.py > $R/$O/warm_traffic_$c.out 2> $R/$O/warm_traffic_$c.err
       done
       cd $R; python tools/warm_traffic.py --collect $O > $O/warm_traffic.json 2> $O/warm_traffic.err; cat $O/warm_traffic.json ;;
+    fuzz)
+      # differential fuzzers against the oracle (new seeds every round); the closed-loop one draws the tile kernel's EXT forms since round 5
+      timeout 900 python tools/fuzz_parity.py 800 50000 > $O/fuzz_parity.txt 2>&1; tail -2 $O/fuzz_parity.txt
+      timeout 900 python tools/fuzz_closed_loop.py 400 51000 > $O/fuzz_closed_loop.txt 2>&1; tail -2 $O/fuzz_closed_loop.txt
+      timeout 600 python tools/fuzz_api_sequence.py 150 52000 > $O/fuzz_api_sequence.txt 2>&1; tail -2 $O/fuzz_api_sequence.txt
+      timeout 600 python tools/fuzz_parity.py 200 53000 phases > $O/fuzz_phases.txt 2>&1; tail -2 $O/fuzz_phases.txt ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
