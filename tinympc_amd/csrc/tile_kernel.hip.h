@@ -131,10 +131,13 @@ constexpr int tile_soc_waves(int nx, int nu, int n, int w, int r, int soc, bool 
 // examples/quadrotor_tracking.cpp:85-88), reset_duals (work->y = 0, work->g = 0 before every solve, :92-93), cold starts that
 // do not read the warm-start records and the store masks of one_shot; bit 1 = per-instance problem data (HET: the matrix rows
 // and rho of the instance's own cache, riccati_kernel.hip.h, in the tile table layout).  All arrays in registers (LM = 0).
+// (EXT forms hold all five arrays in registers AND re-load the matrix rows per instance: two waves per SIMD only with room to spare --
+// (20,8,10) at the box forms' threshold spilt 320 B per lane and ran at half the shared-family form's rate)
+constexpr int tile_ext_waves(int nx, int nu, int n, int r) { return 2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 240 ? 2 : 1; }
 template <int NX, int NU, int N, int W, int R, int SOC = 0, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false, int EXT = 0>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : tile_waves_per_simd(NX, NU, N, R, LM, W)),
-                                   LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : tile_waves_per_simd(NX, NU, N, R, LM, W)))))
+__attribute__((amdgpu_waves_per_eu(LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : (EXT ? tile_ext_waves(NX, NU, N, R) : tile_waves_per_simd(NX, NU, N, R, LM, W))),
+                                   LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : (EXT ? tile_ext_waves(NX, NU, N, R) : tile_waves_per_simd(NX, NU, N, R, LM, W))))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr bool HR = W == 0;                                        // half rows: two instances per DPP row (nx+nu <= 8)
