@@ -1,5 +1,5 @@
 """Option "step_regroup": a fused closed-loop launch of the one-row kernel cut into stretches of K MPC steps, each over the
-instances ordered by the iteration count of their last solve (SolveArgs::perm; batch_api.hip).  The four rows of a wave run in
+instances ordered by the iteration count of their last solve (SolveArgs::perm; batch_dispatch.hip).  The four rows of a wave run in
 lock step -- the order decides what a wave costs, never what an instance computes: every record, every per-step log entry and
 every statistic must be bit-identical to the uncut launch (and, through tests/test_gpu_fused_variants.py, to single-step
 launches and the oracle)."""

@@ -46,7 +46,7 @@ def one_row_shapes():
 
 def test_the_last_entry_can_serve_the_runtime_instantiated_variants():
     """Cone / half-space variants of a tile-only shape keep ALL their arrays in registers (9 L-long arrays with a cone, L = N / R) and
-    inherit R from the shape's LAST entry (batch_api.hip: variant_tile_r): that must be the most register-frugal split the shape has,
+    inherit R from the shape's LAST entry (batch_dispatch.hip: variant_tile_r): that must be the most register-frugal split the shape has,
     and never a half-row form (box constraints only)."""
     regs = one_row_shapes()
     for (nx, nu, N), forms in entries().items():

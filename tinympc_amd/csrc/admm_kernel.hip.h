@@ -122,7 +122,7 @@ struct SolveArgs {
     // bit 1 vnew|znew (= solution->x|u), bit 2 g|y, bit 3 v|z, bit 4 the cone / linear slack and dual records, bit 5 (without bit 0) only the first
     // knot of x|u.
     int cold, store_mask;
-    // Resumed solves (batch_api.hip "repack_after"): an earlier launch capped at iter_base iterations has stored the ADMM
+    // Resumed solves (batch_dispatch.hip "repack_after"): an earlier launch capped at iter_base iterations has stored the ADMM
     // state of the instances that did not converge; index[0 .. *count) lists them and this launch carries on from
     // iteration iter_base with four of them per wave again.  The cone / half-space slacks are then read from their own records
     // instead of being initialised from x (admm.cpp:352-374 runs once per solve).  index == nullptr: a plain launch.
@@ -153,11 +153,11 @@ struct SolveArgs {
     // Instances are independent: the order changes nothing in the results.
     int reverse;
     // one-row kernel, plain launches: slot s of the grid solves instance perm[s] (null: instance s).  A fused closed-loop launch that
-    // is cut into stretches of MPC steps (batch_api.hip "step_regroup") hands every stretch the instances ordered by the iteration
+    // is cut into stretches of MPC steps (batch_dispatch.hip "step_regroup") hands every stretch the instances ordered by the iteration
     // count of their last solve: the four rows of a wave run in lock step, so a wave costs what its slowest row costs, and rows
     // that took alike counts at the last step take alike counts at the next ones.  Same reason as above: nothing in the results.
     const int* perm;
-    int perm_count;           // slots of `perm` (a launch may take a part of the batch: batch_api.hip runs two halves on two streams)
+    int perm_count;           // slots of `perm` (a launch may take a part of the batch: batch_dispatch.hip runs two halves on two streams)
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -1604,7 +1604,7 @@ void admm_solve_kernel(const SolveArgs P) {
                 }
                 acc_iter += (unsigned)(iter - iter0);
                 acc_solved += (unsigned)solved;
-                // (the logs of a single-step launch: a stretch of a fused launch that batch_api.hip cut up, "step_regroup")
+                // (the logs of a single-step launch: a stretch of a fused launch that batch_dispatch.hip cut up, "step_regroup")
                 if (P.iter_log && j == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
                 if (P.u0_log && is_input) P.u0_log[((size_t)step * P.batch + b) * NU + (j - NX)] = X[1];
                 if (nsteps > 1) {

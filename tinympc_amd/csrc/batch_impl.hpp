@@ -1,4 +1,4 @@
-// batch_impl.hpp -- the opaque TinyBatch behind include/tinympc_amd.h (shared by batch_api.hip and
+// batch_impl.hpp -- the opaque TinyBatch behind include/tinympc_amd.h (shared by batch_api.hip, batch_dispatch.hip and
 // compat_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,7 +35,7 @@ struct TinyBatch {
     bool tile_is_jit = false, tile_soc_failed = false;
     bool redispatch = false;                     // launch_solve re-entered by itself after a failed instantiation (not a caller-side change)
     bool no_jit = false, jit_failed = false, variant_jit_failed = false;     // run-time instantiation of the one-row kernel for shapes outside kernel_dims.txt (jit.hpp)
-    int tile_verdict = 0, tile_since = 0;        // the dynamic tile form tried on a one-row shape: 1 kept, -1 rejected, 0 open (batch_api.hip launch_solve)
+    int tile_verdict = 0, tile_since = 0;        // the dynamic tile form tried on a one-row shape: 1 kept, -1 rejected, 0 open (batch_dispatch.hip launch_solve)
     double tile_rate = 0.0;
     bool probe_was_tile = false;
     int tile_w = -1;                             // option "tile_w"

@@ -51,7 +51,7 @@ enum : int {
     PHASE_TERMINATION = 6,   // termination_condition  admm.cpp:310-328 (the residual part; status.y = the returned bool)
 };
 
-#ifdef TINYMPC_GENERAL_KERNEL_IMPL   // the kernel body is compiled into batch_api.hip only
+#ifdef TINYMPC_GENERAL_KERNEL_IMPL   // the kernel body is compiled into batch_dispatch.hip only
 
 __device__ __forceinline__ double wave_max64(double v) {
 #pragma unroll

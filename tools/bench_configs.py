@@ -187,7 +187,7 @@ def config4(B=65536, device=0, en_state_soc=0, en_input_soc=1, name="config4"):
     regroup = dict(verdict=s.get_option("step_regroup_verdict"), launches_per_episode=s.get_option("step_regroup_stretches"),
                    lockstep_estimate=s.get_option("lockstep_permille") / 1000.0,
                    note="verdict 1: the 90-step launch runs as stretches of MPC steps over the instances ordered by their last iteration count "
-                        "(batch_api.hip step_regroup; bit-identical to the uncut launch); lockstep_estimate = rows x the largest "
+                        "(batch_dispatch.hip step_regroup; bit-identical to the uncut launch); lockstep_estimate = rows x the largest "
                         "iteration total of every wave / the totals, from the uncut episode")
     S = nx * N + nu * (N - 1)
     cones = "input second-order cone on" if (en_input_soc and not en_state_soc) else ("state second-order cone on" if not en_input_soc else "state AND input second-order cones on")
