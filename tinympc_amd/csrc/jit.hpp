@@ -44,7 +44,8 @@ inline bool jit_tile_shape(int nx, int nu, int N, int* W, int* R) {
 // soc: the tile kernel's SOC template value -- bit 0 the input family's cone slack is on, bit 1 the state family's
 // ub: the UB form (the box is the same at every knot: a lane's bounds in registers) -- static form only
 // ext: the tile kernel's EXT template value -- bit 0 reference window / reset_duals / cold start / store masks, bit 1 per-instance problem data
-hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn = false, bool ub = false, int ext = 0);
+// lm (ext == 2 only): the TILE_LM_* set of the box form the per-instance data rides on
+hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn = false, bool ub = false, int ext = 0, int lm = 0);
 
 // Compile one instantiation ("tinympc_amd::admm_solve_kernel<...>" / "tinympc_amd::admm_tile_kernel<...>") without loading
 // it -- needs no GPU.  With TINYMPC_AMD_JIT_CACHE=<directory> set the code object is looked up / kept there (one file per

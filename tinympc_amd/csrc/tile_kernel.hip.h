@@ -133,16 +133,22 @@ constexpr int tile_soc_waves(int nx, int nu, int n, int w, int r, int soc, bool 
 // and rho of the instance's own cache, riccati_kernel.hip.h, in the tile table layout).  All arrays in registers (LM = 0).
 // (EXT forms hold all five arrays in registers AND re-load the matrix rows per instance: two waves per SIMD only with room to spare --
 // (20,8,10) at the box forms' threshold spilt 320 B per lane and ran at half the shared-family form's rate)
-constexpr int tile_ext_waves(int nx, int nu, int n, int r) { return 2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 240 ? 2 : 1; }
+constexpr int tile_ext_waves(int nx, int nu, int n, int r, int lm = 0, int w = 1) {
+    return lm != 0 ? tile_waves_per_simd(nx, nu, n, r, lm, w) : (2 * (5 * (n / r) + 2 * (nx + nu)) + 44 <= 240 ? 2 : 1);
+}
 template <int NX, int NU, int N, int W, int R, int SOC = 0, int LIN = 0, int KMAX = LIN_KMAX, bool UB = false, int LM = 0, bool DYN = false, int EXT = 0>
 __global__ __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : (EXT ? tile_ext_waves(NX, NU, N, R) : tile_waves_per_simd(NX, NU, N, R, LM, W))),
-                                   LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : (EXT ? tile_ext_waves(NX, NU, N, R) : tile_waves_per_simd(NX, NU, N, R, LM, W))))))
+__attribute__((amdgpu_waves_per_eu(LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : (EXT ? tile_ext_waves(NX, NU, N, R, LM, W) : tile_waves_per_simd(NX, NU, N, R, LM, W))),
+                                   LIN ? 1 : (SOC ? tile_soc_waves(NX, NU, N, W == 0 ? 1 : W, R, SOC, UB) : (EXT ? tile_ext_waves(NX, NU, N, R, LM, W) : tile_waves_per_simd(NX, NU, N, R, LM, W))))))
 void admm_tile_kernel(const SolveArgs P) {
     constexpr bool LS = (LIN & 1) != 0, LT = (LIN & 2) != 0;
     constexpr bool HR = W == 0;                                        // half rows: two instances per DPP row (nx+nu <= 8)
     constexpr bool EXTF = (EXT & 1) != 0, HETX = (EXT & 2) != 0;
-    static_assert(EXT == 0 || (LM == 0 && !DYN && W >= 1), "EXT forms: all arrays in registers, static tiles");
+    // bit 0 forms: all arrays in registers, static tiles.  Per-instance data ALONE (EXT == 2) rides on any box form of the shape -- its
+    // LDS-offload set, the trajectory regenerated, v|z in its record, dynamic slots: the instance's matrix rows are just other values
+    // in the same registers -- so that a heterogeneous batch runs the form the sweep measured fastest for the shape
+    static_assert(EXT == 0 || W >= 1, "EXT forms: whole DPP rows");
+    static_assert(!EXTF || (LM == 0 && !DYN), "EXT bit 0 forms: all arrays in registers, static tiles");
     constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
     constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
@@ -335,7 +341,8 @@ void admm_tile_kernel(const SolveArgs P) {
 #pragma unroll
             for (int k = 0; k < NX; ++k) pt[k] = tp[T::PT + k * LW + jj];
             const double xp = tile_matvec<W, 0, NX>(0.0, ref_last, pt);
-            if (hrow == R - 1 && is_state) QX[L - 1] = -xp;
+            if constexpr (QR) qx_term = -xp;
+            else if (hrow == R - 1 && is_state) { if constexpr (QL) sQ[(L - 1) * SLOT + li] = -xp; else QX[L - 1] = -xp; }
         }
     };
     // EXT bit 0, at the start of every solve (MPC step `step` of this launch): the reference window and the dual reset

@@ -178,8 +178,7 @@ def config4(B=65536, device=0, en_state_soc=0, en_input_soc=1, name="config4"):
     s.set_option("step_regroup", 0)
     plain = [episode(0) for _ in range(3)][1:]
     s.set_option("step_regroup", -1)
-    for _ in range(2):
-        episode(0)
+    unsettled = [episode(0) for _ in range(2)]         # (the first of them is still ONE launch: it is what tells the library what lock step costs)
     ms, st = [], None
     for _ in range(5):
         ms.append(episode(0))
@@ -198,6 +197,8 @@ def config4(B=65536, device=0, en_state_soc=0, en_input_soc=1, name="config4"):
                launch_form="the library's default dispatch (automatic step_regroup), episodes 6-10 of 11 (1-3: the uncut launch, option off)",
                note="flops_per_iter counts the box iteration only (the cone projection's sqrt / divisions are extra work, not extra credit); "
                     "bytes: bytes_warm + the cone slack records, once per LAUNCH (S = %d)" % S)
+    e["first_call_ms"] = float(unsettled[0])           # what the default dispatch's FIRST episode costs (before it knows the batch)
+    e["unsettled_ms"] = [float(v) for v in unsettled]
     e["hbm"]["gbs"] /= steps                           # the records move once per launch, not once per fused step
     e["hbm"]["frac_formula"] /= steps
     episode(1)                                         # untimed: the same episode once more with the per-step log on, for the checker
@@ -238,6 +239,8 @@ def sweep_cell(nx, nu, N, B=131072, device=0):
     e = _entry(name, "random sweep cell (nx=%d, nu=%d, N=%d) x %d, one cold solve, max_iter 500 (BASELINE configs[4])" % (nx, nu, N, B),
                settled, B, st[0], nx, nu, N, s.algorithmic_bytes(), s.kernel_path(), solved_fraction=st[1] / B, solves_launched=len(ms) * B,
                automatic_split_k=s.get_option("auto_split_k"), tile_alt_verdict=s.get_option("tile_alt_verdict"))
+    e["first_call_ms"] = float(ms[0])                  # a caller's first solve of the batch (one-row shapes: the first of the probe solves)
+    e["unsettled_ms"] = [float(v) for v in (ms[:1] if tile else ms[:6])]
     idx = _sample_idx(B)
     stt = s.status()
     it = np.where(stt["solved"][idx] != 0, stt["iter"][idx], -stt["iter"][idx])

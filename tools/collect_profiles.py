@@ -32,8 +32,6 @@ copies = [("tests", "pytest_gpu.txt", "pytest_gpu.txt"), ("tests", "smoke.txt", 
           ("bench", "bench_driver_flags.json", "bench_driver_flags.json"), ("bench", "bench_default.json", "bench_default.json"),
           ("bench", "bench_driver_flags_details.json", "bench_driver_flags_details.json"), ("bench", "bench_default_details.json", "bench_default_details.json"),
           ("bench", "bench_per_step_details.json", "bench_per_step_details.json"), ("bench", "bench_driver_flags.time", "bench_driver_flags.time"),
-          ("fuzz", "fuzz_parity.txt", "fuzz_parity.txt"), ("fuzz", "fuzz_closed_loop.txt", "fuzz_closed_loop.txt"),
-          ("fuzz", "fuzz_api_sequence.txt", "fuzz_api_sequence.txt"), ("fuzz", "fuzz_phases.txt", "fuzz_phases.txt"),
           ("hetero", "hetero_bench.txt", "hetero_bench.txt"), ("hetero", "dropin_latency.txt", "dropin_latency.txt"),
           ("warm5", "warm_beyond_l3.md", "warm_beyond_l3.md"), ("warm5", "warm_traffic.json", "warm_traffic_beyond_l3.json"),
           ("bench", "bench_per_step.json", "bench_per_step.json"), ("bench", "bench_torchrun1.json", "bench_torchrun1.json"),
