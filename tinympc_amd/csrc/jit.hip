@@ -242,11 +242,11 @@ hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
 
 hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int lin, int kmax, std::string* err, bool dyn, bool ub, int ext, int lm) {
     char name[256];
-    // (ext: the EXT forms -- reference window / reset_duals / cold starts / store masks: static tiles, LM = 0; per-instance problem data
-    // alone (ext == 2): on the LDS-offload set `lm` of the shape's box form, static or dynamic)
+    // (ext: the EXT forms -- reference window / reset_duals / cold starts / store masks, per-instance problem data -- on the
+    // LDS-offload set `lm` of a box form of the shape, static or dynamic; lm = 0, dyn = false: the all-in-registers form)
     if (ext) {
         snprintf(name, sizeof(name), "tinympc_amd::admm_tile_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s, %d, %s, %d>", nx, nu, N, W, R, soc, lin, kmax, ub ? "true" : "false",
-                 ext == 2 ? lm : 0, (ext == 2 && dyn) ? "true" : "false", ext);
+                 lm, dyn ? "true" : "false", ext);
         return get(name, true, err);
     }
     // (dyn: the dynamic slot form -- persistent grid, slots draw instances from SolveArgs::work_counter; plain variants only)

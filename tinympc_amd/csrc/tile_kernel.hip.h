@@ -148,7 +148,9 @@ void admm_tile_kernel(const SolveArgs P) {
     // LDS-offload set, the trajectory regenerated, v|z in its record, dynamic slots: the instance's matrix rows are just other values
     // in the same registers -- so that a heterogeneous batch runs the form the sweep measured fastest for the shape
     static_assert(EXT == 0 || W >= 1, "EXT forms: whole DPP rows");
-    static_assert(!EXTF || (LM == 0 && !DYN), "EXT bit 0 forms: all arrays in registers, static tiles");
+    // Bit 0 too, as long as QX is writable (not re-read from the reference record): the window goes into the QX array wherever it lives.
+    // (The host keeps one_shot launches on the LM = 0 forms: a form that streams v|z would write a record one_shot promises not to touch.)
+    static_assert(!EXTF || (LM & TILE_LM_QXR) == 0, "a reference window needs a QX array of its own");
     constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
     constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
@@ -356,11 +358,12 @@ void admm_tile_kernel(const SolveArgs P) {
                         int kk = k0 + l;
                         kk = kk < P.traj_points ? kk : P.traj_points - 1;
                         const double r = P.traj[(size_t)kk * NX + jj];
-                        QX[l] = -(r * qr);                              // admm.cpp:266 / :279
+                        if constexpr (QL) sQ[l * SLOT + li] = -(r * qr); else QX[l] = -(r * qr);      // admm.cpp:266 / :279
                         if (l == L - 1) ref_last = r;
                     }
                 }
                 terminal_term();
+                if constexpr (QL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (each lane reads back its own entries)
             }
             if (P.reset_duals) {                                        // work->y = 0; work->g = 0
 #pragma unroll
@@ -826,7 +829,7 @@ void admm_tile_kernel(const SolveArgs P) {
                                     const bool valid = is_state || (is_input && g >= 1);
                                     const size_t off = ((size_t)b * N + (is_state ? g : g - 1)) * NZ + jj;
                                     const double xi = xcur;
-                                    if (valid) P.prim[off] = xi;
+                                    if (valid && (!EXTF || (P.store_mask & 1) || ((P.store_mask & 32) && g <= 1))) P.prim[off] = xi;
                                     if (g < N - 1) {
                                         double xn, dnl;
                                         if constexpr (DL) dnl = sD[l * SLOT + li]; else dnl = Dn[l];

@@ -85,3 +85,43 @@ for dims, Bw in (((12, 8, 10), 65536), ((20, 8, 10), 32768), ((20, 4, 30), 16384
         wide(dims, Bw)
     except Exception as e:                                # noqa: BLE001
         print(dims, "failed:", repr(e))
+
+
+# ---- round 5: tracking-style fused episodes (reference window + reset_duals, examples/quadrotor_tracking.cpp:77-106) on wide / long
+# shapes -- the tile kernel's EXT bit-0 form on the shape's fast box form -- against the same fused episode without a window
+def tracking(dims, Bw, T=10):
+    wnx, wnu, wN = dims
+    fam, r2 = tm.random_problem(wnx, wnu, wN)
+    x0w = r2.uniform(-1, 1, (Bw, wnx))
+    traj = r2.normal(0, 0.2, (wN + T + 2, wnx))
+    out = []
+    for windowed in (False, True):
+        sol = tm.TinyBatchSolver.from_problem(fam, Bw)
+        sol.set_bound_constraints(np.full((wnx, 1), -1e17), np.full((wnx, 1), 1e17), np.full((wnu, 1), -0.5), np.full((wnu, 1), 0.5))
+        sol.update_settings(max_iter=100)
+        sol.set_option("advance_x0", 1)
+        sol.set_option("steps_per_launch", T)
+        if windowed:
+            sol.set_reference_trajectory(traj)
+            sol.set_option("reset_duals", 1)
+        best = None
+        for _ in range(3):
+            sol.reset()
+            sol.set_x0(x0w)
+            if windowed:
+                sol.set_option("traj_step", 0)
+            sol.set_option("timing", 1)
+            sol.solve_async()
+            ms = float(np.sum(sol.timing_ms()))
+            best = ms if best is None else min(best, ms)
+        st = sol.reduce_stats()
+        out.append((("window + reset_duals" if windowed else "fixed reference"), sol.kernel_path(), best, st[7]))
+        sol.close()
+    print(f"({wnx},{wnu},{wN}) x {Bw}, {T} fused MPC steps: " + "; ".join(f"{lb} [{kp}]: {ms:.2f} ms, {it / ms * 1e3:.3e} ADMM it/s" for lb, kp, ms, it in out))
+
+
+for dims, Bw in (((20, 8, 10), 32768), ((12, 8, 30), 16384), ((20, 8, 50), 8192)):
+    try:
+        tracking(dims, Bw)
+    except Exception as e:                                # noqa: BLE001
+        print(dims, "tracking failed:", repr(e))
