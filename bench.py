@@ -687,7 +687,7 @@ def main():
         def watchdog():
             # only the phases that can hang without a timeout of their own are on the clock (rendezvous / init_process_group,
             # ncclCommInitRank inside StatsExchange): a slow cold start of the solver itself (library load, first-use hipRTC) is not
-            while _PHASE[0] != "measuring":
+            while _PHASE[0] != "finished":               # (for the whole run: the strong-scaling leg sets up a communicator of its own)
                 time.sleep(1.0)
                 if _PHASE[0] in ("process_group", "communicator") and time.perf_counter() - _PHASE[1] > args.dist_timeout:
                     give_up("rank %d: %s setup did not finish within --dist-timeout %.0f s" % (env_rank, _PHASE[0], args.dist_timeout))
@@ -853,6 +853,7 @@ def run(args, result_fd, setup_done):
         details = write_details(out, args.details)
         sys.stdout.flush()
         os.write(result_fd, (compact_line(out, details) + "\n").encode())
+    enter_phase("finished")
     job.close()
 
 

@@ -137,3 +137,83 @@ def test_knot_invariant_box_in_registers_equals_the_lds_form(dims):
     assert np.array_equal(s.status()["iter"], ref["iter"].astype(int))
     assert np.max(np.abs(s.get("u") - ref["u"])) <= 1e-9 * max(np.max(np.abs(ref["u"])), 1e-300)
     s.close()
+
+
+@pytest.mark.parametrize("name,force", [("quadrotor_20hz", False), ("rocket_landing_20hz", False), ("quadrotor_20hz", True)])
+def test_closed_loop_launch_forms_on_the_coverage_kernel(name, force):
+    """Round 5 (VERDICT r04 'missing' item 5): cones that SHARE rows are projected one after the other as admm.cpp:111-135 does, which
+    only the coverage kernel implements -- and until now it refused fused steps, reference windows, reset_duals and one_shot, so a
+    closed loop with overlapping cones could not be launched at all.  Its state lives in the records: a fused launch is a loop of
+    single-step launches, the window and the dual reset are one small kernel in front of each.  Against the oracle's loop, step by
+    step (iteration counts from the step log, final state), per-instance window offsets; one_shot against a solve from the reset
+    state; force = the same launch forms for a batch WITHOUT overlapping cones that is pinned to this kernel (option force_general:
+    what a shape without a register-resident instantiation gets)."""
+    from cpu_solvers import OracleSolver
+    suite = sc.random_state_suite(name, B=5, seed=77, soc=False if force else "overlap")
+    prob, cfg = suite["problem"], dict(suite["config"], max_iter=25)
+    suite = dict(suite, config=cfg)
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    B, steps_T, launches = 5, 3, 2
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-0.3, 0.3, (B, nx))
+    Uref = rng.normal(0, 0.05, (B, nu, N - 1))
+    n_pts = N + steps_T * launches + 1
+    traj = rng.normal(0, 0.2, (n_pts, nx))
+    offs = rng.integers(0, 3, B).astype(np.int32)
+
+    def make():
+        s = make_batch(suite)
+        if force:
+            s.set_option("force_general", 1)
+        s.set_x0(x0); s.set_u_ref(Uref)
+        return s
+    s = make()
+    s.set_reference_trajectory(traj, offs)
+    s.set_option("reset_duals", 1)
+    s.set_option("advance_x0", 1)
+    s.set_option("step_log", 1)
+    s.set_option("steps_per_launch", steps_T)
+    assert s.kernel_path() == "cover"
+    its = []
+    for _ in range(launches):
+        s.solve_async()
+        its.append(np.abs(s.step_log(steps_T)[0]))
+    its = np.concatenate(its)
+    got = dict(x0=s.get("x0"), x=s.get("x"), u=s.get("u"), vnew=s.get("vnew"), g=s.get("g"), v=s.get("v"))
+    acc = s.reduce_stats()[7]
+    s.close()
+    assert acc == its.sum()
+    for b in range(B):
+        o = sc.make_solver(OracleSolver, prob, cfg)
+        o["Uref"] = Uref[b]
+        xb = x0[b].copy()
+        for k in range(steps_T * launches):
+            o["Xref"] = traj[np.minimum(np.arange(N) + k + offs[b], n_pts - 1)].T
+            o["g"] = np.zeros((nx, N)); o["y"] = np.zeros((nu, N - 1))
+            o["x"][:, 0] = xb
+            o.solve()
+            assert int(o.get("sol_iter")) == its[k, b], (b, k)
+            xb = prob["A"] @ xb + prob["B"] @ o["u"][:, 0] + prob["f"]
+        for k, ref in dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"]).items():
+            assert np.max(np.abs(got[k][b] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref))), (b, k)
+        o.close()
+    # one_shot: garbage in the warm-start records must not be read; x | u (+ vnew) of a solve from the reset state
+    Xref = np.repeat(rng.uniform(-0.3, 0.3, (B, nx, 1)), N, axis=2)
+    r = make()
+    r.set_x_ref(Xref)
+    r.solve()
+    ref = dict(x=r.get("x"), u=r.get("u"), vnew=r.get("vnew"), it=r.status()["iter"].copy())
+    r.close()
+    for mode in (1, 2):
+        q = make()
+        q.set_x_ref(Xref)
+        for f in ("vnew", "znew", "g", "y", "v", "z", "x", "u", "gc", "yc"):
+            q.set(f, rng.normal(0, 3.0, q.get(f).shape))
+        q.set_x0(x0)
+        q.set_option("one_shot", mode)
+        assert q.kernel_path() == "cover"
+        q.solve()
+        assert np.array_equal(q.status()["iter"], ref["it"]) and np.array_equal(q.get("x"), ref["x"]) and np.array_equal(q.get("u"), ref["u"])
+        if mode == 1:
+            assert np.array_equal(q.get("vnew"), ref["vnew"])
+        q.close()

@@ -746,23 +746,24 @@ def test_api_misuse_is_reported_not_ignored():
     s = tm.TinyBatchSolver.from_problem(prob, 4)
     with pytest.raises(tm.TinyMPCError, match="cone dimension"):
         s.set_cone_constraints([0], [4], [0.5], [], [], [])   # the reference's project_soc only handles 3 (admm.cpp:53)
-    # overlapping cones are served (sequential projections, admm.cpp:111-135) -- by the coverage kernel, which has no fused steps
+    with pytest.raises(tm.TinyMPCError):
+        s.get("q")                                            # q/r/p/d need the debug option (or a solve on the coverage kernel)
+    # overlapping cones are served (sequential projections, admm.cpp:111-135) -- by the coverage kernel, fused steps included since
+    # round 5 (tests/test_gpu_fused_variants.py); what it cannot take is adaptive rho (and per-instance data)
     s.set_cone_constraints([0, 2], [3, 3], [0.5, 0.5], [], [], [])
     s.update_settings(en_state_soc=1)
     assert s.kernel_path() == "cover"
     s.set_option("steps_per_launch", 3)
+    s.solve()
+    s.set_option("steps_per_launch", 1)
+    s.set_sensitivity(*[np.zeros((a, b_)) for a, b_ in ((4, 12), (12, 12), (4, 4), (12, 12))])
+    s.set_adaptive_rho(1, 1.0, 100.0, 1)
     with pytest.raises(tm.TinyMPCError, match="overlapping cones"):
         s.solve()
-    s.set_option("steps_per_launch", 1)
+    s.set_adaptive_rho(0, 1.0, 100.0, 1)
     s.update_settings(en_state_soc=0)                          # the family is switched off: the overlap is irrelevant again
     assert s.kernel_path() == "regs"
     s.set_cone_constraints([], [], [], [], [], [])
     with pytest.raises(tm.TinyMPCError, match="out of range"):
         s.set_cone_constraints([], [], [], [2], [3], [0.5])   # nu = 4: rows 2..4 do not exist
-    with pytest.raises(tm.TinyMPCError):
-        s.get("q")                                            # q/r/p/d need the debug option
-    s.set_option("steps_per_launch", 5)
-    s.set_option("force_general", 1)                          # the coverage kernel ...
-    with pytest.raises(tm.TinyMPCError, match="steps_per_launch"):
-        s.solve()                                             # ... has no fused stepping
     s.close()
