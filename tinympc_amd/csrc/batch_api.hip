@@ -737,6 +737,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "no_tile")) { b->no_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "prefer_tile")) { b->prefer_tile = value != 0; b->tab_dirty = true; }
     else if (!strcmp(name, "tile_dyn")) b->tile_dyn_opt = (int)value;   // -1 (default): by batch size; 0: static tiles; 1: the dynamic form whenever it exists
+    else if (!strcmp(name, "het_ub")) b->het_ub = value != 0;
     else if (!strcmp(name, "tile_w")) b->tile_w = (int)value;      // experiments: only entries with this W (0 = half rows, -1 = any)
     else if (!strcmp(name, "tile_lm")) b->tile_lm = (int)value;    // experiments: the tile_dims.txt entry with this LM column
     else if (!strcmp(name, "tile_r")) b->tile_r = (int)value;      // experiments: the tile_dims.txt entry with this R (0: the first that fits)

@@ -41,6 +41,7 @@ struct TinyBatch {
     int tile_w = -1;                             // option "tile_w"
     int tile_lm = -1;                            // option "tile_lm"
     int tile_dyn_opt = -1;                       // option "tile_dyn"
+    bool het_ub = true;                          // option "het_ub": the per-instance-data variant's UB form (run-time instantiated) where the box allows it
     bool last_tile_dyn = false;
     int last_tile_form = -1;                     // W * 1e6 + R * 1e3 + LM of the entry the last tile launch took
     int* d_work_counter = nullptr;               // the dynamic tile form's device-wide instance counter

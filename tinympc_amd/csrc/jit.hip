@@ -235,8 +235,8 @@ int jit_used_names(std::string* out) {
 
 hipFunction_t jit_solve_kernel(const JitKey& k, std::string* err) {
     char name[256];
-    snprintf(name, sizeof(name), "tinympc_amd::admm_solve_kernel<%d, %d, %d, %s, %s, %d, %d, %s, %d, %s>", k.nx, k.nu, k.N,
-             k.soc ? "true" : "false", k.dbg ? "true" : "false", k.mode, k.lin, k.het ? "true" : "false", k.kmax, k.adapt ? "true" : "false");
+    snprintf(name, sizeof(name), "tinympc_amd::admm_solve_kernel<%d, %d, %d, %s, %s, %d, %d, %s, %d, %s%s>", k.nx, k.nu, k.N,
+             k.soc ? "true" : "false", k.dbg ? "true" : "false", k.mode, k.lin, k.het ? "true" : "false", k.kmax, k.adapt ? "true" : "false", k.ub ? ", true" : "");
     return get(name, false, err);
 }
 

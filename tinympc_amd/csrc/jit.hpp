@@ -11,9 +11,10 @@ namespace tinympc_amd {
 
 struct JitKey {
     int nx, nu, N, soc, dbg, mode, lin, het, kmax, adapt;
+    int ub = 0;               // the knot-invariant-bounds form (round 5: for the per-instance-data variant, which is only compiled in without it)
     bool operator<(const JitKey& o) const {
-        const int a[10] = {nx, nu, N, soc, dbg, mode, lin, het, kmax, adapt}, b[10] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het, o.kmax, o.adapt};
-        for (int i = 0; i < 10; ++i)
+        const int a[11] = {nx, nu, N, soc, dbg, mode, lin, het, kmax, adapt, ub}, b[11] = {o.nx, o.nu, o.N, o.soc, o.dbg, o.mode, o.lin, o.het, o.kmax, o.adapt, o.ub};
+        for (int i = 0; i < 11; ++i)
             if (a[i] != b[i]) return a[i] < b[i];
         return false;
     }

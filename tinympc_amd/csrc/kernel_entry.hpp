@@ -9,6 +9,7 @@ struct KernelEntry {
     SolveKernel k[2][2][3];   // [soc][dbg][dpp_mode]
     SolveKernel klin[2][4];   // [soc][LIN 1..3]: register-resident linear constraints (dpp_mode 2, no debug outputs)
     SolveKernel khet[2];      // [soc]: per-instance problem data (dpp_mode 2, no debug outputs)
+    SolveKernel khetub[2];    // [soc]: the same with the knot-invariant box in registers (round 5: +4 % on the hover episode); nullptr: instantiated at run time
     SolveKernel kadapt[2];    // [dbg]: adaptive rho (dpp_mode 2, no cone)
     SolveKernel kub;          // knot-invariant box in registers (plain variant, dpp_mode 2)
     SolveKernel kubsoc;       // the same for the cone variant (its slack lives in LDS since round 4: the two bound registers fit)
@@ -40,6 +41,8 @@ struct TileEntry {
       { KERNELS_LIN(NX, NU, NN, false), KERNELS_LIN(NX, NU, NN, true) },                                    \
       { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, true>,                               \
         tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, true> },                              \
+      { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, true, tinympc_amd::LIN_KMAX, false, true>, \
+        tinympc_amd::admm_solve_kernel<NX, NU, NN, true, false, 2, 0, true, tinympc_amd::LIN_KMAX, false, true> }, \
       { tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, true>, \
         tinympc_amd::admm_solve_kernel<NX, NU, NN, false, true, 2, 0, false, tinympc_amd::LIN_KMAX, true> },  \
       tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>,         \
@@ -52,6 +55,6 @@ struct TileEntry {
     { NX, NU, NN, { { { nullptr, nullptr, tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2> }, { nullptr, nullptr, nullptr } },   \
                     { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } } },                       \
       { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } },                     \
-      { nullptr, nullptr }, { nullptr, nullptr },                                                             \
+      { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr },                                       \
       tinympc_amd::admm_solve_kernel<NX, NU, NN, false, false, 2, 0, false, tinympc_amd::LIN_KMAX, false, true>, nullptr,  \
       { tinympc_amd::half_kernel_or_null<NX, NU, NN, false>(), tinympc_amd::half_kernel_or_null<NX, NU, NN, true>() } }
