@@ -99,7 +99,9 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
 /* Heterogeneous batch: instance i has its OWN (A_i, B_i, f_i, Q_i, R_i, rho_i) -- arrays with a leading batch
  * axis ([batch][nx*nx] column-major, [batch][nx*nu], [batch][nx] (may be NULL), [batch][nx], [batch][nu], [batch]).
  * tiny_precompute_and_set_cache (tiny_api.cpp:307-381) runs on the GPU for all instances at once; the solve kernel
- * then streams each instance's own cache.  Bounds, cones and settings stay shared.  nx + nu <= 16, registered N. */
+ * then streams each instance's own cache.  Bounds, cones and settings stay shared.  Any nx + nu <= 32, nu <= 16 (round 5): shapes the
+ * one-row kernel holds run its HET variant, wide and long shapes the tile kernel's per-instance form on the shape's fastest box form
+ * (run-time instantiated: needs hipRTC); TINY_ERR_UNSUPPORTED when neither kernel holds the shape. */
 int tiny_batch_setup_hetero(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn,
                             const double* Qdiag, const double* Rdiag, const double* rho,
                             int nx, int nu, int N, int batch, int device, int verbose);
@@ -208,7 +210,10 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * "one_shot" (one-shot / cold solves: the warm-start state is taken as zero -- the state after tiny_setup or
  * tiny_batch_reset -- WITHOUT being read, and only the results are written: 1 = x|u and vnew|znew (solution->x|u),
  * 2 = x|u only, the bytes_cold = 8(nx+2S)+44 traffic of a solve that is not going to be warm-started; the other
- * warm-start records are left as they were.  Register-resident shapes only),
+ * warm-start records are left as they were.  Round 5: every shape -- wide and long ones on the tile kernel's EXT forms, as are
+ * reference windows, "reset_duals" and per-instance problem data; the coverage kernel (overlapping cones, no hipRTC) runs these launch
+ * forms and fused steps too, as a loop of single-step launches, and then writes every record back),
+ * "het_ub" (default 1: per-instance problem data with a knot-invariant box takes the variant that keeps the box in two registers),
  * "repack_after" (-1, the default: automatic -- K is derived from the iteration histogram of the batch's previous solve by a
  * cost model, 0 (a plain launch) when the counts are uniform enough that splitting would not pay 5 %; 0: never split;
  * K > 0: split solve for batches whose iteration counts diverge -- the launch stops at iteration K, the
