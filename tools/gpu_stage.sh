@@ -104,10 +104,10 @@ for stage in "$@"; do
       cd $R; python tools/warm_traffic.py --collect $O > $O/warm_traffic.json 2> $O/warm_traffic.err; cat $O/warm_traffic.json ;;
     fuzz)
       # differential fuzzers against the oracle (new seeds every round); the closed-loop one draws the tile kernel's EXT forms since round 5
-      timeout 900 python tools/fuzz_parity.py 800 50000 > $O/fuzz_parity.txt 2>&1; tail -2 $O/fuzz_parity.txt
-      timeout 900 python tools/fuzz_closed_loop.py 400 51000 > $O/fuzz_closed_loop.txt 2>&1; tail -2 $O/fuzz_closed_loop.txt
-      timeout 600 python tools/fuzz_api_sequence.py 150 52000 > $O/fuzz_api_sequence.txt 2>&1; tail -2 $O/fuzz_api_sequence.txt
-      timeout 600 python tools/fuzz_parity.py 200 53000 phases > $O/fuzz_phases.txt 2>&1; tail -2 $O/fuzz_phases.txt ;;
+      timeout 1200 python tools/fuzz_parity.py ${FUZZ_N:-800} ${FUZZ_SEED:-50000} > $O/fuzz_parity.txt 2>&1; tail -2 $O/fuzz_parity.txt
+      timeout 1200 python tools/fuzz_closed_loop.py $(( ${FUZZ_N:-800} / 2 )) $(( ${FUZZ_SEED:-50000} + 1000 )) > $O/fuzz_closed_loop.txt 2>&1; tail -2 $O/fuzz_closed_loop.txt
+      timeout 600 python tools/fuzz_api_sequence.py 150 $(( ${FUZZ_SEED:-50000} + 2000 )) > $O/fuzz_api_sequence.txt 2>&1; tail -2 $O/fuzz_api_sequence.txt
+      timeout 600 python tools/fuzz_parity.py 200 $(( ${FUZZ_SEED:-50000} + 3000 )) phases > $O/fuzz_phases.txt 2>&1; tail -2 $O/fuzz_phases.txt ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
