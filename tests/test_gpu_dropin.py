@@ -69,6 +69,18 @@ def test_plain_c_example_of_the_batched_abi():
     assert "4096 instances x 60 MPC steps" in p.stdout and "kernel path 0" in p.stdout
 
 
+def test_plain_c_example_of_per_instance_data_windows_and_the_plan():
+    """examples/hetero_tracking.c (C99, built by __graft_entry__.build()): 2 048 different (18,6,10) families -- a wide shape outside tile_dims.txt:
+    the tile kernel's per-instance form, instantiated at run time -- tracking a moving reference window for 40 fused MPC steps with the duals reset before
+    every solve; then the launch plan exported and imported into a second handle.  Everything through the C ABI from plain C."""
+    exe = os.path.join(ROOT, "examples", "_build", "hetero_tracking")
+    if not os.path.exists(exe):
+        pytest.fail("examples/_build/hetero_tracking is missing: __graft_entry__.build() produces it")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout, p.stderr[-800:])
+    assert "kernel path 4" in p.stdout and "imported into a second handle" in p.stdout      # 4: the tile kernel, shape instantiated at run time
+
+
 def test_adaptive_rho_through_the_reference_structs():
     """tests/dropin/adaptive_driver.cpp (our caller, the reference's headers): settings->adaptive_rho = 1 and the
     reference's own tiny_initialize_sensitivity_matrices, 60 closed-loop hover steps through tiny_solve(TinySolver*).  Per
