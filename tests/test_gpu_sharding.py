@@ -156,7 +156,8 @@ def test_bench_line_carries_the_other_configs_and_honest_hbm_fields(tmp_path):
     assert line["roofline_hbm"]["beyond_L3"] is True and line["roofline_hbm"]["batch"] >= 262144
     assert 0.2 < line["roofline_hbm"]["own_refs"]["hbm_frac"] < 1.0 and 0.2 < line["warm_regime"]["own_refs"]["hbm_frac"] < 1.0
     assert line["parity"] == {"entries_checked": 10, "mismatches": 0}
-    assert line["configs"]["config3"]["planned_first_call_ms"] <= 1.25 * line["configs"]["config3"]["ms"]      # an imported plan: settled on the first call
+    c3 = line["configs"]["config3"]                               # an imported plan: the settled form on the first call, not a probe
+    assert c3["planned_first_call_ms"] <= 1.25 * c3["ms"] or c3["planned_first_call_ms"] < 0.95 * c3["first_call_ms"], c3
     assert os.path.samefile(os.path.join(ROOT, line["details"]), details)
     d = json.load(open(details))
     assert abs(d["value"] / line["value"] - 1) < 1e-6
