@@ -235,6 +235,13 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * variants store work->x|u -- written once per launch, never read back by a kernel -- with nontemporal stores).
  * "half_rows" (default -1 / 1: shapes with nx + nu <= 8 run TWO instances per 16-lane row, eight per wavefront, where that form is
  * compiled in -- bit-identical to the one-instance-per-row form; 0: off; read-back "last_half_rows").
+ * "prefetch" (round 6; default -1: a plain single-step launch of the register kernel's box variant over a batch that gives every
+ * resident wavefront at least three tiles -- and the first stage of a split solve -- runs as PERSISTENT waves that draw their tiles
+ * from a ticket counter and receive the NEXT tile's warm-start / reference records by LDS-DMA while the current tile iterates: at
+ * two waves per SIMD a wave's load phase otherwise hides behind one neighbour only; 0: never; 1: wherever the form exists, any
+ * batch size.  Same instructions per iteration, instances independent: bit-identical.  "prefetch_vz" (default 0; 1: a launch whose
+ * instances have their own reference records moves v|z through the wave's LDS buffer too instead of reading it straight into
+ * registers), "prefetch_waves" (default 0 = what is resident; > 0: cap on the persistent grid); read-back "last_prefetch").
  * "step_regroup" (fused launches, "steps_per_launch" > 1, of the register kernel.  The four rows of a wavefront run in lock step: a
  * wave costs what its slowest row costs.  -1, the default: when the iteration totals of the batch's previous fused launch say that
  * this costs >= 5 %, the launch runs as STRETCHES of K = steps / 4 (at least 8) MPC steps, each over the instances ordered by the

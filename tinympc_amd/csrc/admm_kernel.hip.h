@@ -158,6 +158,21 @@ struct SolveArgs {
     // that took alike counts at the last step take alike counts at the next ones.  Same reason as above: nothing in the results.
     const int* perm;
     int perm_count;           // slots of `perm` (a launch may take a part of the batch: batch_dispatch.hip runs two halves on two streams)
+    // one-row kernel, PREFETCH form (template PF; round 6): persistent waves whose NEXT tile's records are on their way into the wave's
+    // LDS buffer (LDS-DMA, global_load_lds_dwordx4: no register holds them) while the current tile iterates -- at two waves per SIMD
+    // (247 VGPRs) a wave's load phase otherwise hides behind ONE neighbour only (tools/ubench/ubench_stream_forms.hip: the record traffic
+    // of a warm solve beyond the Infinity Cache 4.3 -> 5.4 TB/s).  pf_mask: which record arrays travel that way (bit 0 vnew|znew, 1 g|y,
+    // 2 v|z, 3 Xref|Uref; the others are read as in the plain form); the buffer is the launch's dynamic LDS, [x0 piece][arrays in bit
+    // order] in 1-KiB pieces.  Which tiles a wave takes: its first pf_static ones by grid stride (block index + i * grid: no
+    // communication, and no value in flight that the wave would have to wait for at a tile's top -- the stores of the tile before stay
+    // in flight), the rest by TICKET, so that the waves drain together whatever their tiles cost.  pf_counter: ticket counters, one per
+    // SHARD (pf_shards = 8 or 1; 64 bytes apart): ticket k of shard x is tile pf_static * grid + k * pf_shards + x, a wave belongs to
+    // shard blockIdx % pf_shards (one counter for the whole device saturates at ~90 returning atomics per microsecond: 65 536 tiles
+    // would take 0.7 ms).  The counters are never reset: a shard's waves draw exactly (its ticketed tiles) + (its waves) tickets per
+    // launch, pf_base[x] is where this launch's begin (the host keeps the sums)
+    int pf_mask, pf_shards, pf_static;
+    unsigned* pf_counter;
+    unsigned pf_base[8];
 };
 
 // ---- DPP row-broadcast FMA blocks ------------------------------------------------------------
@@ -858,7 +873,9 @@ __device__ __forceinline__ void project_halfspace_columns(const int t, const int
 // registers instead of being read from LDS slot by slot -- 18 LDS reads and as many waits less per iteration at N = 10
 // HALF: nx+nu <= 8 -- TWO instances per DPP row (lanes 0-7 | 8-15), eight per wave: every lane-local instruction and every register
 // serves twice the instances; a mat-vec column is a pair of bank-masked FMAs (fused_*_step_half).  Plain box variants only.
-template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false, bool HALF = false>
+// PF: the PREFETCH form (SolveArgs::pf_mask): plain box variants, plain launches (no index / perm / trajectory window)
+template <int NX, int NU, int N, bool SOC, bool DBG, int MODE, int LIN = 0, bool HET = false, int KMAX = LIN_KMAX, bool ADAPT = false, bool UB = false, bool HALF = false,
+          bool PF = false>
 __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(LIN != 0 ? solve_kernel_lin_waves(NX, NU, N, SOC, LIN, KMAX, UB) : solve_kernel_waves_per_simd(NX + NU, N, SOC, false, ADAPT),
                                    LIN != 0 ? solve_kernel_lin_waves(NX, NU, N, SOC, LIN, KMAX, UB) : solve_kernel_waves_per_simd(NX + NU, N, SOC, false, ADAPT))))
@@ -870,8 +887,12 @@ void admm_solve_kernel(const SolveArgs P) {
     // (LIN on the fused blocks -- two / three extra linear-cost terms in the asm statement -- was built and measured: no difference,
     // (12,4,10) + 2 + 2 half-spaces 5.31 ms either way; what the variant pays is its projection step and 208 B/lane of scratch)
     static_assert(!HALF || (NZ <= 8 && FUSED && !SOC && !DBG && !HET && !ADAPT), "half rows: nx+nu <= 8, the plain box kernel on its fused step blocks");
+    static_assert(!PF || (MODE == 2 && !SOC && !DBG && LIN == 0 && !HET && !ADAPT), "prefetch form: the plain box kernel");
     constexpr int RL = HALF ? 8 : 16;                                  // lanes of one instance
     constexpr int IPW = 64 / RL;                                       // instances per wave
+    constexpr int RECD = N * NZ;                                       // doubles of one instance's record
+    constexpr int PF_PIECES = (IPW * RECD * 8 + 1023) / 1024;          // PF: 1-KiB LDS-DMA pieces (64 lanes x 16 B) per array and tile
+    constexpr int PF_ARR = PF_PIECES * 128;                            // ... doubles of one array in the tile buffer
     constexpr unsigned long long RMASK = HALF ? 0xFFull : 0xFFFFull;
     const int lane = threadIdx.x & 63;
     const int j = lane & (RL - 1);
@@ -1013,12 +1034,153 @@ void admm_solve_kernel(const SolveArgs P) {
     const int ninst = P.index ? *P.count : (P.perm ? P.perm_count : P.batch);
     const int ntiles = (ninst + IPW - 1) / IPW;
     const bool resumed = P.index != nullptr;
+    // ---- PREFETCH form: the tile buffer (the launch's dynamic LDS: [x0 piece: 128 doubles][the arrays of pf_mask, PF_ARR each]) and who
+    // fills it.  A piece is ONE global_load_lds_dwordx4: lane l's 16 bytes land at piece base + 16 l, so the buffer mirrors the records'
+    // own layout [instance][knot][row]; the tile's instances are consecutive (a plain launch).  The last pieces of a tile reach up to
+    // 1 KiB past it -- past the END of the array for the last tile: the host allocates every record array and x0 with that much slack
+    // (batch_api.hip PF_SLACK_BYTES; nobody reads what those bytes bring).
+    extern __shared__ __attribute__((aligned(16))) double sPF[];
+    typedef const __attribute__((address_space(1))) void* pf_gptr;
+    typedef __attribute__((address_space(3))) void* pf_lptr;
+    // Buffer slots (compile-time offsets, so that every buffer read is ONE base register + an immediate): [x0 piece][S0][S1][S2][S3].
+    // warm launches: S0 vnew|znew, S1 g|y, then the reference record (pf_mask bit 3: every instance has its own) and v|z (bit 2; without
+    // it v|z is read straight into registers -- its first use is the first termination test) in that order; cold launches (nothing but
+    // the reference record is read): S0 the reference record
+    constexpr int PF_S0 = 128, PF_S1 = PF_S0 + PF_ARR, PF_S2 = PF_S1 + PF_ARR, PF_S3 = PF_S2 + PF_ARR;
+    auto pf_issue = [&](const int t) {
+        const int tl = P.reverse ? ntiles - 1 - t : t;
+        __builtin_amdgcn_global_load_lds((pf_gptr)(P.x0 + ((size_t)tl * (IPW * NX) + (size_t)lane * 2)), (pf_lptr)sPF, 16, 0, 0);
+        const size_t t0 = (size_t)tl * (IPW * RECD) + (size_t)lane * 2;
+        auto arr = [&](const double* p, const int at) {
+#pragma unroll
+            for (int q = 0; q < PF_PIECES; ++q) __builtin_amdgcn_global_load_lds((pf_gptr)(p + t0 + q * 128), (pf_lptr)(sPF + at + q * 128), 16, 0, 0);
+        };
+        if (!P.cold) { arr(P.slack, PF_S0); arr(P.dual, PF_S1); }
+        if (P.pf_mask & 8) arr(P.ref, P.cold ? PF_S0 : PF_S2);
+        if (!P.cold && (P.pf_mask & 4)) arr(P.slack_prev, (P.pf_mask & 8) ? PF_S3 : PF_S2);
+    };
+    unsigned pf_ticket = 0u;                                   // (lane 0) the ticket drawn for the tile after the next one
+    const int pf_shard = PF ? (int)(blockIdx.x % (unsigned)(P.pf_shards > 0 ? P.pf_shards : 1)) : 0;
+    // (the pointer goes through an empty asm: LLVM's atomic optimizer rewrites an add of a uniform value to a UNIFORM address into one
+    // wave-wide add whose result it reads back -- readfirstlane, i.e. a full VMEM wait -- on the spot; a ticket is not needed before the
+    // next tile's top, and that is where its wait belongs)
+    typedef __attribute__((address_space(1))) unsigned* pf_ctr_t;
+    unsigned long long pf_ctr_bits = PF ? (unsigned long long)(P.pf_counter + 16 * pf_shard) : 0ull;
+    if constexpr (PF) asm volatile("" : "+v"(pf_ctr_bits));
+    const pf_ctr_t pf_ctr = (pf_ctr_t)pf_ctr_bits;
+    auto pf_draw = [&]() { return lane == 0 ? __hip_atomic_fetch_add(pf_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; };
+    const unsigned pf_base = PF ? P.pf_base[pf_shard] : 0u;
+    int pf_next = 0, pf_i = 0;                                 // (pf_i: tiles this wave has taken)
+    bool pf_first = true;
+    // a reference record every instance shares: -(ref x diagonal) and the terminal term are formed ONCE per wave and kept in LDS
+    // (one 16-lane row per slot): a tile reads them back instead of carrying ten more doubles per lane from tile to tile
+    __shared__ double sQX[PF ? N * 16 : 1];
+    if constexpr (PF) {
+        if ((int)blockIdx.x < ntiles) {
+            pf_issue((int)blockIdx.x);
+            if (P.pf_static <= 1) pf_ticket = pf_draw();           // (the second tile is a ticketed one already)
+        }
+        if (P.ref_shared) {
+            double rl = 0.0, qxs[N];
+#pragma unroll
+            for (int s = 0; s < N; ++s) {
+                const bool valid = is_state || (is_input && s >= 1);
+                const double r = valid ? P.ref[j - (is_input ? NZ : 0) + s * NZ] : 0.0;
+                qxs[s] = -(r * qr);
+                if (s == N - 1) rl = r;
+            }
+            double pt[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) pt[k] = sPt[k * 16 + j];
+            double xp = 0.0;
+            if constexpr (HALF) ring1_half<0, NX>(xp, rl, pt);
+            else xp = ring_sum<MODE, 0, NX>(0.0, rl, pt);
+            qxs[N - 1] = is_state ? -xp : qxs[N - 1];          // (terminal_term below, for the shared record)
+            if (grp == 0) {
+#pragma unroll
+                for (int s = 0; s < N; ++s) sQX[s * 16 + j] = qxs[s];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     // Tiles of 4 instances: one per wave (grid = tiles), or -- a follow-up stage of a split solve, fewer waves than tiles -- the wave
     // takes its next tile off the stage's counter the moment it is free (its tiles differ in depth: a fixed stride would make the
     // stage wait for the slot that drew the deepest ones)
     for (int tile = blockIdx.x; tile < ntiles;
-         tile = P.work_counter ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(P.work_counter, 1) : 0) + (int)gridDim.x : tile + (int)gridDim.x) {
+         tile = PF ? pf_next : (P.work_counter ? __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(P.work_counter, 1) : 0) + (int)gridDim.x : tile + (int)gridDim.x)) {
         const int slot = (P.reverse ? ntiles - 1 - tile : tile) * IPW + grp;
+        // PF: every lane takes its part of the tile out of the buffer (the rows of a last, partial tile: whatever the clamped pieces
+        // brought -- they do not use it), then the buffer is handed to the NEXT tile's records: issued here, under the full EXEC mask,
+        // in flight while this tile iterates.  Order of this wave's VMEM operations per tile: [reads of the arrays that do not travel
+        // through the buffer] [ticket] [the next tile's pieces] ... [this tile's stores].
+        double pfVN[PF ? N : 1], pfG[PF ? N : 1], pfVP[PF ? N : 1], pfQXs[PF ? N : 1], pf_x0 = 0.0, pf_rl = 0.0;
+        if constexpr (PF) {
+            // The tile's records have landed when the wave's own VMEM counter says so -- nothing else orders a ds_read behind a pending
+            // LDS-DMA.  A wave's VMEM operations complete in issue order; behind this tile's pieces only the stores of the tile before
+            // were issued, among them N each to the vnew|znew and g|y records when the launch writes both: those may stay in flight.
+            if (pf_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if ((P.store_mask & 6) == 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * N <= 63 ? 2 * N : 63) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pf_first = false;
+            if (pf_i + 1 < P.pf_static) pf_next = tile + (int)gridDim.x;
+            else {
+                unsigned pf_t;                                    // (volatile: the read-back stays HERE, behind the wait above)
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(pf_t) : "v"(pf_ticket));
+                pf_next = (int)(pf_t - pf_base) * P.pf_shards + pf_shard + (P.pf_static > 1 ? P.pf_static : 1) * (int)gridDim.x;
+            }
+            const int m = P.pf_mask;
+            // this lane's cell of slot 0 in a buffer array (input lanes: knot s-1 at slot s; their slot 0 and the lanes beyond nx+nu read
+            // a cell nobody uses: at worst the 16 doubles in FRONT of the array, which the x0 piece covers)
+            const int lrow = grp * RECD + (j < NZ ? j - (is_input ? NZ : 0) : 0);
+            const bool warm_t = !P.cold;
+            pf_x0 = sPF[grp * NX + (is_state ? j : 0)];
+#pragma unroll
+            for (int s = 0; s < N; ++s) { pfVN[s] = 0.0; pfG[s] = 0.0; pfVP[s] = 0.0; }
+            if (warm_t) {
+#pragma unroll
+                for (int s = 0; s < N; ++s) { pfVN[s] = sPF[PF_S0 + lrow + s * NZ]; pfG[s] = sPF[PF_S1 + lrow + s * NZ]; }
+            }
+            auto own_ref = [&](const int at) {                    // this instance's own reference record: -(ref x diagonal), admm.cpp:266 / :279
+#pragma unroll
+                for (int s = 0; s < N; ++s) {
+                    const bool valid = is_state || (is_input && s >= 1);
+                    const double r = valid ? sPF[at + lrow + s * NZ] : 0.0;
+                    pfQXs[s] = -(r * qr);
+                    if (s == N - 1) pf_rl = r;
+                }
+            };
+            if (m & 8) { if (warm_t) own_ref(PF_S2); else own_ref(PF_S0); }      // (two call sites: the slot is an immediate in each)
+            else {
+#pragma unroll
+                for (int s = 0; s < N; ++s) pfQXs[s] = sQX[s * 16 + j];
+            }
+            if (warm_t) {
+                if ((m & 12) == 12) {
+#pragma unroll
+                    for (int s = 0; s < N; ++s) pfVP[s] = sPF[PF_S3 + lrow + s * NZ];
+                } else if (m & 4) {
+#pragma unroll
+                    for (int s = 0; s < N; ++s) pfVP[s] = sPF[PF_S2 + lrow + s * NZ];
+                } else {
+                    // straight from its record (a valid instance for every lane): ONE base address + immediates; slot 0 of an input lane
+                    // (no cell: a neutral dummy) reads the lane's slot 1 instead
+                    const int bb = slot < ninst ? slot : ninst - 1;
+                    const double* g0 = P.slack_prev + ((size_t)bb * RECD + (size_t)(j < NZ ? j : 0));
+                    const double* g1 = is_input ? g0 - NZ : g0;
+                    pfVP[0] = is_input ? g0[0] : g1[0];
+#pragma unroll
+                    for (int s = 1; s < N; ++s) pfVP[s] = g1[s * NZ];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's contents are in registers: it is free
+            if (pf_next < ntiles) {                               // (a wave stops drawing with its first ticket beyond the batch)
+                if (pf_i + 2 >= P.pf_static) pf_ticket = pf_draw();   // the tile after the next one is a ticketed one
+                pf_issue(pf_next);
+            }
+            ++pf_i;
+        }
+        (void)pfVN; (void)pfG; (void)pfVP; (void)pf_rl; (void)pf_x0; (void)pfQXs; (void)pf_first; (void)pf_ticket; (void)sQX; (void)pf_ctr; (void)pf_base; (void)pf_draw; (void)pf_i;
         if (slot < ninst) {
             const int b = resumed ? P.index[slot] : (P.perm ? P.perm[slot] : slot);
             const double* het = nullptr;
@@ -1055,7 +1217,7 @@ void admm_solve_kernel(const SolveArgs P) {
             double X[N], G[N], VN[N], VP[N], QX[N], Dn[N - 1];
             // cone slack cells of this lane (W plane of slot 0): sC[cw + s * SLOT_D (+ PL_GC | PL_VC)]
             const int cw = grp * N * SLOT_D + (j < NZ ? j : NZ);
-            const double x0v_in = is_state ? P.x0[(size_t)b * NX + j] : 0.0;      // tiny_set_x0
+            const double x0v_in = is_state ? (PF ? pf_x0 : P.x0[(size_t)b * NX + j]) : 0.0;      // tiny_set_x0
             const int cl = grp * N * CSL + (j < NZ ? j : NZ);  // LIN: this lane's cell of slot 0 (slot s: + s * CSL)
             double VL[LSR ? N : 1], GL[LSR ? N : 1], VT[LTR ? N : 1], GT[LTR ? N : 1];
             double Qd[DBG ? N : 1], Pd[DBG ? N : 1], Dd[DBG ? N : 1];
@@ -1066,6 +1228,15 @@ void admm_solve_kernel(const SolveArgs P) {
                 const bool valid = is_state || (is_input && s >= 1);
                 const size_t off = lbase + s * NZ;
                 const bool warm = valid && !P.cold;
+                if constexpr (PF) {                          // (what the tile buffer held; a shared reference record: formed once per wave)
+                    VN[s] = warm ? pfVN[s] : 0.0;
+                    G[s] = warm ? pfG[s] : 0.0;
+                    VP[s] = warm ? pfVP[s] : 0.0;
+                    QX[s] = pfQXs[s];
+                    X[s] = 0.0;
+                    if (s == N - 1) ref_last = pf_rl;
+                    continue;
+                }
                 const double r = valid ? (P.ref_shared ? P.ref[off - (size_t)b * (N * NZ)] : load_ref(P.ref + off)) : 0.0;
                 VN[s] = warm ? P.slack[off] : 0.0;
                 G[s] = warm ? P.dual[off] : 0.0;
@@ -1137,7 +1308,7 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int k = 0; k < NU; ++k) c1[k] = v[k];
                 }
             };
-            if (!P.traj) terminal_term();
+            if (!P.traj && !(PF && P.ref_shared)) terminal_term();
             const int traj_k0 = P.traj ? (P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0)) : 0;
 
             int iter = 0, solved = 0, checked = 0;
@@ -1680,10 +1851,15 @@ void admm_solve_kernel(const SolveArgs P) {
                 double4 rr = make_double4(ps, pi, ds, di);
                 *reinterpret_cast<double4*>(P.resid + (size_t)b * 4) = rr;
                 if (P.accum) {
-                    uint2 ac = P.accum[b];
-                    ac.x += acc_iter;
-                    ac.y += acc_solved;
-                    P.accum[b] = ac;
+                    if constexpr (PF) {                      // (no value comes back: a persistent wave must not wait for one here)
+                        __hip_atomic_fetch_add(&P.accum[b].x, acc_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&P.accum[b].y, acc_solved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        uint2 ac = P.accum[b];
+                        ac.x += acc_iter;
+                        ac.y += acc_solved;
+                        P.accum[b] = ac;
+                    }
                 }
             }
         }

@@ -222,8 +222,12 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
         if (hipMemsetAsync(*p, 0, kpi_bytes + kpi_pad, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
     }
     b->stage_doubles = (size_t)batch * std::max(nx * N, nu * (N - 1));       // the largest host-layout field (nu > nx happens)
-    if (hipMalloc(&b->d_x0, (size_t)batch * nx * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
-    if (hipMemsetAsync(b->d_x0, 0, (size_t)batch * nx * sizeof(double), b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    // (+ 1 KiB: the PREFETCH form's LDS-DMA pieces are 1 KiB each and the last tile's reach past the end of x0 -- and of the record
+    // arrays, whose kpi_pad covers it; nobody reads what those bytes bring)
+    if (hipMalloc(&b->d_x0, (size_t)batch * nx * sizeof(double) + 1024) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_x0, 0, (size_t)batch * nx * sizeof(double) + 1024, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMalloc(&b->d_pf_counter, 8 * 64) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_pf_counter, 0, 8 * 64, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
     if (hipMalloc(&b->d_stage, b->stage_doubles * sizeof(double)) != hipSuccess) return bail(TINY_ERR_HIP);
     if (hipMalloc(&b->d_status, (size_t)batch * sizeof(int4)) != hipSuccess) return bail(TINY_ERR_HIP);
     if (hipMemsetAsync(b->d_status, 0, (size_t)batch * sizeof(int4), b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
@@ -325,7 +329,7 @@ int tiny_batch_destroy(TinyBatch* b) {
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
                     b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count,
-                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter, b->d_perm, b->d_rg_bins, b->d_ls};
+                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter, b->d_perm, b->d_rg_bins, b->d_ls, b->d_pf_counter};
     for (void* p : bufs)
         if (p) hipFree(p);
     if (b->h_wire) hipHostFree(b->h_wire);
@@ -746,6 +750,10 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
+    else if (!strcmp(name, "prefetch")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "prefetch: -1 (by rule), 0 (never), 1 (wherever the form exists)"); b->prefetch = (int)value; }
+    else if (!strcmp(name, "prefetch_vz")) b->prefetch_vz = value != 0 ? 1 : 0;
+    else if (!strcmp(name, "prefetch_static")) { if (value < 0 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100"); b->prefetch_static = (int)value; }
+    else if (!strcmp(name, "prefetch_waves")) { if (value < 0) return fail(b, TINY_ERR_ARG, "prefetch_waves >= 0"); b->prefetch_waves = (int)value; }
     else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
     else if (!strcmp(name, "step_regroup")) { if (value < -1) return fail(b, TINY_ERR_ARG, "step_regroup: K > 0 (stretches of K MPC steps), 0 (never) or -1 (automatic)"); b->step_regroup = (int)value; b->regroup_verdict = 0; b->regroup_since = 0; b->ls_pending = false; }
     else if (!strcmp(name, "step_regroup_streams")) { if (value < 1 || value > 2) return fail(b, TINY_ERR_ARG, "step_regroup_streams: 1 or 2"); b->regroup_streams = (int)value; }
@@ -880,6 +888,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
+    if (!strcmp(name, "last_prefetch")) return b->last_prefetch ? 1 : 0;     // the last one-row launch (a split solve: its first stage) took the PREFETCH form
     if (!strcmp(name, "last_half_rows")) return b->last_half ? 1 : 0;       // the last one-row launch took the HALF form (two instances per DPP row)
     if (!strcmp(name, "last_tile_form")) return b->last_tile_form;          // W * 1e6 + R * 1e3 + LM of the tile_dims.txt entry the last tile launch took (-1: run-time instantiated)
     if (!strcmp(name, "last_tile_dyn")) return b->last_tile_dyn ? 1 : 0;      // the last tile-kernel launch took the dynamic slot form

@@ -127,6 +127,20 @@ struct TinyBatch {
     bool last_half = false;              // the last one-row launch took it
     int launch_order = 1;                // option "launch_order": 1 = successive plain launches of the one-row kernel walk the batch in alternating directions
     bool order_flip = false;
+    // PREFETCH form of the one-row kernel (round 6; admm_kernel.hip.h PF): persistent waves that draw their tiles from a ticket counter
+    // and whose NEXT tile's records travel into the wave's LDS buffer (LDS-DMA) while the current one iterates.  Option "prefetch":
+    // -1 (default) every plain single-step launch of a batch of at least PF_AUTO_MIN_TILES tiles per resident wave and the first stage
+    // of a split solve; 0 never; 1 wherever the form exists (any batch size: tests).  "prefetch_vz": a launch whose instances have
+    // their OWN reference records moves v|z through the buffer too (1: four arrays, seven waves per CU at (12,4,10)) or reads it straight
+    // into registers (0, the default: its first use is the first termination test).  "prefetch_waves": cap on the persistent grid (0: what is resident)
+    int prefetch = -1, prefetch_vz = 0, prefetch_waves = 0;
+    int prefetch_static = 75;            // option "prefetch_static": percent of a wave's tiles it takes by grid stride (the rest by ticket)
+    unsigned* d_pf_counter = nullptr;    // eight ticket counters (64 bytes apart), never reset: a launch draws a known number from each
+    unsigned pf_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // where the next launch's tickets begin, per shard
+    bool last_prefetch = false;          // the last one-row launch (a split solve: its first stage) took the form
+    const void* pf_occ_kernel = nullptr; // residency of the form's kernel at pf_occ_lds bytes of dynamic LDS (asked once)
+    size_t pf_occ_lds = 0;
+    int pf_occ = 0;
     // step_regroup (fused closed-loop launches of the one-row kernel): the launch is cut into stretches of K MPC steps and every
     // stretch takes the instances ordered by the iteration count of their last solve (SolveArgs::perm; a counting sort on the
     // device between the stretches) -- the four rows of a wave run in lock step, and what a row needed at its last step says what

@@ -36,7 +36,7 @@ def main():
         rows = [r for rs in ex.map(usage, srcs) for r in rs]
     show_all = "--all" in sys.argv
     print(f"{len(rows)} kernel instantiations, {sum(r['scratch'] > 0 for r in rows)} with scratch (memory spills)\n")
-    print("one-row kernel `admm_solve_kernel<NX,NU,N,SOC,DBG,MODE,LIN,HET,KMAX,ADAPT,UB>` -- default variants (box constraints, MODE 2; UB = the form launched when the box is the same at every knot), cone and adaptive-rho variants:\n")
+    print("one-row kernel `admm_solve_kernel<NX,NU,N,SOC,DBG,MODE,LIN,HET,KMAX,ADAPT,UB,HALF,PF>` -- default variants (box constraints, MODE 2; UB = the form launched when the box is the same at every knot), cone and adaptive-rho variants:\n")
     print("| (nx,nu,N) | variant | VGPR | AGPR | scratch B/lane | waves/SIMD | LDS B |")
     print("|---|---|---|---|---|---|---|")
     for r in sorted((r for r in rows if r["kind"] == "one-row"), key=lambda r: (r["args"][:3], r["args"][3:])):
@@ -48,6 +48,11 @@ def main():
         if tag is None and not show_all:
             continue
         tag = tag or f"soc{a[3]} dbg{a[4]} mode{a[5]} lin{a[6]} het{a[7]} adapt{extra[0]} ub{extra[1]}"
+        # (round 4: HALF rows, round 6: the PREFETCH form -- template arguments 12 and 13)
+        if len(a) >= 12 and a[11]:
+            tag += ", HALF rows"
+        if len(a) >= 13 and a[12]:
+            tag += ", PREFETCH form"
         print(f"| ({a[0]},{a[1]},{a[2]}) | {tag} | {r['vgpr']} | {r['agpr']} | {r['scratch']} | {r['occ']} | {r['lds']} |")
     print("\ntile kernel `admm_tile_kernel<NX,NU,N,W,R>`:\n")
     print("| (nx,nu,N) | W x R | form | VGPR | AGPR | scratch B/lane | waves/SIMD | LDS B |")
