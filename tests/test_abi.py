@@ -228,10 +228,16 @@ def test_headline_kernel_register_budget():
     blocks = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                         p.stderr, re.S)
     # <12,4,10, box only, dpp_mode 2, plain>: the per-knot-box form and the knot-invariant-box form (UB) the bench runs
-    head = [b for b in blocks if "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0ELb0ELb0EE" in b[0] or "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0ELb1ELb0EE" in b[0]]
+    head = [b for b in blocks if "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0ELb0ELb0ELb0EE" in b[0] or "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0ELb1ELb0ELb0EE" in b[0]]
     assert len(head) == 2, [b[0] for b in blocks][:4]
     for _, vgpr, agpr, scratch, occ in head:
         assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, head
+    # round 6: their PREFETCH forms (template argument PF) -- two waves per SIMD; what little scratch the UB form has (two loop-invariant
+    # addresses, 16-20 B) sits in front of the straight v|z reads of a tile's top, nowhere near the iteration loop
+    pf = [b for b in blocks if "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0ELb0ELb0ELb1EE" in b[0] or "ILi12ELi4ELi10ELb0ELb0ELi2ELi0ELb0ELi4ELb0ELb1ELb0ELb1EE" in b[0]]
+    assert len(pf) == 2, [b[0] for b in blocks][:4]
+    for _, vgpr, agpr, scratch, occ in pf:
+        assert int(scratch) <= 32 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, pf
 
 
 def test_cone_kernel_register_budget():
@@ -245,7 +251,7 @@ def test_cone_kernel_register_budget():
     assert p.returncode == 0, p.stderr[-2000:]
     blocks = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                         p.stderr, re.S)
-    cone = [b for b in blocks if "ILi6ELi3ELi10ELb1ELb0ELi2ELi0ELb0ELi4ELb0ELb0ELb0EE" in b[0] or "ILi6ELi3ELi10ELb1ELb0ELi2ELi0ELb0ELi4ELb0ELb1ELb0EE" in b[0]]
+    cone = [b for b in blocks if "ILi6ELi3ELi10ELb1ELb0ELi2ELi0ELb0ELi4ELb0ELb0ELb0ELb0EE" in b[0] or "ILi6ELi3ELi10ELb1ELb0ELi2ELi0ELb0ELi4ELb0ELb1ELb0ELb0EE" in b[0]]
     assert len(cone) == 2, [b[0] for b in blocks][:6]
     for _, vgpr, agpr, scratch, occ in cone:
         assert int(scratch) == 0 and int(agpr) == 0 and int(vgpr) <= 256 and int(occ) == 2, cone
