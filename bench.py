@@ -114,7 +114,10 @@ def traffic_per_launch(T, B):
         return None, None
     try:
         t = json.load(open(tpath))
-        for key in (("fused_launch", "fused_100_steps_launch") if T > 1 else ("per_step_launch",)):
+        # the PMC entry whose launches fuse the SAME number of MPC steps as this run's (the 100-step entry was cited for
+        # the driver's 20-step launches); a launch form without an entry of its own has no citation
+        keys = {1: ("per_step_launch",), 20: ("fused_launch_driver_flags",), 100: ("fused_launch", "fused_100_steps_launch")}.get(T, ())
+        for key in keys:
             if key in t:
                 return t[key]["hbm_bytes_per_launch"], "profiles/traffic.json[%s] (%s)" % (key, t[key].get("round", "r02 PMC run"))
     except Exception:
@@ -208,7 +211,9 @@ def compact_line(out, details_path=None):
             for key, short in (("steady_state", "shared_ref"), ("steady_state_per_instance_refs", "own_refs")):
                 r_ = big.get(key)
                 if isinstance(r_, dict):
-                    b_[short] = {"hbm_frac": _r(r_.get("hbm_frac"), 4), "gbs": _r(r_.get("hbm_gbs"), 4), "ms": _r(r_.get("ms_per_launch"), 4)}
+                    # (hbm_frac: the 30 launches' bytes over their time; min / med / max: the launches one by one)
+                    b_[short] = {"hbm_frac": _r(r_.get("hbm_frac"), 4), "min": _r(r_.get("hbm_frac_min"), 3), "med": _r(r_.get("hbm_frac_median"), 3),
+                                 "max": _r(r_.get("hbm_frac_max"), 3), "gbs": _r(r_.get("hbm_gbs"), 4), "ms": _r(r_.get("ms_per_launch"), 4)}
             line["roofline_hbm"] = b_
             optional.append("roofline_hbm")
         cold = reg.get("cold")
@@ -220,7 +225,8 @@ def compact_line(out, details_path=None):
         if "error" in cpu:
             line["cpu_baseline"] = {"error": str(cpu["error"])[:200]}
         else:
-            line["cpu_baseline"] = {"value": _r(cpu.get("value"), 6), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+            line["cpu_baseline"] = {"value": _r(cpu.get("value"), 6), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "physical_cores": cpu.get("physical_cores"),
+                                    "kind": cpu.get("kind"),
                                     "sample": str(cpu.get("sample", ""))[:200]}
     cfgs = out.get("configs")
     if isinstance(cfgs, dict):
@@ -579,8 +585,12 @@ def regimes_replay(hv, fl, bytes_warm, full=True, reps=5):
 
     def steady(msv, ref_shared, store_primal, note):
         t = float(msv[warm_steps].mean()) * 1e-3
-        moved = float(np.mean([moved_bytes_per_solve(bytes_warm, S, nx, nu, it, ref_shared, store_primal) for it in iters[warm_steps]]))
+        per_step = np.array([moved_bytes_per_solve(bytes_warm, S, nx, nu, it, ref_shared, store_primal) for it in iters[warm_steps]])
+        moved = float(per_step.mean())
+        fr = per_step * B / (msv[warm_steps] * 1e-3) / 1e9 / HBM_PEAK_GBS          # every launch of the 30 on its own bytes and its own time
         return {"steps": "70-99", "ms_per_launch": t * 1e3, "ms_per_launch_min": float(msv[warm_steps].min()),
+                "ms_per_launch_median": float(np.median(msv[warm_steps])), "ms_per_launch_max": float(msv[warm_steps].max()),
+                "hbm_frac_min": float(fr.min()), "hbm_frac_median": float(np.median(fr)), "hbm_frac_max": float(fr.max()),
                 "admm_iters_per_solve": float(iters[warm_steps].mean()),
                 "bytes_moved_per_solve": moved, "algorithmic_bytes_per_solve": bytes_warm,
                 "hbm_gbs": moved * B / t / 1e9, "hbm_frac": moved * B / t / 1e9 / HBM_PEAK_GBS,

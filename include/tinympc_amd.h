@@ -239,9 +239,9 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * resident wavefront at least three tiles -- and the first stage of a split solve -- runs as PERSISTENT waves that draw their tiles
  * from a ticket counter and receive the NEXT tile's warm-start / reference records by LDS-DMA while the current tile iterates: at
  * two waves per SIMD a wave's load phase otherwise hides behind one neighbour only; 0: never; 1: wherever the form exists, any
- * batch size.  Same instructions per iteration, instances independent: bit-identical.  "prefetch_vz" (default 0; 1: a launch whose
- * instances have their own reference records moves v|z through the wave's LDS buffer too instead of reading it straight into
- * registers), "prefetch_waves" (default 0 = what is resident; > 0: cap on the persistent grid); read-back "last_prefetch").
+ * batch size.  Same instructions per iteration, instances independent: bit-identical.  "prefetch_static" (default 75: percent of
+ * a wave's tiles it takes by grid stride before it draws tickets), "prefetch_waves" (default 0 = what is resident; > 0: cap on the
+ * persistent grid); read-back "last_prefetch").
  * "step_regroup" (fused launches, "steps_per_launch" > 1, of the register kernel.  The four rows of a wavefront run in lock step: a
  * wave costs what its slowest row costs.  -1, the default: when the iteration totals of the batch's previous fused launch say that
  * this costs >= 5 %, the launch runs as STRETCHES of K = steps / 4 (at least 8) MPC steps, each over the instances ordered by the

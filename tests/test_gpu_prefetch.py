@@ -59,12 +59,11 @@ def test_prefetch_form_cold_and_warm_against_the_oracle_and_the_plain_form(B, wa
         warm["cases"][k] = ref[k]
     warm["cases"]["x0"] = suite["cases"]["x0"] * 0.9
     wref = sc.run_cases(OracleSolver, warm)
-    for vz in (0, 1):                        # v|z read straight into registers / through the buffer as the fourth array
-        w = run_cases_hip(warm, options=dict(pf, prefetch_vz=vz))
-        assert_match(w, wref, RTOL, f"prefetch form, warm, B={B}, waves={waves}, vz={vz}")
-        wp = run_cases_hip(warm, options=dict(base, prefetch=0))
-        for k in FIELDS:
-            assert np.array_equal(w[k], wp[k]), (k, B, waves, vz)
+    w = run_cases_hip(warm, options=pf)
+    assert_match(w, wref, RTOL, f"prefetch form, warm, B={B}, waves={waves}")
+    wp = run_cases_hip(warm, options=dict(base, prefetch=0))
+    for k in FIELDS:
+        assert np.array_equal(w[k], wp[k]), (k, B, waves)
     assert len(np.unique(wref["iter"])) > 1
 
 

@@ -680,6 +680,10 @@ __device__ __forceinline__ double resid_max(double a, double b) {
 #ifndef TINYMPC_REF_LOAD
 #define TINYMPC_REF_LOAD 1
 #endif
+// record stores as whole knot segments (see the write-back of admm_solve_kernel): 0 never, 1 the PREFETCH form, 2 every box variant
+#ifndef TINYMPC_FULL_LINE_STORES
+#define TINYMPC_FULL_LINE_STORES 2
+#endif
 // per-instance Xref|Uref records are read once per launch and never written by a kernel: the same argument (1 = nontemporal load)
 __device__ __forceinline__ double load_ref(const double* p) {
 #if TINYMPC_REF_LOAD == 1
@@ -1031,9 +1035,13 @@ void admm_solve_kernel(const SolveArgs P) {
     // UB: slot 1 speaks for every slot (slot 0 of an input lane is the neutral dummy: its box stays (-inf, +inf))
     const double lo_u = P.tab[TAB_BOUNDS + (N > 1 ? 16 : 0) + j], hi_u = P.tab[TAB_BOUNDS + N * 16 + (N > 1 ? 16 : 0) + j];
     const double lo_u0 = P.tab[TAB_BOUNDS + j], hi_u0 = P.tab[TAB_BOUNDS + N * 16 + j];
-    const int ninst = P.index ? *P.count : (P.perm ? P.perm_count : P.batch);
+    // (PF: a plain single-step launch over the whole batch -- no index list, no permutation, no trajectory window: those paths are
+    // compiled OUT of the form, because a register-returning load on ANY path between a tile's hand-over and its stores makes the
+    // compiler wait for the whole VMEM queue at the join, the next tile's pieces included)
+    const int ninst = PF ? P.batch : (P.index ? *P.count : (P.perm ? P.perm_count : P.batch));
     const int ntiles = (ninst + IPW - 1) / IPW;
-    const bool resumed = P.index != nullptr;
+    const bool resumed = !PF && P.index != nullptr;
+    const bool has_traj = !PF && P.traj != nullptr;
     // ---- PREFETCH form: the tile buffer (the launch's dynamic LDS: [x0 piece: 128 doubles][the arrays of pf_mask, PF_ARR each]) and who
     // fills it.  A piece is ONE global_load_lds_dwordx4: lane l's 16 bytes land at piece base + 16 l, so the buffer mirrors the records'
     // own layout [instance][knot][row]; the tile's instances are consecutive (a plain launch).  The last pieces of a tile reach up to
@@ -1043,9 +1051,10 @@ void admm_solve_kernel(const SolveArgs P) {
     typedef const __attribute__((address_space(1))) void* pf_gptr;
     typedef __attribute__((address_space(3))) void* pf_lptr;
     // Buffer slots (compile-time offsets, so that every buffer read is ONE base register + an immediate): [x0 piece][S0][S1][S2][S3].
-    // warm launches: S0 vnew|znew, S1 g|y, then the reference record (pf_mask bit 3: every instance has its own) and v|z (bit 2; without
-    // it v|z is read straight into registers -- its first use is the first termination test) in that order; cold launches (nothing but
-    // the reference record is read): S0 the reference record
+    // Warm launches: S0 vnew|znew, S1 g|y, S2 v|z, S3 the reference record when every instance has its own (pf_mask bit 3); cold
+    // launches read nothing but the reference record: S0.  EVERY record read of a tile goes through the buffer: one register-returning
+    // load left in flight across the hand-over would make the compiler's own wait for it -- which cannot tell the pieces issued behind
+    // it apart -- a wait for the next tile's records too, and the prefetch would hide nothing (measured: round 6, first form).
     constexpr int PF_S0 = 128, PF_S1 = PF_S0 + PF_ARR, PF_S2 = PF_S1 + PF_ARR, PF_S3 = PF_S2 + PF_ARR;
     auto pf_issue = [&](const int t) {
         const int tl = P.reverse ? ntiles - 1 - t : t;
@@ -1055,9 +1064,8 @@ void admm_solve_kernel(const SolveArgs P) {
 #pragma unroll
             for (int q = 0; q < PF_PIECES; ++q) __builtin_amdgcn_global_load_lds((pf_gptr)(p + t0 + q * 128), (pf_lptr)(sPF + at + q * 128), 16, 0, 0);
         };
-        if (!P.cold) { arr(P.slack, PF_S0); arr(P.dual, PF_S1); }
-        if (P.pf_mask & 8) arr(P.ref, P.cold ? PF_S0 : PF_S2);
-        if (!P.cold && (P.pf_mask & 4)) arr(P.slack_prev, (P.pf_mask & 8) ? PF_S3 : PF_S2);
+        if (!P.cold) { arr(P.slack, PF_S0); arr(P.dual, PF_S1); arr(P.slack_prev, PF_S2); }
+        if (P.pf_mask & 8) arr(P.ref, P.cold ? PF_S0 : PF_S3);
     };
     unsigned pf_ticket = 0u;                                   // (lane 0) the ticket drawn for the tile after the next one
     const int pf_shard = PF ? (int)(blockIdx.x % (unsigned)(P.pf_shards > 0 ? P.pf_shards : 1)) : 0;
@@ -1074,7 +1082,7 @@ void admm_solve_kernel(const SolveArgs P) {
     bool pf_first = true;
     // a reference record every instance shares: -(ref x diagonal) and the terminal term are formed ONCE per wave and kept in LDS
     // (one 16-lane row per slot): a tile reads them back instead of carrying ten more doubles per lane from tile to tile
-    __shared__ double sQX[PF ? N * 16 : 1];
+    double* const sQX = sPF + PF_S3;                           // (the slot of the per-instance records: free when the record is shared)
     if constexpr (PF) {
         if ((int)blockIdx.x < ntiles) {
             pf_issue((int)blockIdx.x);
@@ -1150,39 +1158,31 @@ void admm_solve_kernel(const SolveArgs P) {
                     if (s == N - 1) pf_rl = r;
                 }
             };
-            if (m & 8) { if (warm_t) own_ref(PF_S2); else own_ref(PF_S0); }      // (two call sites: the slot is an immediate in each)
+            if (m & 8) { if (warm_t) own_ref(PF_S3); else own_ref(PF_S0); }      // (two call sites: the slot is an immediate in each)
             else {
 #pragma unroll
                 for (int s = 0; s < N; ++s) pfQXs[s] = sQX[s * 16 + j];
             }
             if (warm_t) {
-                if ((m & 12) == 12) {
 #pragma unroll
-                    for (int s = 0; s < N; ++s) pfVP[s] = sPF[PF_S3 + lrow + s * NZ];
-                } else if (m & 4) {
-#pragma unroll
-                    for (int s = 0; s < N; ++s) pfVP[s] = sPF[PF_S2 + lrow + s * NZ];
-                } else {
-                    // straight from its record (a valid instance for every lane): ONE base address + immediates; slot 0 of an input lane
-                    // (no cell: a neutral dummy) reads the lane's slot 1 instead
-                    const int bb = slot < ninst ? slot : ninst - 1;
-                    const double* g0 = P.slack_prev + ((size_t)bb * RECD + (size_t)(j < NZ ? j : 0));
-                    const double* g1 = is_input ? g0 - NZ : g0;
-                    pfVP[0] = is_input ? g0[0] : g1[0];
-#pragma unroll
-                    for (int s = 1; s < N; ++s) pfVP[s] = g1[s * NZ];
-                }
+                for (int s = 0; s < N; ++s) pfVP[s] = sPF[PF_S2 + lrow + s * NZ];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's contents are in registers: it is free
             if (pf_next < ntiles) {                               // (a wave stops drawing with its first ticket beyond the batch)
-                if (pf_i + 2 >= P.pf_static) pf_ticket = pf_draw();   // the tile after the next one is a ticketed one
+                // the tile after the next one is a ticketed one.  A BRANCH (the empty asm keeps it one): as a select, or assigned on every
+                // path, the ticket register -- which may have a draw in flight -- would be touched in every tile, and the compiler waits
+                // for the whole VMEM queue before it touches it: the stores of the tile before would never stay in flight
+                if (pf_i + 2 >= P.pf_static) {
+                    asm volatile("" ::: "memory");
+                    pf_ticket = pf_draw();
+                }
                 pf_issue(pf_next);
             }
             ++pf_i;
         }
         (void)pfVN; (void)pfG; (void)pfVP; (void)pf_rl; (void)pf_x0; (void)pfQXs; (void)pf_first; (void)pf_ticket; (void)sQX; (void)pf_ctr; (void)pf_base; (void)pf_draw; (void)pf_i;
         if (slot < ninst) {
-            const int b = resumed ? P.index[slot] : (P.perm ? P.perm[slot] : slot);
+            const int b = PF ? slot : (resumed ? P.index[slot] : (P.perm ? P.perm[slot] : slot));
             const double* het = nullptr;
             if constexpr (HET) {                               // this instance's own cache (A, B, Q, R, rho differ per instance)
                 het = P.het_tabs + (size_t)b * TAB_BOUNDS;
@@ -1308,18 +1308,18 @@ void admm_solve_kernel(const SolveArgs P) {
                     for (int k = 0; k < NU; ++k) c1[k] = v[k];
                 }
             };
-            if (!P.traj && !(PF && P.ref_shared)) terminal_term();
-            const int traj_k0 = P.traj ? (P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0)) : 0;
+            if (!has_traj && !(PF && P.ref_shared)) terminal_term();
+            const int traj_k0 = has_traj ? (P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0)) : 0;
 
             int iter = 0, solved = 0, checked = 0;
             unsigned acc_iter = 0, acc_solved = 0;
             bool vp_touched = false;                           // v|z differ from what was loaded (a solve that converges at its first check leaves them alone)
             double rp = 0.0, rd = 0.0;
-            const int nsteps = P.steps > 1 ? P.steps : 1;
+            const int nsteps = PF ? 1 : (P.steps > 1 ? P.steps : 1);
             const int iter_first = resumed ? P.iter_base : 0;  // (a multiple of check_termination: the countdown restarts in phase)
             for (int step = 0; step < nsteps; ++step) {        // closed-loop MPC steps fused in one launch
                 X[0] = x0v;                                    // work->x.col(0) = x0
-                if (P.traj) {                                  // work->Xref = Xref_total.block(0, k, nx, N)
+                if (has_traj) {                                // work->Xref = Xref_total.block(0, k, nx, N)
                     if (is_state) {
 #pragma unroll
                         for (int s = 0; s < N; ++s) {
@@ -1786,6 +1786,38 @@ void admm_solve_kernel(const SolveArgs P) {
             }
 
             // ---- write back (coalesced) -------------------------------------------------------
+            // FLS: every store instruction writes WHOLE knot segments [x_s ; u_s] (128 bytes = one cache line at nx+nu = 16).  The slot
+            // convention -- input lanes hold knot s-1 at slot s -- otherwise makes a store write 96 bytes of one line and 32 of the line
+            // before it: partial-line stores, and HBM takes those at three quarters of the rate of whole lines (tools/ubench/
+            // ubench_stream_forms.hip -DSLOT_MAJOR=1 -DSPLIT_LINES=1: the copy pattern of a warm solve 5.7 -> 4.4 TB/s, and the
+            // PREFETCH form turns from 20 % faster than one tile per wave into 7 % slower).  So the input lanes store the value of their
+            // NEXT slot into the segment of the state lanes' slot; the input cells of the last knot (no u_{N-1}: never read, zero since
+            // the records were allocated) are written as zero.  Same values at the same addresses: bit-identical records.
+            constexpr bool FLS = TINYMPC_FULL_LINE_STORES != 0 && (PF || TINYMPC_FULL_LINE_STORES == 2) && !SOC && LIN == 0 && !DBG;
+            if (FLS && (P.store_mask & 32) == 0) {
+                if constexpr (FLS) {
+                    const size_t seg = (size_t)b * (N * NZ) + j;
+                    const bool in_row = j < NZ;
+#pragma unroll
+                    for (int s = 0; s < N; ++s) {
+                        const size_t off = seg + s * NZ;
+                        const double xs = is_input ? (s + 1 < N ? X[s + 1 < N ? s + 1 : s] : 0.0) : X[s];
+                        const double vs = is_input ? (s + 1 < N ? VN[s + 1 < N ? s + 1 : s] : 0.0) : VN[s];
+                        const double gs = is_input ? (s + 1 < N ? G[s + 1 < N ? s + 1 : s] : 0.0) : G[s];
+                        const double ps = is_input ? (s + 1 < N ? VP[s + 1 < N ? s + 1 : s] : 0.0) : VP[s];
+                        if (in_row) {
+                            if (P.store_mask & 1) {
+                                // max_iter = 0: the sweeps never ran, x[:,1:] and u keep what they held (only x[:,0] = x0 is set)
+                                if (acc_iter > 0) { if constexpr (PF) P.prim[off] = xs; else store_primal(P.prim + off, xs); }
+                                else if (s == 0 && is_state) P.prim[off] = xs;
+                            }
+                            if (P.store_mask & 2) P.slack[off] = vs;
+                            if (P.store_mask & 4) P.dual[off] = gs;
+                            if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = ps;   // admm.cpp:431-441 returns before v = vnew
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int s = 0; s < N; ++s) {
                 const bool valid = is_state || (is_input && s >= 1);

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -216,10 +217,22 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
     const size_t kpi_bytes = (size_t)batch * N * nz * sizeof(double);
     // (+ one record and a little of zero padding: the tile kernel's VPG forms park the stores of lanes that hold no row there)
     const size_t kpi_pad = (size_t)N * nz * sizeof(double) + 1024;
+    // ONE slab for the seven record arrays, each array's start SKEWED against its neighbours' (round 6): a launch touches the same
+    // offset of five of them at the same time -- the records of one tile --, and arrays that hipMalloc places a multiple of a large power
+    // of two apart send those accesses to the same HBM channels.  TINYMPC_KPI_SKEW (bytes, a multiple of 256; experiments) overrides the stagger
     double** kpis[] = {&b->d_ref, &b->d_prim, &b->d_slack, &b->d_dual, &b->d_slack_prev, &b->d_cslack, &b->d_cdual};
-    for (double** p : kpis) {
-        if (hipMalloc(p, kpi_bytes + kpi_pad) != hipSuccess) return bail(TINY_ERR_HIP);
-        if (hipMemsetAsync(*p, 0, kpi_bytes + kpi_pad, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    size_t skew = KPI_SKEW_BYTES;
+    if (const char* e = getenv("TINYMPC_KPI_SKEW")) skew = (size_t)strtoull(e, nullptr, 10) & ~(size_t)255;
+    const size_t gap = ((kpi_bytes + kpi_pad + 255) & ~(size_t)255) + skew;
+    if (getenv("TINYMPC_KPI_SEPARATE")) {             // (experiment: one allocation per array, as before round 6; leaked at destroy)
+        for (int i = 0; i < 7; ++i) {
+            if (hipMalloc(kpis[i], gap) != hipSuccess) return bail(TINY_ERR_HIP);
+            if (hipMemsetAsync(*kpis[i], 0, gap, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+        }
+    } else {
+    if (hipMalloc(&b->d_kpi_slab, 7 * gap) != hipSuccess) return bail(TINY_ERR_HIP);
+    if (hipMemsetAsync(b->d_kpi_slab, 0, 7 * gap, b->stream) != hipSuccess) return bail(TINY_ERR_HIP);
+    for (int i = 0; i < 7; ++i) *kpis[i] = (double*)((char*)b->d_kpi_slab + (size_t)i * gap);
     }
     b->stage_doubles = (size_t)batch * std::max(nx * N, nu * (N - 1));       // the largest host-layout field (nu > nx happens)
     // (+ 1 KiB: the PREFETCH form's LDS-DMA pieces are 1 KiB each and the last tile's reach past the end of x0 -- and of the record
@@ -324,7 +337,7 @@ int tiny_batch_destroy(TinyBatch* b) {
     if (!b) return TINY_ERR_NULL;
     hipSetDevice(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
-    void* bufs[] = {b->d_ref, b->d_prim, b->d_slack, b->d_dual, b->d_slack_prev, b->d_cslack, b->d_cdual, b->d_x0,
+    void* bufs[] = {b->d_kpi_slab, b->d_x0,
                     b->d_stage, b->d_status, b->d_resid, b->d_stats, b->d_tab, b->d_dbg_qr, b->d_dbg_pd, b->d_accum,
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
@@ -751,7 +764,6 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
     else if (!strcmp(name, "prefetch")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "prefetch: -1 (by rule), 0 (never), 1 (wherever the form exists)"); b->prefetch = (int)value; }
-    else if (!strcmp(name, "prefetch_vz")) b->prefetch_vz = value != 0 ? 1 : 0;
     else if (!strcmp(name, "prefetch_static")) { if (value < 0 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100"); b->prefetch_static = (int)value; }
     else if (!strcmp(name, "prefetch_waves")) { if (value < 0) return fail(b, TINY_ERR_ARG, "prefetch_waves >= 0"); b->prefetch_waves = (int)value; }
     else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
@@ -888,6 +900,8 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "auto_split_permille")) return (long)(b->auto_gain * 1000.0 + 0.5);
     if (!strcmp(name, "auto_split_verdict")) return b->auto_verdict;
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
+    if (!strcmp(name, "last_prefetch_grid")) return b->last_pf_grid;         // ... its persistent grid (waves) and its tile buffer (bytes of dynamic LDS)
+    if (!strcmp(name, "last_prefetch_lds")) return (long)b->last_pf_lds;
     if (!strcmp(name, "last_prefetch")) return b->last_prefetch ? 1 : 0;     // the last one-row launch (a split solve: its first stage) took the PREFETCH form
     if (!strcmp(name, "last_half_rows")) return b->last_half ? 1 : 0;       // the last one-row launch took the HALF form (two instances per DPP row)
     if (!strcmp(name, "last_tile_form")) return b->last_tile_form;          // W * 1e6 + R * 1e3 + LM of the tile_dims.txt entry the last tile launch took (-1: run-time instantiated)

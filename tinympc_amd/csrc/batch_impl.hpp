@@ -24,6 +24,7 @@ struct Settings {              // TinySettings (types.hpp:63-82) hot-path subset
 
 }  // namespace tinympc_amd
 
+constexpr size_t KPI_SKEW_BYTES = 0;             // stagger between the starts of the record arrays inside their slab (see tiny_batch_setup)
 struct TinyBatch {
     int nx = 0, nu = 0, N = 0, batch = 0, device = 0, num_cus = 256;
     const tinympc_amd::KernelEntry* kernel = nullptr;
@@ -67,6 +68,7 @@ struct TinyBatch {
     double *d_tab = nullptr, *d_x0 = nullptr, *d_ref = nullptr, *d_prim = nullptr, *d_slack = nullptr,
            *d_dual = nullptr, *d_slack_prev = nullptr, *d_cslack = nullptr, *d_cdual = nullptr, *d_resid = nullptr,
            *d_stage = nullptr, *d_stats = nullptr, *d_dbg_qr = nullptr, *d_dbg_pd = nullptr;
+    void* d_kpi_slab = nullptr;                  // the allocation behind d_ref ... d_cdual (batch_api.hip: skewed starts)
     int4* d_status = nullptr;
     uint2* d_accum = nullptr;
     double *d_lslack = nullptr, *d_ldual = nullptr, *d_tlslack = nullptr, *d_tldual = nullptr, *d_gtab = nullptr;
@@ -130,14 +132,15 @@ struct TinyBatch {
     // PREFETCH form of the one-row kernel (round 6; admm_kernel.hip.h PF): persistent waves that draw their tiles from a ticket counter
     // and whose NEXT tile's records travel into the wave's LDS buffer (LDS-DMA) while the current one iterates.  Option "prefetch":
     // -1 (default) every plain single-step launch of a batch of at least PF_AUTO_MIN_TILES tiles per resident wave and the first stage
-    // of a split solve; 0 never; 1 wherever the form exists (any batch size: tests).  "prefetch_vz": a launch whose instances have
-    // their OWN reference records moves v|z through the buffer too (1: four arrays, seven waves per CU at (12,4,10)) or reads it straight
-    // into registers (0, the default: its first use is the first termination test).  "prefetch_waves": cap on the persistent grid (0: what is resident)
-    int prefetch = -1, prefetch_vz = 0, prefetch_waves = 0;
+    // of a split solve; 0 never; 1 wherever the form exists (any batch size: tests).  "prefetch_waves": cap on the persistent grid
+    // (0: what is resident)
+    int prefetch = -1, prefetch_waves = 0;
     int prefetch_static = 75;            // option "prefetch_static": percent of a wave's tiles it takes by grid stride (the rest by ticket)
     unsigned* d_pf_counter = nullptr;    // eight ticket counters (64 bytes apart), never reset: a launch draws a known number from each
     unsigned pf_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // where the next launch's tickets begin, per shard
     bool last_prefetch = false;          // the last one-row launch (a split solve: its first stage) took the form
+    int last_pf_grid = 0;
+    size_t last_pf_lds = 0;
     const void* pf_occ_kernel = nullptr; // residency of the form's kernel at pf_occ_lds bytes of dynamic LDS (asked once)
     size_t pf_occ_lds = 0;
     int pf_occ = 0;

@@ -19,6 +19,7 @@
 #include <map>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -112,16 +113,32 @@ struct Ctx {
     double* d_xfer = nullptr;
     size_t xfer_doubles = 0;
     hipEvent_t ev[8] = {};         // download groups of a large solve_group: the scatter of a group starts when ITS copy has landed
+    // Round 6: a context is locked by the call that uses it, not the process.  The reference's tiny_solve on DISTINCT solvers is
+    // re-entrant (its only global is the print format, tiny_api.cpp:11); so is this one: every context has its own TinyBatch, stream,
+    // staging buffers -- and this mutex.  Two threads on the SAME solver serialise here (the reference would race).
+    std::mutex mu;
 };
-void release(Ctx& c) {
-    for (hipEvent_t& e : c.ev) if (e) (void)hipEventDestroy(e);
+void release(Ctx& c) {             // (c.mu held, or the context unreachable)
+    for (hipEvent_t& e : c.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (c.b) tiny_batch_destroy(c.b);
     if (c.h_pin) hipHostFree(c.h_pin);
     if (c.d_xfer) hipFree(c.d_xfer);
-    c = Ctx();
+    c.b = nullptr; c.n = c.nx = c.nu = c.N = 0; c.family = 0; c.family_valid = false; c.h_pin = nullptr; c.d_xfer = nullptr; c.xfer_doubles = 0;
 }
-std::map<TinySolver*, Ctx> g_ctx;
+// the map of contexts is all the process-wide lock guards: look-up, insertion, removal (microseconds)
+std::map<TinySolver*, std::shared_ptr<Ctx>> g_ctx;
 std::mutex g_mu;
+std::shared_ptr<Ctx> context_of(TinySolver* s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::shared_ptr<Ctx>& p = g_ctx[s];
+    if (!p) p = std::make_shared<Ctx>();
+    return p;
+}
+void forget_context(TinySolver* s, const std::shared_ptr<Ctx>& c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(s);
+    if (it != g_ctx.end() && it->second == c) g_ctx.erase(it);
+}
 
 int raw_batch(TinyBatch** out, int nx, int nu, int N, int n) {
     // a TinyBatch whose cache is filled from the caller's TinyCache at every solve
@@ -222,10 +239,9 @@ bool is_state_field(TinyField f) {
            f == TINY_F_GL_TV;
 }
 
-// the device context (a TinyBatch of n instances) that backs solver s0; g_mu must be held
-int device_context(TinySolver* s0, int n, TinyBatch** out) {
+// the device context (a TinyBatch of n instances) that backs solver s0; ctx.mu must be held
+int device_context(Ctx& ctx, TinySolver* s0, int n, TinyBatch** out) {
     const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
-    Ctx& ctx = g_ctx[s0];
     // The reference has no destroy function, so a caller may free a solver and tiny_setup() another one of a different
     // shape at the same address: the context is only reused when group size AND (nx, nu, N) still match.
     if (ctx.b && (ctx.n != n || ctx.nx != nx || ctx.nu != nu || ctx.N != N)) release(ctx);
@@ -234,7 +250,7 @@ int device_context(TinySolver* s0, int n, TinyBatch** out) {
         if (rc) {
             fprintf(stderr, "tiny_solve: cannot create the device context for (nx,nu,N)=(%d,%d,%d): error %d "
                             "(libtinympc_amd has no CPU path)\n", nx, nu, N, rc);
-            g_ctx.erase(s0);
+            ctx.b = nullptr;
             return rc;
         }
         ctx.n = n; ctx.nx = nx; ctx.nu = nu; ctx.N = N;
@@ -303,9 +319,11 @@ void parallel_solvers(int n, F&& body) {
     static const int cap = getenv("TINYMPC_AMD_HOST_THREADS") ? std::min(32, std::max(1, atoi(getenv("TINYMPC_AMD_HOST_THREADS")))) : 16;
     const int nt = (n < 512) ? 1 : (int)std::min<unsigned>((unsigned)cap, std::max(1u, hw / 2));
     if (nt <= 1) { body(0, n, 0); return; }
-    // (callers hold g_mu: one batch call at a time.)  The parked threads belong to the process that created them: a fork()ed
+    // (ONE pool for the process: concurrent large groups take turns at it -- pool_mu.)  The parked threads belong to the process that created them: a fork()ed
     // child has none of them, and waiting on pending_ there would never end -- so the pool is per pid; the parent's pool object
     // is abandoned in the child (its threads do not exist there: joining them would hang as well).
+    static std::mutex pool_mu;
+    std::lock_guard<std::mutex> pool_lk(pool_mu);
     static WorkerPool* pool_ptr = nullptr;
     static pid_t pool_pid = 0;
     if (!pool_ptr || pool_pid != getpid()) { pool_ptr = new WorkerPool(cap - 1); pool_pid = getpid(); }
@@ -343,26 +361,27 @@ uint64_t family_hash(const TinySolver* s) {
     return h;
 }
 
-int solve_group_locked(TinySolver** solvers, int n, TinyBatch** bout);
+int solve_group_locked(Ctx& ctx, TinySolver** solvers, int n, TinyBatch** bout);
 // Every error return of the body below may leave asynchronous copies into the context's pinned / transfer buffers in flight
 // (uploads before the solve, the event-ordered downloads after it); the next call reuses those buffers, so a failed call
 // drains the stream (best effort) before it reports.
 int solve_group(TinySolver** solvers, int n) {
     if (!solvers || n <= 0 || !solvers[0]) return TINY_ERR_NULL;
-    std::lock_guard<std::mutex> lk(g_mu);
+    const std::shared_ptr<Ctx> ctx = context_of(solvers[0]);
+    std::lock_guard<std::mutex> lk(ctx->mu);
     TinyBatch* b = nullptr;
-    const int rc = solve_group_locked(solvers, n, &b);
+    const int rc = solve_group_locked(*ctx, solvers, n, &b);
+    if (!ctx->b) forget_context(solvers[0], ctx);       // (no device context could be made: nothing to keep)
     if (rc != TINY_OK && b && b->stream)      // (1 = max_iter reached shares its value with TINY_ERR_DIM: the stream is idle then, the call is free)
         { (void)hipStreamSynchronize(b->stream); (void)hipGetLastError(); }
     return rc;
 }
-int solve_group_locked(TinySolver** solvers, int n, TinyBatch** bout) {
+int solve_group_locked(Ctx& ctx, TinySolver** solvers, int n, TinyBatch** bout) {
     TinySolver* s0 = solvers[0];
     const int nx = s0->work->nx, nu = s0->work->nu, N = s0->work->N;
     TinyBatch* b = nullptr;
-    if (int rc = device_context(s0, n, &b)) return rc;
+    if (int rc = device_context(ctx, s0, n, &b)) return rc;
     *bout = b;
-    Ctx& ctx = g_ctx[s0];
     const uint64_t fam = family_hash(s0);
     if (!ctx.family_valid || ctx.family != fam) {
         ctx.family_valid = false;
@@ -576,10 +595,11 @@ int solve_group_locked(TinySolver** solvers, int n, TinyBatch** bout) {
 // phase on the GPU, write back the fields that phase writes.  Returns < 0 on error, else the phase's boolean.
 int phase_call(TinySolver* s, int phase) {
     if (!s || !s->work || !s->cache || !s->settings) return -TINY_ERR_NULL;
-    std::lock_guard<std::mutex> lk(g_mu);
+    const std::shared_ptr<Ctx> ctxp = context_of(s);
+    std::lock_guard<std::mutex> lk(ctxp->mu);
     TinyBatch* b = nullptr;
-    if (int rc = device_context(s, 1, &b)) return -rc;
-    g_ctx[s].family_valid = false;                     // the phase path re-uploads the family unconditionally
+    if (int rc = device_context(*ctxp, s, 1, &b)) { forget_context(s, ctxp); return -rc; }
+    ctxp->family_valid = false;                        // the phase path re-uploads the family unconditionally
     if (int rc = sync_family(b, s)) { fprintf(stderr, "tinympc_amd phase: %s\n", b->err); return -rc; }
     TinyWorkspace* w = s->work;
     const TinySettings* st = s->settings;
@@ -919,9 +939,13 @@ TinyVectorPOD* project_hyperplane(TinyVectorPOD* result, const TinyVectorPOD* z,
 int tiny_destroy(TinySolver* solver) {
     if (!solver) return TINY_ERR_NULL;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_ctx.find(solver);
-        if (it != g_ctx.end()) { release(it->second); g_ctx.erase(it); }
+        std::shared_ptr<Ctx> c;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            auto it = g_ctx.find(solver);
+            if (it != g_ctx.end()) { c = it->second; g_ctx.erase(it); }
+        }
+        if (c) { std::lock_guard<std::mutex> lk(c->mu); release(*c); }
     }
     // every matrix member is {data*, ...}: walk the structs as arrays of words would be fragile; free by name
     TinyWorkspace* w = solver->work;

@@ -94,6 +94,31 @@ VARIANTS = {
                                   "                    if (P.store_mask & 2) __builtin_nontemporal_store(VN[s], P.slack + off);\n                    if (P.store_mask & 4) __builtin_nontemporal_store(G[s], P.dual + off);\n                    if ((P.store_mask & 8) && vp_touched) __builtin_nontemporal_store(VP[s], P.slack_prev + off);"),
                                  ("                VN[s] = warm ? P.slack[off] : 0.0;\n                G[s] = warm ? P.dual[off] : 0.0;\n                VP[s] = warm ? P.slack_prev[off] : 0.0;",
                                   "                VN[s] = warm ? __builtin_nontemporal_load(P.slack + off) : 0.0;\n                G[s] = warm ? __builtin_nontemporal_load(P.dual + off) : 0.0;\n                VP[s] = warm ? __builtin_nontemporal_load(P.slack_prev + off) : 0.0;")]),
+    # round 6, the PREFETCH form's own costs (timing only: the accumulated iteration counters come out wrong / unchanged results)
+    "pf_noaccum": ("u_12_4_10", [], [("                    if constexpr (PF) {                      // (no value comes back: a persistent wave must not wait for one here)\n                        __hip_atomic_fetch_add(&P.accum[b].x, acc_iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n                        __hip_atomic_fetch_add(&P.accum[b].y, acc_solved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n                    } else {",
+                                      "                    if constexpr (PF) {\n                    } else {")]),
+    "pf_keep0": ("u_12_4_10", [], [("            else if ((P.store_mask & 6) == 6) asm volatile(\"s_waitcnt vmcnt(%0)\" :: \"n\"(2 * N <= 63 ? 2 * N : 63) : \"memory\");\n", "")]),
+    "pf_rmwaccum": ("u_12_4_10", [], [("                    if constexpr (PF) {                      // (no value comes back: a persistent wave must not wait for one here)", "                    if constexpr (false) {")]),
+    # TLB reach?  a wave's tiles CONTIGUOUS (wave w: tiles w * pf_static ...) instead of grid-strided: valid with prefetch_static = 100 and
+    # tiles = grid * pf_static exactly (65 536 / 2 048)
+    "pf_blocked": ("u_12_4_10", [], [("        if ((int)blockIdx.x < ntiles) {\n            pf_issue((int)blockIdx.x);", "        if ((int)blockIdx.x < ntiles) {\n            pf_issue((int)blockIdx.x * P.pf_static);"),
+                                      ("    for (int tile = blockIdx.x; tile < ntiles;\n         tile = PF ? pf_next", "    for (int tile = PF ? blockIdx.x * P.pf_static : blockIdx.x; tile < ntiles;\n         tile = PF ? pf_next"),
+                                      ("            if (pf_i + 1 < P.pf_static) pf_next = tile + (int)gridDim.x;", "            if (pf_i + 1 < P.pf_static) pf_next = tile + 1;")]),
+    # round 6: what the PREFETCH form's write-back does to the HBM regime (results unchanged in all of them)
+    #   pf_p0: x|u stored with plain stores in the PF form (the plain form keeps its nontemporal ones); + _nt: the LDS-DMA pieces issued
+    #   nontemporal (aux = 2); + _am: write-back array by array instead of slot by slot; + _stag: the waves of a CU start 0 ... 7 x 2 us apart
+    "pf_p0": ("u_12_4_10", [], [("                        else store_primal(P.prim + off, X[s]);", "                        else if constexpr (PF) P.prim[off] = X[s];\n                        else store_primal(P.prim + off, X[s]);")]),
+    "pf_p0_nt": ("u_12_4_10", [], [("                        else store_primal(P.prim + off, X[s]);", "                        else if constexpr (PF) P.prim[off] = X[s];\n                        else store_primal(P.prim + off, X[s]);"),
+                                   ("(pf_lptr)(sPF + at + q * 128), 16, 0, 0);", "(pf_lptr)(sPF + at + q * 128), 16, 0, 2);")]),
+    "pf_p0_stag": ("u_12_4_10", [], [("                        else store_primal(P.prim + off, X[s]);", "                        else if constexpr (PF) P.prim[off] = X[s];\n                        else store_primal(P.prim + off, X[s]);"),
+                                     ("    if constexpr (PF) {\n        if ((int)blockIdx.x < ntiles) {\n            pf_issue(", "    if constexpr (PF) {\n        for (unsigned w = 0; w < ((blockIdx.x >> 8) & 7u) * 32u; ++w) __builtin_amdgcn_s_sleep(127);\n        if ((int)blockIdx.x < ntiles) {\n            pf_issue(")]),
+    "pf_p0_am": ("u_12_4_10", [], [("                        else store_primal(P.prim + off, X[s]);", "                        else if constexpr (PF) { }\n                        else store_primal(P.prim + off, X[s]);"),
+                                   ("                    if (P.store_mask & 2) P.slack[off] = VN[s];\n                    if (P.store_mask & 4) P.dual[off] = G[s];\n                    if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];",
+                                    "                    if constexpr (!PF) {\n                    if (P.store_mask & 2) P.slack[off] = VN[s];\n                    if (P.store_mask & 4) P.dual[off] = G[s];\n                    if ((P.store_mask & 8) && vp_touched) P.slack_prev[off] = VP[s];\n                    }"),
+                                   ("            // ---- write back (coalesced) -------------------------------------------------------\n",
+                                    "            if constexpr (PF) {\n#pragma unroll\n                for (int s = 0; s < N; ++s) { const bool valid = is_state || (is_input && s >= 1); if (valid && (P.store_mask & 2)) P.slack[lbase + s * NZ] = VN[s]; }\n#pragma unroll\n                for (int s = 0; s < N; ++s) { const bool valid = is_state || (is_input && s >= 1); if (valid && (P.store_mask & 4)) P.dual[lbase + s * NZ] = G[s]; }\n#pragma unroll\n                for (int s = 0; s < N; ++s) { const bool valid = is_state || (is_input && s >= 1); if (valid && (P.store_mask & 8) && vp_touched) P.slack_prev[lbase + s * NZ] = VP[s]; }\n#pragma unroll\n                for (int s = 0; s < N; ++s) { const bool valid = is_state || (is_input && s >= 1); if (valid && (P.store_mask & 1) && acc_iter > 0) P.prim[lbase + s * NZ] = X[s]; }\n            }\n            // ---- write back (coalesced) -------------------------------------------------------\n")]),
+    "fls0": ("u_12_4_10", ["-DTINYMPC_FULL_LINE_STORES=0"], []),       # record stores as whole knot segments: never / in every box variant (the default: PF only)
+    "fls2": ("u_12_4_10", ["-DTINYMPC_FULL_LINE_STORES=2"], []),
     # timing-only ablations of the cone kernel (results are WRONG by construction)
     "abl_fwd_nogc": ("u_6_3_10", [], [("gr[(i + 2) % 3] = sC[cw + (i + 2) * SLOT_D + PL_GC];", "gr[(i + 2) % 3] = 0.0;"),
                                      ("                        gr[0] = sC[cw + PL_GC];\n                        if constexpr (N >= 2) gr[1] = sC[cw + SLOT_D + PL_GC];\n",

@@ -26,6 +26,12 @@ __device__ __forceinline__ void dma_tile(const double* in, size_t arr, int tile,
                                              (lptr_t)(buf + a * (4 * REC) + q * 128), 16, 0, 0);
 }
 
+#ifndef KEEP
+#define KEEP (W * N)          // stores of the tile before that may stay in flight at a tile's top (form 2); -DKEEP=20: what the solve kernel allows
+#endif
+#ifndef SLOT_MAJOR
+#define SLOT_MAJOR 0          // 1: the write-back walks the slots and stores every array's cell of a slot (the solve kernel's order)
+#endif
 template <int R, int W, int MODE>
 __global__ __launch_bounds__(64) void stream(const double* __restrict__ in, double* __restrict__ out, int batch, size_t arr, int chain, int reverse) {
     extern __shared__ double buf[];
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(64) void stream(const double* __restrict__ in, doub
             // complete in issue order on gfx9, and the W * N stores of the tile before were issued BEHIND this tile's DMA: they may
             // stay in flight
             if (t == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W * N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
@@ -58,6 +64,23 @@ __global__ __launch_bounds__(64) void stream(const double* __restrict__ in, doub
         }
         double acc = v[0][N - 1] + v[1][N - 1];
         for (int i = 0; i < chain; ++i) acc = fma(acc, 1.0000001, 1e-9);
+#if SLOT_MAJOR
+        // SPLIT_LINES: the solve kernel's lanes -- rows 12-15 (the inputs) hold knot s-1 at slot s, so a store instruction writes 96 bytes
+        // of one 128-byte line and 32 bytes of the line before it
+#ifndef SPLIT_LINES
+#define SPLIT_LINES 0
+#endif
+#pragma unroll
+        for (int s = 0; s < N; ++s)
+#pragma unroll
+            for (int a = 0; a < W; ++a) {
+                const double o = v[a % R][s] + acc;
+                const size_t at = a * arr + rec + s * NZ + j - ((SPLIT_LINES && j >= 12) ? NZ : 0);
+                if (SPLIT_LINES && j >= 12 && s == 0) continue;
+                if (a == 0) __builtin_nontemporal_store(o, out + at);
+                else out[at] = o;
+            }
+#else
 #pragma unroll
         for (int a = 0; a < W; ++a)
 #pragma unroll
@@ -66,6 +89,7 @@ __global__ __launch_bounds__(64) void stream(const double* __restrict__ in, doub
                 if (a == 0) __builtin_nontemporal_store(o, out + a * arr + rec + s * NZ + j);
                 else out[a * arr + rec + s * NZ + j] = o;
             }
+#endif
     }
 }
 
@@ -75,6 +99,9 @@ int main(int argc, char** argv) {
     double *in, *out;
     (void)hipMalloc(&in, 4 * arr * 8); (void)hipMalloc(&out, 4 * arr * 8);
     (void)hipMemset(in, 0, 4 * arr * 8); (void)hipMemset(out, 0, 4 * arr * 8);
+#ifdef IN_PLACE
+    out = in;                 // the solve kernel rewrites the records it read: vnew|znew, g|y (and v|z) in place
+#endif
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     int ncu = 256;
     { hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0); ncu = p.multiProcessorCount; }

@@ -21,6 +21,9 @@ def run():
     s.update_settings(max_iter=h["max_iter"])
     s.set_option("advance_x0", 1)
     s.set_option("share_ref", 0)
+    for kv in filter(None, os.environ.get("WARM_OPTS", "").split(",")):       # e.g. WARM_OPTS=prefetch=0
+        k, v = kv.split("=")
+        s.set_option(k, int(v))
     s.set_x_ref(np.tile(np.array(h["xref"], dtype=np.float64).reshape(nx, 1), (1, N)), broadcast=True)
     s.set_x0(np.array(h["x0"], dtype=np.float64), broadcast=True)
     its = []
