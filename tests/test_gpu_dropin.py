@@ -160,3 +160,23 @@ def test_rho_benchmark_helpers_called_through_their_cxx_names():
         assert num.sub("#", a) == num.sub("#", b), (a[:120], b[:120])        # words, integers, dimensions, flags
         for x, y in zip(num.findall(a), num.findall(b)):
             assert abs(float(x) - float(y)) <= 1e-9 * max(abs(float(y)), 1e-300) + 1e-12, (a[:120], b[:120])
+
+
+def test_tiny_solve_from_eight_threads_on_distinct_solvers():
+    """the reference's tiny_solve on DISTINCT solvers is re-entrant (its only global is the print format,
+    tiny_api.cpp:11).  examples/dropin_threads.c: eight host threads, each on its own TinySolver (two problem families), 200
+    closed-loop steps through tiny_set_x0 / tiny_solve -- iteration totals and final states identical bit for bit to the same episodes
+    run one after the other, no deadlock, and the throughput ratio printed (the drop-in contexts have their own locks since round 6)."""
+    import re
+    exe = os.path.join(ROOT, "examples", "_build", "dropin_threads")
+    if not os.path.exists(exe):
+        pytest.fail("examples/_build/dropin_threads is missing: __graft_entry__.build() produces it")
+    p = subprocess.run([exe, "8", "200"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert sum("== serial" in ln for ln in lines) == 8 and not any("DIFFERS" in ln for ln in lines), p.stdout
+    assert lines[-1] == "OK"
+    m = re.search(r"throughput ratio ([0-9.]+)", p.stdout)
+    assert m and float(m.group(1)) > 0.5, p.stdout                      # (concurrent calls must at least not collapse; the figure goes to profiles/)
+    fams = {re.search(r"\(nx (\d+)", ln).group(1) for ln in lines if ln.startswith("solver")}
+    assert fams == {"4", "6"}
