@@ -159,6 +159,8 @@ def _config_summary(e):
         c["first_call_ms"] = _r(e["first_call_ms"])
     if e.get("planned_first_call_ms") is not None:
         c["planned_first_call_ms"] = _r(e["planned_first_call_ms"])
+    if e.get("plan_shipped"):
+        c["plan"] = "shipped"                            # the first call already ran under tinympc_amd/data/plans.txt's entry
     return c
 
 

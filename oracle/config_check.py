@@ -9,8 +9,9 @@ host core, spawn context: no HIP context is ever forked), this module
   * times the REAL reference (oracle/_ref/libtinympc_ref.so; the oracle when it is absent: kind "port") on the same
     records, about `seconds` of solve time per core and entry, setup / state reset outside the clock -> `cpu_baseline`
 
-Entry kinds: "single" = one cold solve per record (configs 3 and 5); "episode" = a closed loop of `steps` MPC steps with a
-moving state-reference window (config 4: examples/rocket_landing_mpc.cpp:120-135).
+Entry kinds: "single" = one cold solve per record (configs 3 and 5; with `problems`: every record under its OWN problem data); "episode" =
+a closed loop of `steps` MPC steps with a moving state-reference window (config 4: examples/rocket_landing_mpc.cpp:120-135); "tracking"
+= the same with the duals reset before every solve (examples/quadrotor_tracking.cpp:77-106).
 """
 import multiprocessing as mp
 import os
@@ -41,6 +42,28 @@ def _run_one(s, e, r):
     if e["kind"] == "episode":
         tot, it, u0, _ = s.closed_loop_traj(e["x0"][r], e["steps"], e["traj"])
         return it, u0, e["steps"], tot
+    if e["kind"] == "tracking":
+        # examples/quadrotor_tracking.cpp:77-106, step by step: work->Xref = the window k ... k + N - 1 (clamped at the trajectory's end),
+        # work->y = 0, work->g = 0, tiny_set_x0, tiny_solve, x0 <- A x0 + B u[:,0] (+ f)
+        prob, traj, T = e["problem"], np.asarray(e["traj"], dtype=np.float64), e["steps"]
+        A, Bm, f = np.asarray(prob["A"]), np.asarray(prob["B"]), np.asarray(prob["f"]).reshape(-1)
+        N = prob["N"]
+        x = np.array(e["x0"][r], dtype=np.float64)
+        its = np.zeros(T, dtype=np.int32)
+        u0 = np.zeros((T, prob["nu"]))
+        tot = 0
+        for k in range(T):
+            win = np.minimum(np.arange(k, k + N), len(traj) - 1)
+            s["Xref"] = traj[win].T
+            s["g"] = np.zeros_like(s["g"]); s["y"] = np.zeros_like(s["y"])
+            s["x"][:, 0] = x
+            s.solve()
+            it = int(s.get("sol_iter"))
+            its[k] = it if int(s.get("sol_solved")) else -it
+            tot += it
+            u0[k] = s["u"][:, 0]
+            x = A @ x + Bm @ u0[k] + f
+        return its, u0, T, tot
     s.solve()
     it = int(s.get("sol_iter"))
     return np.array([it if int(s.get("sol_solved")) else -it], dtype=np.int32), s["u"][:, 0].copy(), 1, it
@@ -59,22 +82,29 @@ def _worker(args):
         if mine:
             # parity: the oracle on this worker's records, each from the cold state of tiny_setup
             cfg = sc.default_config(e["problem"], **e["cfg_kw"])
-            s = sc.make_solver(OracleSolver, e["problem"], cfg)
-            cold = s.snapshot()
+            own = e.get("problems")                      # per-instance problem data: every record has its own family (its own tiny_setup)
+            s = None if own else sc.make_solver(OracleSolver, e["problem"], cfg)
+            cold = None if own else s.snapshot()
             for r in mine:
-                s.restore(cold)
+                if own:
+                    s = sc.make_solver(OracleSolver, own[r], cfg)
+                else:
+                    s.restore(cold)
                 _prepare(s, e, r)
                 it, u0, _, _ = _run_one(s, e, r)
                 res["iters"].append(it)
                 res["u0"].append(u0)
-            s.close()
+                if own:
+                    s.close()
+            if not own:
+                s.close()
             # CPU baseline: the real reference on the same records, round and round until `seconds` of solve time
             cls = RefSolver if have_ref() else OracleSolver
-            s = sc.make_solver(cls, e["problem"], cfg)
+            s = sc.make_solver(cls, own[mine[0]] if own else e["problem"], cfg)
             cold = s.snapshot()
             k = 0
             while res["busy"] < seconds:
-                r = mine[k % len(mine)]
+                r = mine[0] if own else mine[k % len(mine)]      # (per-instance data: the setup is outside the clock, so one record's family is timed)
                 k += 1
                 s.restore(cold)
                 _prepare(s, e, r)
@@ -119,7 +149,7 @@ def run(spec_path, seconds=1.0, cores=None):
                 busy_max = max(busy_max, r["busy"])
         it = np.array(it); u0 = np.array(u0)
         g_it = np.asarray(e["gpu_iter"]); g_u0 = np.asarray(e["gpu_u0"])
-        if e["kind"] == "episode":                       # GPU logs are [steps, n(, nu)]
+        if e["kind"] in ("episode", "tracking"):         # GPU logs are [steps, n(, nu)]
             g_it = g_it.T; g_u0 = np.transpose(g_u0, (1, 0, 2))
         else:
             g_it = g_it.reshape(n, 1)

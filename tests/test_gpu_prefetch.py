@@ -130,3 +130,52 @@ def test_prefetch_rule_and_what_does_not_take_the_form():
     assert took_prefetch(suite, {"no_tile": 1, "prefetch": 1, "steps_per_launch": 3}) == 0
     assert took_prefetch(suite, {"no_tile": 1, "prefetch": 1, "grid_waves_per_cu": 2}) == 0
     assert took_prefetch(suite, {"no_tile": 1, "prefetch": 0}) == 0
+
+
+def _kernel_dims_shapes():
+    shapes = []
+    with open(os.path.join(os.path.dirname(HERE), "tinympc_amd", "csrc", "kernel_dims.txt")) as f:
+        for line in f:
+            w = line.split("#")[0].split()
+            if len(w) >= 3:
+                shapes.append((int(w[0]), int(w[1]), int(w[2])))
+    return shapes
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dims", _kernel_dims_shapes())
+def test_default_dispatch_of_every_compiled_in_shape_at_a_batch_the_rule_applies_to(dims):
+    """Every kernel_dims.txt shape, a batch large enough for the PREFETCH rule (several tiles per resident wave, cold launch), the
+    library's DEFAULT dispatch, three cold solves in a row (plain probe, split probe, whatever the clock then keeps): the launches
+    finish -- round 6 found the one long-horizon shape with the form, (8,2,30), hanging in its ticketed tiles; the form is now
+    confined to the two-waves-per-SIMD shapes -- and leave the bits of the plain launch (prefetch = 0, no split, no tile form)."""
+    import tinympc_amd as tm
+    nx, nu, N = dims
+    B = 40000
+    prob, rng = tm.random_problem(nx, nu, N)
+    x0 = rng.uniform(-1, 1, (B, nx))
+    xr = np.repeat(rng.uniform(-0.2, 0.2, (B, nx, 1)), N, axis=2)
+
+    def run(opts, n):
+        s = tm.TinyBatchSolver.from_problem(prob, B)
+        s.set_bound_constraints(np.full((nx, 1), -1e17), np.full((nx, 1), 1e17), np.full((nu, 1), -0.5), np.full((nu, 1), 0.5))
+        s.update_settings(max_iter=60)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.set_x0(x0); s.set_x_ref(xr)
+        took = 0
+        for _ in range(n):
+            s.reset()
+            s.solve_async()
+            s.synchronize()
+            took |= int(s.get_option("last_prefetch"))
+        out = (s.status()["iter"].copy(), s.get("u").copy(), s.get("y").copy())
+        s.close()
+        return out, took
+    plain, took0 = run({"prefetch": 0, "repack_after": 0, "no_tile": 1, "plan": 0}, 1)
+    auto, took = run({"plan": 0}, 3)
+    assert took0 == 0
+    if N > 12:
+        assert took == 0, "the PREFETCH form is confined to the two-waves-per-SIMD shapes"
+    for a, b in zip(plain, auto):
+        assert np.array_equal(a, b), dims

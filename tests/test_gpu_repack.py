@@ -285,6 +285,7 @@ def test_an_imported_plan_gives_the_settled_launch_form_on_the_first_solve():
         return dict(iter=st["iter"], solved=st["solved"], x=s.get("x"), u=s.get("u"), g=s.get("g"), v=s.get("v"))
 
     a = make_batch(suite)
+    a.set_option("plan", 0)                                   # (this handle settles by itself: no shipped plan of tinympc_amd/data/plans.txt)
     ms_a = [cold_solve(a) for _ in range(14)]
     plan = a.get_plan()
     f = tm.TinyBatchSolver.plan_fields(plan)
@@ -331,3 +332,46 @@ def test_an_imported_plan_gives_the_settled_launch_form_on_the_first_solve():
     with pytest.raises(tm.TinyMPCError):
         d.set_plan(bytes(tm.PLAN_BYTES))
     d.close()
+
+
+def test_a_fresh_handle_of_a_baseline_shape_takes_the_shipped_plan():
+    """the settled TinyBatchPlans of the BASELINE shapes travel with the library (tinympc_amd/data/plans.txt, written
+    by tools/make_plans.py).  A fresh handle whose shape, settings and batch bucket match an entry launches that entry's form on its
+    FIRST solve (read-back "plan_shipped"); option "plan" = 0, other settings or a batch of another order of magnitude: the handle
+    probes as before.  Results never depend on it."""
+    plans = os.path.join(os.path.dirname(HERE), "tinympc_amd", "data", "plans.txt")
+    entries = [ln.split() for ln in open(plans) if ln.startswith("plan ")]
+    assert len(entries) >= 10 and all(len(e) >= 21 and int(e[20]) == len(e) - 21 for e in entries)
+    key = [e for e in entries if e[1:5] == ["12", "4", "10", "262144"]]
+    assert key and int(key[0][5]) == 100 and int(key[0][7]) in (1, -1)        # config 3's entry: max_iter 100, a settled verdict
+    base = sc.tracking_random_suite(B=2048, seed=99)
+    rep = 128
+    cases = {k: np.concatenate([v] * rep, axis=0) for k, v in base["cases"].items()}
+    suite = dict(base, cases=cases, config=dict(base["config"], max_iter=100))
+
+    def first_solve(opts, settings=None):
+        s = make_batch(suite)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        if settings:
+            s.update_settings(**settings)
+        s.set_x0(cases["x0"]); s.set_x_ref(cases["Xref"]); s.set_u_ref(cases["Uref"])
+        s.solve()
+        st = s.status()
+        out = dict(iter=st["iter"].copy(), u=s.get("u").copy(), shipped=s.get_option("plan_shipped"), k=s.get_option("auto_split_k"),
+                   verdict=s.get_option("auto_split_verdict"))
+        s.close()
+        return out
+    a = first_solve({})
+    b = first_solve({"plan": 0})
+    c = first_solve({}, settings=dict(max_iter=90))
+    assert a["shipped"] == 1 and a["verdict"] == int(key[0][7]) and a["k"] == int(key[0][8])
+    assert b["shipped"] == 0 and b["verdict"] == 0
+    assert c["shipped"] == 0
+    assert np.array_equal(a["iter"], b["iter"]) and np.array_equal(a["u"], b["u"])
+    small = make_batch(sc.tracking_random_suite(B=64, seed=5))
+    cs = sc.tracking_random_suite(B=64, seed=5)["cases"]
+    small.set_x0(cs["x0"]); small.set_x_ref(cs["Xref"]); small.set_u_ref(cs["Uref"])
+    small.solve()
+    assert small.get_option("plan_shipped") == 0               # (the plan of a batch of another order of magnitude is not taken)
+    small.close()

@@ -8,6 +8,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <dlfcn.h>
+#include <string>
+#include <mutex>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -763,6 +767,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
+    else if (!strcmp(name, "plan")) { b->plan_opt = value != 0 ? 1 : 0; if (!b->plan_opt) b->plan_tried = true; }
     else if (!strcmp(name, "prefetch")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "prefetch: -1 (by rule), 0 (never), 1 (wherever the form exists)"); b->prefetch = (int)value; }
     else if (!strcmp(name, "prefetch_static")) { if (value < 0 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100"); b->prefetch_static = (int)value; }
     else if (!strcmp(name, "prefetch_waves")) { if (value < 0) return fail(b, TINY_ERR_ARG, "prefetch_waves >= 0"); b->prefetch_waves = (int)value; }
@@ -772,7 +777,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "auto_cold")) b->auto_cold = value != 0;       // 0: always read the warm-start records, also right after a reset
     else if (!strcmp(name, "uniform_bounds")) b->use_ub = value != 0;
     else if (!strcmp(name, "one_shot")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "one_shot: 0, 1 or 2"); b->one_shot = (int)value; }
-    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_copy.clear(); b->hist_pending = false; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; }
+    else if (!strcmp(name, "repack_after")) { if (value < -1) return fail(b, TINY_ERR_ARG, "repack_after: K > 0, 0 (never) or -1 (automatic)"); b->repack_after = (int)value; b->auto_cap = 0; b->hist_copy.clear(); b->hist_pending = false; b->auto_verdict = 0; b->growth_verdict = 0; b->auto_plain_rate = b->auto_split_rate = 0.0; b->auto_probes = 0; if (value < 0 && b->plan_opt) { b->plan_tried = false; b->plan_shipped = false; } }    // (automatic again: the shipped plan is looked up afresh)
     else if (!strcmp(name, "repack_waves_per_cu")) b->repack_waves_per_cu = (int)std::max(1L, value);
     else if (!strcmp(name, "repack_growth")) { b->repack_growth = (int)value; b->growth_verdict = 0; }
     else if (!strcmp(name, "repack_sort")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "repack_sort: 1, 0 or -1 (automatic)"); b->repack_sort = (int)value; }
@@ -902,6 +907,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
     if (!strcmp(name, "last_prefetch_grid")) return b->last_pf_grid;         // ... its persistent grid (waves) and its tile buffer (bytes of dynamic LDS)
     if (!strcmp(name, "last_prefetch_lds")) return (long)b->last_pf_lds;
+    if (!strcmp(name, "plan_shipped")) return b->plan_shipped ? 1 : 0;        // a plan of data/plans.txt was imported at the first solve
     if (!strcmp(name, "last_prefetch")) return b->last_prefetch ? 1 : 0;     // the last one-row launch (a split solve: its first stage) took the PREFETCH form
     if (!strcmp(name, "last_half_rows")) return b->last_half ? 1 : 0;       // the last one-row launch took the HALF form (two instances per DPP row)
     if (!strcmp(name, "last_tile_form")) return b->last_tile_form;          // W * 1e6 + R * 1e3 + LM of the tile_dims.txt entry the last tile launch took (-1: run-time instantiated)
@@ -952,19 +958,30 @@ int tiny_batch_set_plan(TinyBatch* b, const TinyBatchPlan* in) {
         return fail(b, TINY_ERR_ARG, "not a TinyBatchPlan of this library version");
     if (in->nx != b->nx || in->nu != b->nu || in->N != b->N)
         return fail(b, TINY_ERR_DIM, "the plan was made for (nx,nu,N)=(%d,%d,%d), this batch is (%d,%d,%d)", in->nx, in->nu, in->N, b->nx, b->nu, b->N);
-    if (in->auto_verdict < -1 || in->auto_verdict > 1 || in->tile_verdict < -1 || in->tile_verdict > 1 || in->regroup_verdict < -1 || in->regroup_verdict > 1 ||
-        in->auto_cap < 0 || in->auto_cap >= TinyBatch::HIST_BINS || (in->auto_growth != 2 && in->auto_growth != 4) || !(in->auto_plain_rate >= 0.0) || !(in->auto_split_rate >= 0.0))
+    // every field is checked (a plan is a POD read from a file): verdicts in {-1, 0, 1}, counts non-negative, clock
+    // readings finite and non-negative.  A plan is advice only -- results never depend on it -- but a corrupt one must not pin a launch form
+    auto verdict = [](int v) { return v >= -1 && v <= 1; };
+    auto rate = [](double v) { return v >= 0.0 && v < 1e300; };
+    if (!verdict(in->auto_verdict) || !verdict(in->tile_verdict) || !verdict(in->regroup_verdict) || !verdict(in->growth_verdict) ||
+        in->auto_cap < 0 || in->auto_cap >= TinyBatch::HIST_BINS || (in->auto_growth != 2 && in->auto_growth != 4) || in->auto_cap_max_iter < 0 ||
+        in->auto_probes < 0 || in->batch <= 0 || !rate(in->auto_plain_rate) || !rate(in->auto_split_rate) || !rate(in->auto_gain) || !rate(in->tile_rate) ||
+        !rate(in->lockstep_ratio) || (in->hist_valid != 0 && in->hist_valid != 1))
         return fail(b, TINY_ERR_ARG, "TinyBatchPlan: field out of range");
     HIP_TRY(b, hipSetDevice(b->device));
     // (a plan is advice about launch forms, never about results: every form is bit-identical.  It applies to solves with the
     // max_iter it was made for -- auto_cap_max_iter -- exactly as a plan learnt in this process would)
-    b->auto_verdict = in->auto_verdict; b->auto_cap = in->auto_cap; b->auto_cap_max_iter = in->auto_cap_max_iter;
-    b->auto_growth = in->auto_growth; b->growth_verdict = in->growth_verdict; b->auto_probes = std::max(2, in->auto_probes);
+    // A verdict whose supporting clock reading is missing, or that was made under other settings than the handle's, counts as OPEN
+    const bool same_settings = in->max_iter == b->set.max_iter && in->check_termination == b->set.check_termination;
+    const bool far_batch = in->batch > 4L * b->batch || b->batch > 4L * in->batch;       // (the plan of a batch of another order of magnitude)
+    b->auto_verdict = (same_settings && !far_batch && in->auto_plain_rate > 0.0 && (in->auto_verdict != 1 || in->auto_split_rate > 0.0)) ? in->auto_verdict : 0;
+    b->auto_cap = in->auto_cap; b->auto_cap_max_iter = in->auto_cap_max_iter;
+    b->auto_growth = in->auto_growth; b->growth_verdict = b->auto_verdict == 1 ? in->growth_verdict : 0; b->auto_probes = std::max(2, in->auto_probes);
     b->auto_plain_rate = in->auto_plain_rate; b->auto_split_rate = in->auto_split_rate; b->auto_gain = in->auto_gain;
-    b->tile_verdict = in->tile_verdict; b->tile_rate = in->tile_rate;
-    b->regroup_verdict = in->regroup_verdict; b->lockstep_ratio = in->lockstep_ratio;
+    b->tile_verdict = (same_settings && !far_batch && (in->tile_verdict != 1 || in->tile_rate > 0.0)) ? in->tile_verdict : 0; b->tile_rate = in->tile_rate;
+    b->regroup_verdict = far_batch ? 0 : in->regroup_verdict; b->lockstep_ratio = in->lockstep_ratio;
     if (in->hist_valid) b->hist_copy.assign(in->hist, in->hist + TinyBatch::HIST_BINS); else b->hist_copy.clear();
     b->auto_since = b->tile_since = b->regroup_since = 0;
+    b->plan_tried = true;                            // (an imported plan stands: the shipped one is not looked up behind it)
     b->hist_pending = false; b->ls_pending = false; b->probe_was_tile = false; b->probe_was_growth = false; b->auto_last_cap = 0;
     // what the first launch of an imported form would otherwise allocate inside its solve call
     if (b->auto_verdict == 1 && b->auto_cap > 0) {
@@ -974,6 +991,70 @@ int tiny_batch_set_plan(TinyBatch* b, const TinyBatchPlan* in) {
     if (b->regroup_verdict == 1) { if (int rc = ensure_regroup_buffers(b, true)) return rc; }
     return TINY_OK;
 }
+
+}  // extern "C"
+namespace tinympc_amd {
+// ---- shipped plans: tinympc_amd/data/plans.txt next to the library (or TINYMPC_AMD_PLANS=<file>; "0": none) ---------------------------
+// one plan per line, written by tools/make_plans.py from tiny_batch_get_plan of settled handles:
+//   plan nx nu N batch max_iter check_termination auto_verdict auto_cap auto_cap_max_iter auto_growth growth_verdict auto_probes
+//        tile_verdict regroup_verdict auto_plain_rate auto_split_rate auto_gain tile_rate lockstep_ratio nhist i:count ...
+static const std::vector<TinyBatchPlan>& shipped_plans() {
+    static std::vector<TinyBatchPlan> plans;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::string path;
+        if (const char* e = getenv("TINYMPC_AMD_PLANS")) path = e;
+        else {
+            Dl_info info;
+            if (dladdr(reinterpret_cast<const void*>(&tiny_batch_setup), &info) && info.dli_fname) {
+                path = info.dli_fname;
+                const size_t cut = path.find_last_of('/');
+                path = (cut == std::string::npos ? std::string(".") : path.substr(0, cut)) + "/data/plans.txt";
+            }
+        }
+        if (path.empty() || path == "0") return;
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return;
+        char word[16];
+        while (fscanf(f, "%15s", word) == 1) {
+            if (strcmp(word, "plan") != 0) { int c; while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }      // comments, unknown lines
+            TinyBatchPlan p;
+            memset(&p, 0, sizeof(p));
+            p.magic = TINY_PLAN_MAGIC; p.version = TINY_PLAN_VERSION; p.bytes = (int)sizeof(TinyBatchPlan);
+            int nh = 0;
+            if (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %lf %lf %lf %lf %lf %d", &p.nx, &p.nu, &p.N, &p.batch, &p.max_iter, &p.check_termination,
+                       &p.auto_verdict, &p.auto_cap, &p.auto_cap_max_iter, &p.auto_growth, &p.growth_verdict, &p.auto_probes, &p.tile_verdict, &p.regroup_verdict,
+                       &p.auto_plain_rate, &p.auto_split_rate, &p.auto_gain, &p.tile_rate, &p.lockstep_ratio, &nh) != 20) break;
+            bool ok = nh >= 0 && nh <= 1024;
+            for (int i = 0; i < nh && ok; ++i) {
+                int bin = 0; unsigned cnt = 0;
+                ok = fscanf(f, "%d:%u", &bin, &cnt) == 2 && bin >= 0 && bin < 1024;
+                if (ok) p.hist[bin] = cnt;
+            }
+            if (!ok) break;
+            p.hist_valid = nh > 0 ? 1 : 0;
+            plans.push_back(p);
+        }
+        fclose(f);
+    });
+    return plans;
+}
+bool apply_shipped_plan(TinyBatch* b) {
+    const TinyBatchPlan* best = nullptr;
+    double best_d = 1e300;
+    for (const TinyBatchPlan& p : shipped_plans()) {
+        if (p.nx != b->nx || p.nu != b->nu || p.N != b->N || p.max_iter != b->set.max_iter || p.check_termination != b->set.check_termination) continue;
+        if (p.batch > 2L * b->batch || b->batch > 2L * p.batch) continue;                 // the batch bucket: within a factor of two
+        const double d = std::fabs(std::log((double)p.batch / (double)b->batch));
+        if (d < best_d) { best_d = d; best = &p; }
+    }
+    if (!best) return false;
+    if (tiny_batch_set_plan(b, best) != TINY_OK) { b->err[0] = 0; return false; }
+    b->plan_shipped = true;
+    return true;
+}
+}  // namespace tinympc_amd
+extern "C" {
 
 int tiny_batch_kernel_path(TinyBatch* b) {
     if (!b) return TINY_ERR_NULL;

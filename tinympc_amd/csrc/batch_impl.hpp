@@ -139,6 +139,13 @@ struct TinyBatch {
     unsigned* d_pf_counter = nullptr;    // eight ticket counters (64 bytes apart), never reset: a launch draws a known number from each
     unsigned pf_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // where the next launch's tickets begin, per shard
     bool last_prefetch = false;          // the last one-row launch (a split solve: its first stage) took the form
+    // shipped plans (round 6): the settled TinyBatchPlans of the BASELINE shapes travel with the library (tinympc_amd/data/plans.txt); a
+    // fresh handle whose shape, settings and batch bucket match one takes its launch form on the FIRST solve instead of probing.
+    // Option "plan" = 0: off.  Read-back "plan_shipped"
+    int plan_opt = 1;
+    bool helpers_loaded = false;          // batch_dispatch.hip preload_helper_kernels
+    const void* loaded_kernel = nullptr;  // the kernel whose code object this handle has asked for last (hipFuncGetAttributes in front of a first launch)
+    bool plan_tried = false, plan_shipped = false;
     int last_pf_grid = 0;
     size_t last_pf_lds = 0;
     const void* pf_occ_kernel = nullptr; // residency of the form's kernel at pf_occ_lds bytes of dynamic LDS (asked once)
@@ -196,6 +203,7 @@ struct TinyBatch {
 namespace tinympc_amd {
 int fail(TinyBatch* b, int code, const char* fmt, ...);
 int launch_solve(TinyBatch* b);
+bool apply_shipped_plan(TinyBatch* b);               // batch_api.hip: the matching entry of data/plans.txt, if any, imported into a fresh handle
 int xfer_fields(TinyBatch* b, const TinyField* fields, const size_t* offsets, int n, double* d_buf, bool to_device,
                 bool with_status, size_t off_status, size_t off_resid);
 // project_soc (which = 0) / project_hyperplane (1) of an n-vector in device memory, one GPU thread, synchronous
