@@ -292,7 +292,16 @@ int tiny_batch_set_stream(TinyBatch* b, void* hip_stream);      /* run on a call
  * vectors ([n_points][nx] doubles), shared by every instance.  While it is set, the state reference of a solve
  * is the N-knot window starting at (MPC step counter + offsets[instance]); the counter starts at 0, advances by
  * one per MPC step (also inside fused launches) and can be moved with set_option("traj_step", k).  offsets may be
- * NULL; xref_points == NULL switches back to the per-instance Xref records.  Register-resident shapes only. */
+ * NULL; xref_points == NULL switches back to the per-instance Xref records.
+ * What is left in the records DIFFERS by kernel path (tiny_batch_kernel_path tells which one runs):
+ *   - register-resident kernels (one-row, tile): the window lives in registers; the Xref records keep what the caller set, and
+ *     "one_shot" writes only the records its store mask names (g|y, v|z stay as they were);
+ *   - coverage kernel (overlapping cones, no hipRTC): every windowed launch WRITES the window of its last MPC step into the Xref
+ *     records (they are per-instance from then on: after set_reference_trajectory(NULL) they hold that window, not the caller's
+ *     earlier reference -- set Xref again), and a "one_shot" launch rewrites EVERY warm-start record (prim, slack, dual,
+ *     slack_prev, cone and half-space slacks) with the state the solve ended in.
+ * A caller that leaves one_shot / windowed mode and must not depend on the path resets the batch (tiny_batch_reset) or sets Xref
+ * and the warm-start fields it relies on. */
 int tiny_batch_set_reference_trajectory(TinyBatch* b, const double* xref_points, int n_points, const int* offsets, int flags);
 /* After a launch with "steps_per_launch" = T > 1 and "step_log" = 1: per fused MPC step and instance,
  * iters[T][batch] (negative = that solve hit max_iter) and the applied control u0[T][batch][nu]. */

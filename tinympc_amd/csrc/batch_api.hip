@@ -309,6 +309,7 @@ int tiny_batch_setup_hetero(TinyBatch** out, const double* Adyn, const double* B
     for (size_t i = 0; i < B; ++i)
         if (its[i] < 0) { fail(b, TINY_ERR_ARG, "singular R + B'PB for instance %zu", i); return bail(TINY_ERR_ARG); }
     b->hetero = true;
+    b->het_tab_cols = tab_cols; b->het_tab_lw = tab_lw;      // (the launch checks the kernel it is about to run against this layout: ADVICE r05)
     return TINY_OK;
 }
 

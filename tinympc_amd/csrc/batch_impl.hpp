@@ -143,6 +143,9 @@ struct TinyBatch {
     // fresh handle whose shape, settings and batch bucket match one takes its launch form on the FIRST solve instead of probing.
     // Option "plan" = 0: off.  Read-back "plan_shipped"
     int plan_opt = 1;
+    // layout of d_het_tabs as tiny_batch_setup_hetero built it (columns x lanes per column: 16 x 16 one-row kernel, 32 x 16 W tile kernel);
+    // a launch whose kernel reads another layout is refused instead of reading the tables with the wrong stride
+    int het_tab_cols = 0, het_tab_lw = 0;
     bool helpers_loaded = false;          // batch_dispatch.hip preload_helper_kernels
     const void* loaded_kernel = nullptr;  // the kernel whose code object this handle has asked for last (hipFuncGetAttributes in front of a first launch)
     bool plan_tried = false, plan_shipped = false;

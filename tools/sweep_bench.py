@@ -26,6 +26,7 @@ import tinympc_amd as tm  # noqa: E402
 from tinympc_amd.distributed import shard_indices  # noqa: E402
 
 PARITY = None                                         # --parity: list of samples (one per cell)
+UNIFORM = 0                                           # --uniform K: see run_cell
 RANK = int(os.environ.get("RANK", "0"))
 LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
 WORLD = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,6 +90,13 @@ def run_cell(nx, nu, N, B, reps):
     s.update_settings(max_iter=500)
     x0 = rng.uniform(-1, 1, (B, nx))
     xr = np.repeat(rng.uniform(-0.2, 0.2, (B, nx, 1)), N, axis=2)
+    if UNIFORM > 0:
+        # --uniform K: the instruction path of ONE iteration, measured -- tolerances 0 (no solve ever passes its test: every instance runs
+        # exactly K iterations, every row of every wave is busy, no lock step, no split, no tails) -- for tools/sweep_counters.py /
+        # sweep_ceiling.py under rocprofv3 --pmc SQ_INSTS_VALU: instructions per wave-iteration = the kernel's real loop length
+        s.update_settings(abs_pri_tol=0.0, abs_dua_tol=0.0, max_iter=UNIFORM)
+        s.set_option("repack_after", 0)
+        s.set_option("plan", 0)
     best = None
     s.set_x0(x0)                                      # inputs resident before the timed solves (reset() keeps x0 and the references):
     s.set_x_ref(xr)                                   # a 200 MB upload in front of every solve lets the GPU clock down first
@@ -121,6 +129,62 @@ def run_cell(nx, nu, N, B, reps):
                 auto_split_k=auto_k, auto_split_predicted=auto_pm / 1000.0, iter_histogram={int(v): int(c) for v, c in zip(hv, hc)})
 
 
+def hetero_parity(args):
+    """full-batch evidence for the round-5 per-instance-data forms of the tile kernel (tiny_api.cpp:307-381 once per
+    INSTANCE).  tools/bench_configs.py hetero_cell builds the batch (A x (1 + N(0, 1e-3)), B x (1 + N(0, 0.05)), rho x U(0.8, 1.2) per
+    instance) and the sample; oracle/config_check.py solves every sampled instance under its own problem data."""
+    import pickle
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_configs as bc
+    cells = ([tuple(int(v) for v in c.split(",")) for c in args.cells.split(";")] if args.cells else
+             [(nx, nu, N) for nx in (4, 8, 12, 20) for nu in (2, 4, 8) for N in (10, 30, 50) if nx + nu > 16 or N == 50])
+    rows, specs = [], []
+    print("| nx | nu | N | kernel | ms | it/solve | solved | FP64 frac |")
+    print("|---|---|---|---|---|---|---|---|")
+    for nx, nu, N in cells:
+        try:
+            e, spec = bc.hetero_cell(nx, nu, N, B=args.batch)
+        except Exception as ex:                        # noqa: BLE001
+            rows.append(dict(nx=nx, nu=nu, N=N, error=repr(ex)))
+            print("| %d | %d | %d | error: %s |" % (nx, nu, N, repr(ex)[:120]), flush=True)
+            continue
+        rows.append(dict(nx=nx, nu=nu, N=N, kernel=e["kernel"], ms=e["ms"], iters_per_solve=e["iters_per_solve"], solved_fraction=e.get("solved_fraction"),
+                         fp64_frac=e["roofline"]["frac"], name=spec["name"]))
+        specs.append(spec)
+        print("| %d | %d | %d | %s | %.3f | %.1f | %.3f | %.3f |" % (nx, nu, N, e["kernel"], e["ms"], e["iters_per_solve"], e.get("solved_fraction") or 0.0, e["roofline"]["frac"]), flush=True)
+    spec_path = os.path.join(tempfile.mkdtemp(prefix="tinympc_sweep_het_"), "samples.pkl")
+    pickle.dump(specs, open(spec_path, "wb"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); import config_check; print('@@CHK@@' + json.dumps(config_check.run(%r, seconds=0.02)))"
+            % (os.path.join(root, "oracle"), spec_path))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=3000)
+    chk = [json.loads(ln[7:]) for ln in p.stdout.splitlines() if ln.startswith("@@CHK@@")]
+    with open(args.hetero, "w") as f:
+        f.write("The tile kernel's per-instance-data form (round 5) on every config-5 cell the tile kernel serves, at the FULL batch (%d instances, every one its own A, B,\n"
+                "rho and cache -- tiny_api.cpp:307-381 per instance, computed by the batched Riccati kernel --, one cold solve, max_iter 500): 256 instances evenly spaced\n"
+                "through the batch, each solved again by ITS OWN oracle (oracle/liboracle.so: tiny_setup with that instance's data); iteration counts and solved flags must be\n"
+                "equal, u[:,0] relative to the solve's largest entry.  (tools/sweep_bench.py --hetero)\n\n" % args.batch)
+        f.write("| cell | kernel | ms | FP64 frac | instances | iteration sum GPU | oracle | count mismatches | max rel err u0 |\n|---|---|---|---|---|---|---|---|---|\n")
+        bad = 0
+        for r in rows:
+            if "error" in r:
+                f.write("| (%d,%d,%d) | launch failed: %s |\n" % (r["nx"], r["nu"], r["N"], r["error"][:200]))
+                bad += 1
+                continue
+            ps = chk[0][r["name"]]["parity_sample"] if chk and r["name"] in chk[0] else None
+            if ps is None:
+                f.write("| (%d,%d,%d) | %s | checker failed: %s |\n" % (r["nx"], r["nu"], r["N"], r["kernel"], (p.stderr or "")[-200:].replace("\n", " ")))
+                bad += 1
+                continue
+            bad += ps["iteration_count_mismatches"]
+            f.write("| (%d,%d,%d) | %s | %.3f | %.3f | %d | %d | %d | %d | %.1e |\n" % (r["nx"], r["nu"], r["N"], r["kernel"], r["ms"], r["fp64_frac"], ps["instances"],
+                                                                                      ps["iter_sum_gpu"], ps["iter_sum_oracle"], ps["iteration_count_mismatches"], ps["max_rel_err_u0"]))
+        f.write("\ntotal iteration-count mismatches: %d\n" % bad)
+    print("hetero parity table ->", args.hetero)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=131072)
@@ -129,7 +193,15 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--parity", default="", help="(1 GPU) also check 256 instances of every cell's batch against the oracle, iteration counts "
                                                  "and u[:,0] (oracle/config_check.py, processes of its own AFTER the GPU work); markdown table to this file")
+    ap.add_argument("--hetero", default="", help="(1 GPU, with --parity's checker) the tile kernel's per-instance-data form at every cell's FULL batch: every instance "
+                                                 "its own A, B, rho (its own cache from the batched Riccati kernel), one cold solve; 256 instances evenly spaced "
+                                                 "through the batch against EACH ONE'S OWN oracle (tiny_setup per instance); markdown table to this file")
+    ap.add_argument("--uniform", type=int, default=0, help="K > 0: every instance runs exactly K iterations (tolerances 0): the per-iteration instruction path, for counters")
     args = ap.parse_args()
+    global UNIFORM
+    UNIFORM = args.uniform
+    if args.hetero and WORLD == 1:
+        return hetero_parity(args)
     global PARITY
     if args.parity and WORLD == 1:
         PARITY = []

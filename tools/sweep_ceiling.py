@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
-"""CPU only: what each cell of the config-5 sweep CAN reach with the mapping it runs on, so that a measured FP64
-fraction of 0.11 splits into what the mapping forbids and what is left on the table.
+"""CPU only: what each cell of the config-5 sweep CAN reach with the mapping it runs on, and where the measured
+FP64 fraction goes, factor by factor.
 
-    python tools/sweep_ceiling.py profiles/r05_sweep_config5.json > profiles/r06_sweep_ceiling.md
+    python tools/sweep_ceiling.py profiles/r06_sweep_config5.json profiles/r06_sweep_counters.json profiles/r06_sweep_counters_uniform.json > profiles/r06_sweep_ceiling.md
 
-FP64 peak = every issue slot of every SIMD an FMA on all 64 lanes.  Per cell, from the gfx950 assembly of the instantiation the cell
-launches (hipcc -S, the innermost loop with the most FP64 FMAs = one ADMM iteration of every instance the wave holds):
+FP64 peak = every issue slot of every SIMD an FMA on all 64 lanes (128 FLOP per wave-instruction; 78.6 TFLOP/s at 2.4 GHz).  A cell's
+measured fraction is the product of three factors, each read from a different source:
 
-  instr_eff     algorithmic FLOPs per wave-iteration (SURVEY.md 8 footnote 1 x instances per wave) / (2 x 64 x instructions per
-                wave-iteration) -- folds lane use ((nx+nu) of the 16 W lanes), rows idle in a sweep (R > 1), the FP64 share of the
-                instruction stream and the FMA density of the FP64 instructions
-  issue_util    the share of issue slots a SIMD fills, from SQ_INSTS_VALU / SQ_WAVE_CYCLES of profiles/r04_kernel_counters_table.md: two
-                waves per SIMD interleave their dependent chains (0.50 + 0.50 = every slot); ONE one-row wave reaches 0.79-0.89 (its fused
-                step blocks carry two chains), ONE tile-kernel wave 0.47-0.67 -> 1.0 / 0.85 / 0.58
-  lockstep_eff  rows of a wave iterate together: mean iterations / E[max over the instances of a wave] from the cell's own iteration
-                histogram (random grouping).  Dynamic slot forms and split solves recover most of it: listed separately, NOT in the ceiling
-  ceiling       instr_eff x issue_util;   measured / ceiling = what lock step, load / store phases, launch tails and waits leave
+  instr_eff     (the MAPPING)  algorithmic FLOPs per wave-iteration (SURVEY.md 8 footnote 1 x instances per wave) / (128 x instructions
+                of one loop pass).  The loop's length is MEASURED: `sweep_bench.py --uniform 100` under rocprofv3 --pmc SQ_INSTS_VALU runs
+                every instance for exactly 100 iterations (tolerances 0: no lock step, no split, every row busy), instructions issued /
+                wave-iterations is what one pass costs (the static count of the gfx950 assembly -- hipcc -S, the loop with the most FP64
+                FMAs -- stands next to it: the tile kernel's loop is a slot state machine whose load / store / regenerate blocks the
+                static count includes although they run once per solve).  Folds lane use ((nx+nu) of the 16 W lanes), rows idle in a
+                sweep (R > 1), the FP64 share of the instruction stream and the FMA density of the FP64 instructions.  THIS is the
+                cell's ceiling: every issue slot taken, every row of every wave busy with an instance of its own.
+  packing       (LOCK STEP and everything outside the loop, from SQ_INSTS_VALU of a profiled run: tools/sweep_counters.py)  loop
+                instructions per ideal wave-iteration / VALU instructions actually issued per ideal wave-iteration (iterations of all
+                instances / instances per wave).  Rows that idle while a neighbour iterates still issue; load / store code, probes and
+                launch tails issue too.
+  issue_util    (the SCHEDULE, same counters)  4 x VALU instructions / (1024 SIMDs x kernel time x 2.4 GHz): the share of the chip's
+                issue slots taken -- waits for LDS / memory / dependent results, one wave per SIMD, clocks below nominal.
+
+  measured = instr_eff x packing x issue_util (the profiled run's own fraction: column "product"; the clean run's: "measured").
+  lockstep_eff  for reference: mean iterations / E[max over the instances of a wave] from the cell's own iteration histogram (random
+                grouping, static rows) -- what packing would be WITHOUT the dynamic slot forms / split solves.
 """
 import collections
 import concurrent.futures
@@ -104,9 +113,6 @@ def analyse_cell(cell):
     waves = 2 if waves >= 2 else 1
     fl = flops_per_iter(nx, nu, N)
     instr_eff = fl * ipw / (2.0 * 64.0 * total)
-    # measured VALU instructions per wave-cycle (profiles/r04_kernel_counters_table.md): two waves 0.50 each = every slot; a lone one-row
-    # wave 0.79-0.89 (its fused step blocks interleave two chains), a lone tile wave 0.47-0.67
-    issue = 1.0 if waves >= 2 else (0.85 if kern != "tile" else 0.58)
     # lock step: E[max of ipw draws] from the histogram
     hist = {int(k): v for k, v in cell.get("iter_histogram", {}).items()}
     n = float(sum(hist.values())) or 1.0
@@ -118,39 +124,64 @@ def analyse_cell(cell):
         prev = acc
     lock = mean / emax if emax > 0 else 1.0
     return dict(cell, form=form, ipw=ipw, lane_use=lane_use, rows=R, loop_instr=total, fp64_share=c["fp64"] / float(total), regs=regs, waves=waves,
-                instr_eff=instr_eff, issue_util=issue, lockstep_eff=lock, ceiling=instr_eff * issue)
+                instr_eff=instr_eff, lockstep_eff=lock, ceiling=instr_eff, flops_per_wave_iter=fl * ipw)
 
 
 def main():
     cells = json.load(open(sys.argv[1]))
     if isinstance(cells, dict):
         cells = cells.get("cells", [])
+    counters = {}
+    if len(sys.argv) > 2:
+        counters = {(c["nx"], c["nu"], c["N"]): c for c in json.load(open(sys.argv[2]))}
+    uniform = {}
+    if len(sys.argv) > 3:
+        uniform = {(c["nx"], c["nu"], c["N"]): c for c in json.load(open(sys.argv[3]))}
     with concurrent.futures.ThreadPoolExecutor(8) as ex:
         rows = list(ex.map(analyse_cell, cells))
-    print("# Round 6: the config-5 sweep cell by cell -- measured FP64 fraction against what the mapping allows (tools/sweep_ceiling.py, measured column: %s)\n" % os.path.basename(sys.argv[1]))
-    print(__doc__.split("FP64 peak")[1].join(["FP64 peak", ""]) if False else "FP64 peak" + __doc__.split("FP64 peak")[1])
-    print("| (nx,nu,N) | form | inst / wave | lane use | loop instr | FP64 share | regs | waves / SIMD | instr_eff | issue_util | **ceiling** | measured | measured / ceiling | lockstep_eff (static rows) | what blocks it |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:                                     # the loop's MEASURED length where the uniform run has it (the static count stays in its own column)
+        u = uniform.get((r.get("nx"), r.get("nu"), r.get("N")))
+        if u and "error" not in r and u.get("instr_per_instance_iter"):
+            r["loop_static"] = r["loop_instr"]
+            r["loop_instr"] = u["instr_per_instance_iter"] * r["ipw"]
+            r["instr_eff"] = r["ceiling"] = r["flops_per_wave_iter"] / (128.0 * r["loop_instr"])
+            r["uniform_util"] = u["issue_util"]
+    print("# Round 6: the config-5 sweep cell by cell -- the measured FP64 fraction as mapping x packing x schedule (tools/sweep_ceiling.py; measured: %s, counters: %s)\n"
+          % (os.path.basename(sys.argv[1]), os.path.basename(sys.argv[2]) if len(sys.argv) > 2 else "none"))
+    print("FP64 peak" + __doc__.split("FP64 peak")[1])
+    print("| (nx,nu,N) | form | inst / wave | lane use | loop instr (measured; static count) | FP64 share (static) | VGPR+AGPR | scratch B/lane | waves / SIMD | **instr_eff = ceiling** | packing | issue_util | product | measured | measured / ceiling | lockstep_eff (static rows) | largest loss |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     below = 0
+    tot = 0.0
     for r in sorted(rows, key=lambda r: (r["N"], r["nx"], r["nu"])):
         if "error" in r:
             print("| (%d,%d,%d) | error: %s |" % (r["nx"], r["nu"], r["N"], r["error"].replace("\n", " ")[:80]))
             continue
+        tot += r["ms"]
+        c = counters.get((r["nx"], r["nu"], r["N"]))
         ratio = r["fp64_frac"] / r["ceiling"]
-        why = []
-        if r["lane_use"] < 0.7:
-            why.append("lane use %.2f" % r["lane_use"])
-        if r["waves"] < 2:
-            why.append("one wave per SIMD")
-        if r["fp64_share"] < 0.8:
-            why.append("%.0f %% of the stream is not FP64" % (100 * (1 - r["fp64_share"])))
+        pack = util = prod = None
+        regs, scratch = r["regs"], None
+        if c and c.get("instr_per_instance_iter"):
+            issued_per_wave_iter = c["instr_per_instance_iter"] * r["ipw"]
+            pack = r["loop_instr"] / issued_per_wave_iter
+            util = c["issue_util"]
+            prod = r["instr_eff"] * pack * util
+            regs, scratch = c["vgpr"] + c["agpr"], c["scratch_bytes_per_lane"]
+        loss = []
+        cand = [("mapping: lane use %.2f" % r["lane_use"], r["lane_use"]), ("mapping: %.0f %% of the loop is not FP64" % (100 * (1 - r["fp64_share"])), r["fp64_share"])]
+        if pack is not None:
+            cand += [("packing %.2f%s" % (pack, "" if "dyn" in r["form"] else " (static rows: lock step %.2f)" % r["lockstep_eff"]), min(pack, 1.0)),
+                     ("schedule: issue_util %.2f at %d wave%s per SIMD" % (util, r["waves"], "" if r["waves"] == 1 else "s"), util)]
+        cand.sort(key=lambda kv: kv[1])
+        loss = "; ".join(k for k, v in cand[:2] if v < 0.9) or "at its ceiling"
         if ratio < 0.8:
-            why.append("measured %.2f of the ceiling: lock step %.2f%s" % (ratio, r["lockstep_eff"], "" if "dyn" in r["form"] else " (static rows)") )
             below += 1
-        print("| (%d,%d,%d) | %s | %d | %.2f | %d | %.2f | %d | %d | %.3f | %.2f | **%.3f** | %.3f | %.2f | %.2f | %s |" %
-              (r["nx"], r["nu"], r["N"], r["form"], r["ipw"], r["lane_use"], r["loop_instr"], r["fp64_share"], r["regs"], r["waves"], r["instr_eff"],
-               r["issue_util"], r["ceiling"], r["fp64_frac"], ratio, r["lockstep_eff"], "; ".join(why) or "at its ceiling"))
-    print("\n%d of %d cells below 0.8 of their own ceiling." % (below, len(rows)))
+        f = lambda v, fmt="%.2f": "--" if v is None else fmt % v
+        print("| (%d,%d,%d) | %s | %d | %.2f | %d; %s | %.2f | %s | %s | %d | **%.3f** | %s | %s | %s | %.3f | %.2f | %.2f | %s |" %
+              (r["nx"], r["nu"], r["N"], r["form"], r["ipw"], r["lane_use"], r["loop_instr"], r.get("loop_static", "--"), r["fp64_share"], regs, f(scratch, "%d"), r["waves"], r["instr_eff"],
+               f(pack), f(util), f(prod, "%.3f"), r["fp64_frac"], ratio, r["lockstep_eff"], loss))
+    print("\nsweep total %.1f ms; %d of %d cells below 0.8 of their own ceiling (instr_eff: every issue slot taken, every row busy)." % (tot, below, len(rows)))
 
 
 if __name__ == "__main__":
