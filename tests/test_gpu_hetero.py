@@ -168,7 +168,12 @@ def test_fused_tracking_episode_on_wide_and_long_shapes_runs_on_the_tile_kernel(
             assert int(o.get("sol_iter")) == its[k, b], (b, k)
             xb = fam["A"] @ xb + fam["B"] @ o["u"][:, 0] + fam["f"]
         for k, ref in dict(x0=xb, x=o["x"], u=o["u"], vnew=o["vnew"], g=o["g"], v=o["v"]).items():
-            assert rel_err(got[k][b], ref) < 1e-7, (b, k)         # (per-solve 1e-13 compounds through twelve plant steps)
+            # Tolerance: ONE solve of these shapes agrees with the oracle to ~1e-13 relative (the summation order of the FMA chains; the
+            # single-solve tests hold every field to 1e-9).  Here twelve closed-loop steps feed each solve's u_0 through the plant into
+            # the next x0, and the iteration is contractive but not by much (|A - B Kinf| ~ 0.9 ... 1): a difference of 1e-13 in step
+            # k can grow by up to ~10x per step through the active-set pattern of the box -- 1e-13 x 10^(steps/2) ~ 1e-7 is the bound
+            # asserted; the iteration COUNTS of all twelve solves are asserted equal above, which is the sharper check.
+            assert rel_err(got[k][b], ref) < 1e-7, (b, k)
         o.close()
     # one launch per MPC step: the same episode bit for bit
     s1 = make()
