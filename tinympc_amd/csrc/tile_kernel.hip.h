@@ -39,6 +39,17 @@ __device__ __forceinline__ void swap16(double v, double& a, double& b) {
     b = __hiloint2double(r1[1], r0[1]);
 }
 
+// W = 2 on TWO accumulators (round 6, measured and NOT the default: -DTINYMPC_TILE_W2_CHAINS=2): each half of a two-row mat-vec (a:
+// columns 0-15, b: 16-31) on the one-row kernel's two-chain block (admm_kernel.hip.h ring<0>: even columns on a0, odd ones on a1).  A
+// lone wave per SIMD issues a DEPENDENT v_fmac_f64_dpp every 5.25 cycles and an independent one every 4.38
+// (profiles/r01_ubench_fp64_dpp.txt), so a 24-column chain would save ~20 cycles -- and costs a zeroed second accumulator and a final
+// add (two instructions = 8 cycles), plus what the allocator does with two more live registers at 512.  A/B of two libraries on one
+// box, all twelve wide sweep cells, 131 072 instances: 3-9 % SLOWER ((20,4,50) 217.4 -> 237.1 ms, (20,8,10) 16.85 -> 18.34);
+// iteration counts unchanged.  profiles/r06_negative_results.md.
+#ifndef TINYMPC_TILE_W2_CHAINS
+#define TINYMPC_TILE_W2_CHAINS 1
+#endif
+
 // init + sum_{k=C0}^{C1-1} M[jj][k] * w[k], w spread one entry per lane over W rows; m[k - C0] = M[jj][k]
 template <int W, int C0, int C1>
 __device__ __forceinline__ double tile_matvec(double init, double src, const double* m) {
@@ -53,6 +64,12 @@ __device__ __forceinline__ double tile_matvec(double init, double src, const dou
             swap16(src, a, b);
             constexpr int E0 = C1 < 16 ? C1 : 16;          // end of the part that lives in the even row
             constexpr int S1 = C0 > 16 ? C0 : 16;          // start of the part that lives in the odd row
+            if constexpr (TINYMPC_TILE_W2_CHAINS == 2 && C1 - C0 >= 4) {
+                double a0 = init, a1 = 0.0;
+                if constexpr (C0 < 16) ring<0, C0, E0 - C0>(a0, a1, a, m);
+                if constexpr (C1 > 16) ring<0, S1 - 16, C1 - S1>(a0, a1, b, m + (S1 - C0));
+                return a0 + a1;
+            }
             if constexpr (C0 < 16) ring1<C0, E0 - C0>(acc, a, m);
             if constexpr (C1 > 16) ring1<S1 - 16, C1 - S1>(acc, b, m + (S1 - C0));
         }
