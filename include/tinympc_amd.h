@@ -213,6 +213,12 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * warm-start records are left as they were.  Round 5: every shape -- wide and long ones on the tile kernel's EXT forms, as are
  * reference windows, "reset_duals" and per-instance problem data; the coverage kernel (overlapping cones, no hipRTC) runs these launch
  * forms and fused steps too, as a loop of single-step launches, and then writes every record back),
+ * "one_shot_fast" (default 1, round 6: a one-shot launch of a wide / long shape rides on the shape's fast box form -- LDS-offload set,
+ * dynamic slots; a form that streams v|z streams into a scratch array of the record's shape, allocated on first use, so that the
+ * record stays untouched -- 1.2-1.9x the rate of the all-in-registers form, which 0 brings back; profiles/r06_one_shot_tile_forms.md),
+ * "plan" (default 1: a fresh handle whose shape, settings and batch bucket match an entry of tinympc_amd/data/plans.txt -- or of the
+ * file TINYMPC_AMD_PLANS names; "0": none -- takes that entry's launch form on its FIRST solve instead of probing; read-back
+ * "plan_shipped"; tools/make_plans.py writes the file),
  * "het_ub" (default 1: per-instance problem data with a knot-invariant box takes the variant that keeps the box in two registers),
  * "repack_after" (-1, the default: automatic -- K is derived from the iteration histogram of the batch's previous solve by a
  * cost model, 0 (a plain launch) when the counts are uniform enough that splitting would not pay 5 %; 0: never split;

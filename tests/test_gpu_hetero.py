@@ -191,14 +191,23 @@ def test_fused_tracking_episode_on_wide_and_long_shapes_runs_on_the_tile_kernel(
     s1.set_x0(x0); s1.set_x_ref(Xref); s1.set_u_ref(Uref)
     s1.solve()
     ref = dict(x=s1.get("x"), u=s1.get("u"), vnew=s1.get("vnew"), it=s1.status()["iter"].copy())
-    for mode in (1, 2):
-        for f in ("vnew", "znew", "g", "y", "v", "z", "x", "u"):
-            s1.set(f, rng.normal(0, 5.0, s1.get(f).shape))
-        s1.set_x0(x0)
-        s1.set_option("one_shot", mode)
-        assert s1.kernel_path() == "tile"
-        s1.solve()
-        assert np.array_equal(s1.status()["iter"], ref["it"]) and np.array_equal(s1.get("x"), ref["x"]) and np.array_equal(s1.get("u"), ref["u"])
-        if mode == 1:
-            assert np.array_equal(s1.get("vnew"), ref["vnew"])
+    # Round 6: a one-shot launch rides on the shape's FAST box form (LDS-offload set, dynamic slots; a form that streams v|z streams
+    # into a scratch array, SolveArgs::vz_stream) -- option "one_shot_fast" = 0: the all-in-registers form of round 5.  Both: the
+    # results of the solve from the reset state bit for bit, and every record the launch does not name EXACTLY as the caller left it.
+    for fast in (1, 0):
+        s1.set_option("one_shot_fast", fast)
+        for mode in (1, 2):
+            junk = {}
+            for f in ("vnew", "znew", "g", "y", "v", "z", "x", "u"):
+                junk[f] = rng.normal(0, 5.0, s1.get(f).shape)
+                s1.set(f, junk[f])
+            s1.set_x0(x0)
+            s1.set_option("one_shot", mode)
+            assert s1.kernel_path() == "tile"
+            s1.solve()
+            assert np.array_equal(s1.status()["iter"], ref["it"]) and np.array_equal(s1.get("x"), ref["x"]) and np.array_equal(s1.get("u"), ref["u"])
+            if mode == 1:
+                assert np.array_equal(s1.get("vnew"), ref["vnew"])
+            for f in ("g", "y", "v", "z") + (("vnew", "znew") if mode == 2 else ()):
+                assert np.array_equal(s1.get(f), junk[f]), (f, mode, fast)
     s1.close()

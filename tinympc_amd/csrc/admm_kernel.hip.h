@@ -158,6 +158,10 @@ struct SolveArgs {
     // that took alike counts at the last step take alike counts at the next ones.  Same reason as above: nothing in the results.
     const int* perm;
     int perm_count;           // slots of `perm` (a launch may take a part of the batch: batch_dispatch.hip runs two halves on two streams)
+    // tile kernel, forms that stream v|z out of the register file (TILE_LM_VPG): where the stream goes.  null: the instance's v|z record
+    // (what a warm-started solve must leave there anyway); a ONE-SHOT launch promises not to touch that record, and hands a scratch
+    // array of the same shape here instead (round 6: one_shot rides on the shape's fast box form, not on the all-in-registers one)
+    double* vz_stream;
     // one-row kernel, PREFETCH form (template PF; round 6): persistent waves whose NEXT tile's records are on their way into the wave's
     // LDS buffer (LDS-DMA, global_load_lds_dwordx4: no register holds them) while the current tile iterates -- at two waves per SIMD
     // (247 VGPRs) a wave's load phase otherwise hides behind ONE neighbour only (tools/ubench/ubench_stream_forms.hip: the record traffic

@@ -347,7 +347,7 @@ int tiny_batch_destroy(TinyBatch* b) {
                     b->d_iter_log, b->d_u0_log, b->d_lslack, b->d_ldual, b->d_tlslack, b->d_tldual, b->d_gtab, b->d_traj,
                     b->d_traj_offsets, b->d_hA, b->d_hB, b->d_hf, b->d_hQw, b->d_hRw, b->d_hrho, b->d_hK, b->d_hP, b->d_hQuu,
                     b->d_hAmBKt, b->d_hAPf, b->d_hBPf, b->d_het_tabs, b->d_hiters, b->d_ttab, b->d_repack_index, b->d_repack_count,
-                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter, b->d_perm, b->d_rg_bins, b->d_ls, b->d_pf_counter};
+                    b->d_wire, b->d_arho, b->d_aK, b->d_aP, b->d_aC1, b->d_aC2, b->d_atab, b->d_work_counter, b->d_perm, b->d_rg_bins, b->d_ls, b->d_pf_counter, b->d_vz_scratch};
     for (void* p : bufs)
         if (p) hipFree(p);
     if (b->h_wire) hipHostFree(b->h_wire);
@@ -768,6 +768,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "store_primal")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "store_primal: 0, 1 or 2"); b->store_primal = (int)value; }
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
+    else if (!strcmp(name, "one_shot_fast")) b->one_shot_fast = value != 0;
     else if (!strcmp(name, "plan")) { b->plan_opt = value != 0 ? 1 : 0; if (!b->plan_opt) b->plan_tried = true; }
     else if (!strcmp(name, "prefetch")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "prefetch: -1 (by rule), 0 (never), 1 (wherever the form exists)"); b->prefetch = (int)value; }
     else if (!strcmp(name, "prefetch_static")) { if (value < 0 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100"); b->prefetch_static = (int)value; }

@@ -146,6 +146,10 @@ struct TinyBatch {
     // layout of d_het_tabs as tiny_batch_setup_hetero built it (columns x lanes per column: 16 x 16 one-row kernel, 32 x 16 W tile kernel);
     // a launch whose kernel reads another layout is refused instead of reading the tables with the wrong stride
     int het_tab_cols = 0, het_tab_lw = 0;
+    // one_shot on the tile kernel (round 6): option "one_shot_fast" = 1 (default) lets a one-shot launch ride on the shape's fast box
+    // form -- LDS-offload set, v|z streamed to d_vz_scratch instead of its record, dynamic slots --, 0 keeps the all-in-registers form
+    bool one_shot_fast = true;
+    double* d_vz_scratch = nullptr;
     bool helpers_loaded = false;          // batch_dispatch.hip preload_helper_kernels
     const void* loaded_kernel = nullptr;  // the kernel whose code object this handle has asked for last (hipFuncGetAttributes in front of a first launch)
     bool plan_tried = false, plan_shipped = false;

@@ -166,7 +166,7 @@ void admm_tile_kernel(const SolveArgs P) {
     // in the same registers -- so that a heterogeneous batch runs the form the sweep measured fastest for the shape
     static_assert(EXT == 0 || W >= 1, "EXT forms: whole DPP rows");
     // Bit 0 too, as long as QX is writable (not re-read from the reference record): the window goes into the QX array wherever it lives.
-    // (The host keeps one_shot launches on the LM = 0 forms: a form that streams v|z would write a record one_shot promises not to touch.)
+    // (one_shot on a form that streams v|z: the host hands the stream a scratch array, SolveArgs::vz_stream -- the record stays untouched.)
     static_assert(!EXTF || (LM & TILE_LM_QXR) == 0, "a reference window needs a QX array of its own");
     constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
     constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
@@ -452,10 +452,11 @@ void admm_tile_kernel(const SolveArgs P) {
             if constexpr (VG) {
                 // this lane's column of the instance's v|z record (slot l at + l NZ); lanes that hold no row, and the input lanes' dummy
                 // slot 0, go to the pad behind the records (tiny_batch_setup: zeros, and zeros are all that is ever written there)
-                double* const pad = P.slack_prev + (size_t)P.batch * N * NZ + (lane & 15);
-                vpp = jj < NZ ? P.slack_prev + ((size_t)b * N + g0 - (is_input ? 1 : 0)) * NZ + jj : pad;
+                double* const vzb = (EXTF && P.vz_stream) ? P.vz_stream : P.slack_prev;     // (a one-shot launch streams into a scratch array)
+                double* const pad = vzb + (size_t)P.batch * N * NZ + (lane & 15);
+                vpp = jj < NZ ? vzb + ((size_t)b * N + g0 - (is_input ? 1 : 0)) * NZ + jj : pad;
                 vpp0 = (hrow == 0 && is_input) ? pad : vpp;
-                if constexpr (QR) { rpp = P.ref + (vpp - P.slack_prev); rpp0 = P.ref + (vpp0 - P.slack_prev); }
+                if constexpr (QR) { rpp = P.ref + (vpp - vzb); rpp0 = P.ref + (vpp0 - vzb); }
             }
             if constexpr (EXT == 0) {   // terminal term -(Xref[:,N-1]' Pinf) on the last horizon row (admm.cpp:292)
                 double pt[NX];
@@ -575,7 +576,9 @@ void admm_tile_kernel(const SolveArgs P) {
                     }
                 }
                 if constexpr (VG) {
-                    if (iter == 0) {                                   // a solve's first iteration: v|z of the solve before, from its record, into
+                    // (a cold start -- one_shot -- takes v|z as zero without reading it: vnew|znew were loaded as zeros, and only a
+                    // launch's FIRST solve is cold: the later solves of a fused launch read what the stream left)
+                    if (iter == 0 && !(EXTF && P.cold && step == 0)) {   // a solve's first iteration: v|z of the solve before, from its record, into
                         __builtin_amdgcn_s_waitcnt(0);                 // the vnew|znew registers (dead behind the backward sweep)
 #pragma unroll
                         for (int l = 0; l < L; ++l) VN[l] = (l == 0 ? vpp0 : vpp)[l * NZ];
