@@ -167,7 +167,8 @@ void admm_tile_kernel(const SolveArgs P) {
     static_assert(EXT == 0 || W >= 1, "EXT forms: whole DPP rows");
     // Bit 0 too, as long as QX is writable (not re-read from the reference record): the window goes into the QX array wherever it lives.
     // (one_shot on a form that streams v|z: the host hands the stream a scratch array, SolveArgs::vz_stream -- the record stays untouched.)
-    static_assert(!EXTF || (LM & TILE_LM_QXR) == 0, "a reference window needs a QX array of its own");
+    // (A reference WINDOW needs a QX array of its own: the host never pairs a trajectory with a form that re-reads QX from the reference
+    // record -- batch_dispatch.hip launch_tile --; reset_duals and one_shot launches without a window take those forms too, round 6.)
     constexpr int WW = HR ? 1 : W;                                     // 16-lane rows across the knot vector (table layout)
     constexpr int ROWL = HR ? 8 : 16 * WW;                             // lanes between the horizon rows of one instance
     constexpr int NZ = NX + NU, LW = 16 * WW, L = N / R, RPI = WW * R, LPI = RPI * (HR ? 8 : 16), IPW = 64 / LPI;
@@ -367,7 +368,7 @@ void admm_tile_kernel(const SolveArgs P) {
     // EXT bit 0, at the start of every solve (MPC step `step` of this launch): the reference window and the dual reset
     auto ext_begin_solve = [&]() {
         if constexpr (EXTF) {
-            if (P.traj) {                                               // work->Xref = Xref_total.block(0, k, nx, N)
+            if (!QR && P.traj) {                                        // work->Xref = Xref_total.block(0, k, nx, N)
                 const int k0 = P.traj_step0 + (P.traj_offsets ? P.traj_offsets[b] : 0) + step + g0;
                 if (is_state) {
 #pragma unroll
