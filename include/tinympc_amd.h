@@ -331,6 +331,14 @@ int tiny_batch_kernel_path(TinyBatch* b);
  * what to feed tiny_jit_compile() elsewhere.  Returns the code-object size in bytes (> 0; *from_disk = 1 if it was found in
  * the directory), or TINY_ERR_HIP with the reason in msg. */
 long tiny_jit_compile(const char* instantiation, int* from_disk, char* msg, int msg_len);
+/* The PREBUILT store (round 6): <directory of the library>/jit_prebuilt/ (TINYMPC_AMD_JIT_PREBUILT=<dir> overrides, "0": off) holds
+ * code objects compiled at BUILD time -- tinympc_amd.build() calls tiny_jit_prebuild() for every name of csrc/jit_prebuilt.txt (the
+ * run-time instantiated forms the BASELINE-shaped workloads of bench.py take).  They are keyed by the kernel sources, the name and the
+ * options, NOT by the hipRTC version of the running process: a process that has loaded another ROCm's compiler (PyTorch wheels bring
+ * their own libhiprtc / libamd_comgr) runs the build's code, and the first launch of a listed form reads a file instead of compiling.
+ * Looked up after TINYMPC_AMD_JIT_CACHE, before compiling.  Returns the code-object size, 0 if the file was already there, or
+ * TINY_ERR_HIP with the reason in msg.  dir NULL: the library's own store. */
+long tiny_jit_prebuild(const char* instantiation, const char* dir, char* msg, int msg_len);
 int tiny_jit_used(char* out, int out_len);                   /* returns the number of names; out may be NULL */
 /* bytes of HBM traffic one warm solve must move per instance: 8*(nx + 8*S) + 44, S = nx*N + nu*(N-1)
  * (SURVEY.md section 8(d)); cold = 8*(nx + 2*S) + 44 */

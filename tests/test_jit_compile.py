@@ -90,3 +90,43 @@ def test_disk_cache_of_code_objects(tmp_path):
     # an unwritable / missing directory only costs the caching
     r = _compile([name], os.path.join(tmp_path, "does", "not", "exist"))["results"][0]
     assert "error" not in r and not r["hit"]
+
+
+PREBUILD_CHILD = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import tinympc_amd as tm
+out = []
+for name in sys.argv[2:]:
+    a = tm.jit_prebuild(name)
+    b = tm.jit_prebuild(name)
+    n, hit = tm.jit_compile(name)
+    out.append({"first": a, "second": b, "bytes": n, "hit": hit})
+print(json.dumps(out))
+'''
+
+
+def test_prebuilt_store_of_code_objects(tmp_path):
+    """Round 6: code objects compiled at BUILD time (tinympc_amd.build() -> tiny_jit_prebuild for the names of csrc/jit_prebuilt.txt)
+    are found by name before anything is compiled -- keyed by the kernel sources, not by the hipRTC version of the process, so that a
+    process which has loaded another ROCm's compiler (PyTorch's wheel) runs the build's code."""
+    _need_hiprtc()
+    import json
+    name = VARIANTS[0]
+    env = dict(os.environ, TINYMPC_AMD_JIT_PREBUILT=str(tmp_path))
+    env.pop("TINYMPC_AMD_JIT_CACHE", None)
+    p = subprocess.run([sys.executable, "-c", PREBUILD_CHILD, ROOT, name], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])[0]
+    files = os.listdir(tmp_path)
+    assert r["first"][0] > 1000 and r["second"][0] == 0 and r["hit"] and r["bytes"] == r["first"][0]
+    assert len(files) == 1 and files[0].startswith("tinympc_amd_pre_") and os.path.basename(r["first"][1]) == files[0]
+    # switched off: the same name is compiled
+    env["TINYMPC_AMD_JIT_PREBUILT"] = "0"
+    p = subprocess.run([sys.executable, "-c", CHILD, ROOT, name], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and not json.loads(p.stdout.strip().splitlines()[-1])["results"][0]["hit"]
+    # the library's own store (tinympc_amd/jit_prebuilt/, filled by build()): every listed name is there
+    listed = [ln.strip() for ln in open(os.path.join(ROOT, "tinympc_amd", "csrc", "jit_prebuilt.txt")) if ln.strip() and not ln.startswith("#")]
+    assert len(listed) >= 20
+    r = _compile(listed[:4])
+    assert all("error" not in x and x["hit"] for x in r["results"]), r["results"]

@@ -43,7 +43,7 @@ BATCH_SYMBOLS = (
     "tiny_batch_get", "tiny_batch_reset", "tiny_batch_solve", "tiny_batch_solve_async", "tiny_batch_synchronize",
     "tiny_batch_get_status", "tiny_batch_reduce_stats", "tiny_batch_set_option", "tiny_batch_set_stream",
     "tiny_batch_phase", "tiny_batch_get_timing", "tiny_batch_get_step_log", "tiny_batch_set_reference_trajectory", "tiny_batch_last_error", "tiny_batch_supported_dims", "tiny_batch_algorithmic_bytes", "tiny_batch_kernel_path",
-    "tiny_jit_compile", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
+    "tiny_jit_compile", "tiny_jit_prebuild", "tiny_jit_used", "tiny_batch_allreduce_stats", "tiny_batch_stats_message",
     "tiny_rccl_unique_id", "tiny_rccl_comm_init_rank", "tiny_rccl_comm_destroy", "tiny_rccl_comm_count", "tiny_rccl_available", "tiny_reduce_stats_messages",
     "tiny_batch_get_option", "tiny_predict_split", "tiny_step_regroup_plan", "tiny_batch_get_plan", "tiny_batch_set_plan", "tiny_batch_set_cache", "tiny_batch_set_adaptive_rho", "tiny_batch_set_sensitivity", "tiny_batch_set_cache_state", "tiny_batch_get_cache_state")
 GROUP_SYMBOLS = (
@@ -91,12 +91,58 @@ def build(force: bool = False, report=None) -> str:
     mode = "forced full rebuild" if force else ("rebuilt" if len(reused) == 0 else ("incremental" if rebuilt else "reused (every object up to date)"))
     say("tinympc_amd.build: %s -- %d object(s) compiled now%s, %d reused, %.1f s" %
         (mode, len(rebuilt), (" (" + ", ".join(rebuilt[:8]) + (", ..." if len(rebuilt) > 8 else "") + ")") if rebuilt else "", len(reused), time.time() - t0))
+    pre = prebuild_jit(say)
     try:
         with open(os.path.join(CSRC, "_gen", "build_report.json"), "w") as f:
-            json.dump({"build_mode": mode, "rebuilt": rebuilt, "reused": reused, "seconds": time.time() - t0, "when": time.time()}, f, indent=1)
+            json.dump({"build_mode": mode, "rebuilt": rebuilt, "reused": reused, "seconds": time.time() - t0, "when": time.time(), "jit_prebuilt": pre}, f, indent=1)
     except OSError:
         pass
     return LIB_PATH
+
+
+def prebuild_jit(say=None, jobs=None):
+    """The prebuilt store of run-time instantiated kernels (csrc/jit_prebuilt.txt -> tinympc_amd/jit_prebuilt/*.co): every listed name
+    that is not there yet is compiled by a process of its own (hipRTC of the toolchain this build runs on; needs no GPU), files the list
+    no longer names are removed.  Returns {"compiled": n, "reused": m, "failed": [...]}."""
+    import concurrent.futures
+    say = say or (lambda line: print(line, file=sys.stderr, flush=True))
+    listing = os.path.join(CSRC, "jit_prebuilt.txt")
+    store = os.path.join(_HERE, "jit_prebuilt")
+    if not os.path.exists(listing):
+        return {"compiled": 0, "reused": 0, "failed": []}
+    names = [ln.strip() for ln in open(listing) if ln.strip() and not ln.startswith("#")]
+    os.makedirs(store, exist_ok=True)
+    code = ("import sys, json; sys.path.insert(0, %r); import tinympc_amd as tm\n"
+            "try:\n    print('@@' + json.dumps(tm.jit_prebuild(sys.argv[1])))\nexcept Exception as e:\n    print('@@' + json.dumps([-1, repr(e)]))" % os.path.dirname(_HERE))
+    env = dict(os.environ)
+    env.pop("TINYMPC_AMD_JIT_PREBUILT", None)
+
+    def one(name):
+        p = subprocess.run([sys.executable, "-c", code, name], capture_output=True, text=True, env=env)
+        for ln in p.stdout.splitlines():
+            if ln.startswith("@@"):
+                import json
+                return name, json.loads(ln[2:])
+        return name, [-1, (p.stderr or "no output")[-300:]]
+    t0 = __import__("time").time()
+    keep, compiled, reused, failed = set(), 0, 0, []
+    with concurrent.futures.ThreadPoolExecutor(jobs or min(8, os.cpu_count() or 1)) as ex:
+        for name, (n, msg) in ex.map(one, names):
+            if n < 0:
+                failed.append((name, msg))
+            else:
+                keep.add(os.path.basename(msg))
+                compiled += 1 if n > 0 else 0
+                reused += 1 if n == 0 else 0
+    if not failed:
+        for f in os.listdir(store):
+            if f.endswith(".co") and f not in keep:
+                os.remove(os.path.join(store, f))
+    say("tinympc_amd.build: run-time instantiated kernels prebuilt into tinympc_amd/jit_prebuilt/: %d compiled now, %d reused, %d failed, %.1f s"
+        % (compiled, reused, len(failed), __import__("time").time() - t0))
+    for name, msg in failed:
+        say("  failed: %s: %s" % (name, msg))
+    return {"compiled": compiled, "reused": reused, "failed": [n for n, _ in failed]}
 
 
 _lib = None
@@ -143,6 +189,8 @@ def lib():
         L.tiny_batch_algorithmic_bytes.restype = C.c_long
         L.tiny_jit_compile.argtypes = [C.c_char_p, _ip, C.c_char_p, C.c_int]
         L.tiny_jit_compile.restype = C.c_long
+        L.tiny_jit_prebuild.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.tiny_jit_prebuild.restype = C.c_long
         L.tiny_jit_used.argtypes = [C.c_char_p, C.c_int]
         L.tiny_batch_stats_message.argtypes = [C.c_void_p, C.c_void_p]
         L.tiny_batch_set_cache.argtypes = [C.c_void_p, C.c_char_p, _dp]
@@ -205,6 +253,16 @@ def jit_compile(instantiation: str):
     if n <= 0:
         raise RuntimeError(msg.value.decode(errors="replace") or f"tiny_jit_compile failed ({n})")
     return int(n), bool(hit.value)
+
+
+def jit_prebuild(instantiation: str, directory=None):
+    """Build time: compile one run-time instantiated kernel with THIS process's hipRTC and keep it in the prebuilt store (default: next
+    to the library, tinympc_amd/jit_prebuilt/).  Returns (code-object size -- 0 if it was already there --, its file)."""
+    msg = C.create_string_buffer(2048)
+    n = lib().tiny_jit_prebuild(instantiation.encode(), directory.encode() if directory else None, msg, len(msg))
+    if n < 0:
+        raise RuntimeError(msg.value.decode(errors="replace") or f"tiny_jit_prebuild failed ({n})")
+    return int(n), msg.value.decode(errors="replace")          # (size -- 0: it was there already --, file)
 
 
 def jit_used():

@@ -854,6 +854,12 @@ long tiny_jit_compile(const char* instantiation, int* from_disk, char* msg, int 
     if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", why.c_str());
     return n > 0 ? n : (long)TINY_ERR_HIP;
 }
+long tiny_jit_prebuild(const char* instantiation, const char* dir, char* msg, int msg_len) {
+    std::string why;
+    const long n = jit_prebuild(instantiation, dir, &why);
+    if (msg && msg_len > 0) snprintf(msg, (size_t)msg_len, "%s", why.c_str());
+    return n >= 0 ? n : (long)TINY_ERR_HIP;
+}
 int tiny_jit_used(char* out, int out_len) {
     std::string names;
     const int n = jit_used_names(&names);

@@ -90,6 +90,33 @@ std::string disk_path(const std::string& name) {
     return std::string(dir) + file;
 }
 
+// The PREBUILT store (round 6): code objects compiled at BUILD time by the build machine's toolchain (tinympc_amd.build() ->
+// tiny_jit_prebuild for every name of csrc/jit_prebuilt.txt), in <directory of the library>/jit_prebuilt/ (TINYMPC_AMD_JIT_PREBUILT=<dir>
+// overrides, "0" switches it off).  Keyed by the kernel headers, the name and the options -- NOT by the hipRTC version of the process:
+// a process that has loaded another ROCm (PyTorch's wheel brings its own libhiprtc / libamd_comgr, which serve every later dlopen by
+// soname) then runs the build's code instead of what that older compiler makes of the same source (measured: the per-instance-data form
+// of (20,8,10), 5.7 ms compiled by ROCm 7.2, 8.1 ms by the 7.0 compiler inside torch 2.10 -- profiles/r06_jit_compiler_probe.md), and
+// the first launch of a listed form costs a file read instead of seconds of compilation.
+std::string prebuilt_dir() {
+    if (const char* e = getenv("TINYMPC_AMD_JIT_PREBUILT")) return strcmp(e, "0") ? std::string(e) : std::string();
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&prebuilt_dir), &info) || !info.dli_fname) return "";
+    std::string path(info.dli_fname);
+    const size_t cut = path.find_last_of('/');
+    return (cut == std::string::npos ? std::string(".") : path.substr(0, cut)) + "/jit_prebuilt";
+}
+std::string prebuilt_path(const std::string& dir, const std::string& name) {
+    if (dir.empty()) return "";
+    uint64_t h = 1469598103934665603ull;
+    h = fnv(h, kAdmmKernelSrc, sizeof(kAdmmKernelSrc));
+    h = fnv(h, kTileKernelSrc, sizeof(kTileKernelSrc));
+    h = fnv(h, name.data(), name.size());
+    for (const char* o : kOpts) h = fnv(h, o, strlen(o));
+    char file[48];
+    snprintf(file, sizeof(file), "/tinympc_amd_pre_%016llx.co", (unsigned long long)h);
+    return dir + file;
+}
+
 // file = magic | u32 len(lowered) | u64 len(code) | lowered | code | u64 fnv(code); anything unexpected = not cached
 bool disk_load(const std::string& path, Code* c) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -125,6 +152,10 @@ Code compile(const std::string& name_s, const bool tile) {
     const char* name = name_s.c_str();
     const std::string path = disk_path(name_s);
     if (!path.empty() && disk_load(path, &c)) { c.from_disk = true; return c; }
+    if (!getenv("TINYMPC_AMD_JIT_DEFINES")) {         // (experiment builds define macros the prebuilt objects were not made with)
+        const std::string pre = prebuilt_path(prebuilt_dir(), name_s);
+        if (!pre.empty() && disk_load(pre, &c)) { c.from_disk = true; return c; }
+    }
     Rtc& R = rtc();
     if (!R.ok) { c.err = "libhiprtc is not available"; return c; }
     // hipRTC brings its own runtime header: the two system includes of the kernel header are dropped
@@ -219,6 +250,34 @@ long jit_compile_only(const char* instantiation, int* from_disk, std::string* er
     const Code& c = code_for(name, tile);
     if (from_disk) *from_disk = c.from_disk ? 1 : 0;
     if (c.blob.empty()) { if (err) *err = c.err; return -1; }
+    return (long)c.blob.size();
+}
+
+// BUILD time: compile `instantiation` with THIS process's hipRTC (no cache is consulted) and leave it in `dir` under its prebuilt name;
+// returns the code-object size, 0 if the file was already there, < 0 on failure
+long jit_prebuild(const char* instantiation, const char* dir, std::string* err) {
+    const std::string name(instantiation ? instantiation : "");
+    const bool tile = name.find("admm_tile_kernel<") != std::string::npos;
+    if (!tile && name.find("admm_solve_kernel<") == std::string::npos) { if (err) *err = "not an instantiation of admm_solve_kernel / admm_tile_kernel"; return -1; }
+    const std::string path = prebuilt_path(dir ? std::string(dir) : prebuilt_dir(), name);
+    if (path.empty()) { if (err) *err = "no prebuilt directory"; return -1; }
+    if (err) *err = path;                            // (on success the message is the file: the build keeps exactly the files it was told about)
+    Code have;
+    if (disk_load(path, &have)) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    // (compile() looks the caches up first: keep it away from both for this call)
+    const char* keep_cache = getenv("TINYMPC_AMD_JIT_CACHE");
+    const std::string cache_val = keep_cache ? keep_cache : "";
+    const char* keep_pre = getenv("TINYMPC_AMD_JIT_PREBUILT");
+    const std::string pre_val = keep_pre ? keep_pre : "";
+    unsetenv("TINYMPC_AMD_JIT_CACHE");
+    setenv("TINYMPC_AMD_JIT_PREBUILT", "0", 1);
+    Code c = compile(name, tile);
+    if (keep_cache) setenv("TINYMPC_AMD_JIT_CACHE", cache_val.c_str(), 1);
+    if (keep_pre) setenv("TINYMPC_AMD_JIT_PREBUILT", pre_val.c_str(), 1); else unsetenv("TINYMPC_AMD_JIT_PREBUILT");
+    if (c.blob.empty()) { if (err) *err = c.err; return -1; }
+    disk_store(path, c);
+    if (!disk_load(path, &have)) { if (err) *err = "could not write " + path; return -1; }
     return (long)c.blob.size();
 }
 

@@ -53,6 +53,8 @@ hipFunction_t jit_tile_kernel(int nx, int nu, int N, int W, int R, int soc, int 
 // instantiation, keyed by the kernel sources, the options and the hipRTC version; written atomically).  Returns the code
 // size in bytes, -1 on failure (*err); *from_disk = 1 when nothing had to be compiled.
 long jit_compile_only(const char* instantiation, int* from_disk, std::string* err);
+// build time: compile with this process's hipRTC and keep the code object in the prebuilt store `dir` (null: next to the library); 0: already there
+long jit_prebuild(const char* instantiation, const char* dir, std::string* err);
 int jit_used_names(std::string* out);       // the instantiations compiled / loaded so far, one per line; returns their number
 
 }  // namespace tinympc_amd

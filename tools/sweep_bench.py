@@ -183,6 +183,7 @@ def hetero_parity(args):
                                                                                       ps["iter_sum_gpu"], ps["iter_sum_oracle"], ps["iteration_count_mismatches"], ps["max_rel_err_u0"]))
         f.write("\ntotal iteration-count mismatches: %d\n" % bad)
     print("hetero parity table ->", args.hetero)
+    print("@@JIT@@" + json.dumps(tm.jit_used()))          # (the run-time instantiated forms these launches took: csrc/jit_prebuilt.txt)
 
 
 def main():
