@@ -24,7 +24,7 @@ constexpr bool pf_shape(int nx, int nu, int n, bool half) {
     const long arr = ((long)ipw * n * nz * 8 + 1023) / 1024 * 1024;
     const int waves = 4 * solve_kernel_waves_per_simd(nz, n, false);
     // (two waves per SIMD only: the one long-horizon shape whose buffer would fit, (8,2,30), hung in its ticketed tiles on the GPU --
-    // round 6, tools/scratch/plan_hang2.py -- and a solve of hundreds of iterations has nothing to gain from the form)
+    // round 6, tools/experiments/prefetch_hang_8_2_30.py -- and a solve of hundreds of iterations has nothing to gain from the form)
     if (waves < 8) return false;
     return fused_shape(nx, nu) && (n * nz) % 2 == 0 && 1024 + 3 * arr + 8L * (nx * 16 + 2 * n * 16) <= 160L * 1024 / waves;
 }

@@ -1,3 +1,5 @@
+"""GPU, round 6: is the per-instance-data form of (20,8,10) slower after other handles have lived and died in the process?  No -- it is slower when
+torch was imported first (profiles/r06_jit_compiler_probe.md; tools/jit_compiler_probe.py is the clean form of this probe)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 """GPU: one_shot launches on wide / long shapes, the fast box form (round 6) against the all-in-registers form (round 5)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinympc_amd as tm
 B = 65536
 print("| cell | plain cold solve (ms) | one_shot = 2, all-in-registers form | one_shot = 2, fast box form | last_tile_form |")

@@ -2,7 +2,7 @@
 """CPU: the SQ counters of one profiled sweep run, per cell.
 
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d <dir> -o sweep -- \
-        python tools/sweep_bench.py --out <dir>/sweep_pmc.json                       (GPU; tools/scratch/r06_sweep_job.sh)
+        python tools/sweep_bench.py --out <dir>/sweep_pmc.json                       (GPU; tools/sweep_evidence.sh)
     python tools/sweep_counters.py <dir> [solves per cell] [counters JSON of a `sweep_bench.py --uniform K` run] > profiles/r06_sweep_counters.json
 
 Every dispatch of a solve kernel (admm_solve_kernel / admm_tile_kernel / admm_general_kernel <nx, nu, N, ...>) belongs to the cell of

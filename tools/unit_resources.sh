@@ -1,4 +1,5 @@
 #!/bin/bash
+# resource usage of every kernel of one generated unit: name <template arguments> VGPR AGPR scratch occupancy LDS.   tools/unit_resources.sh u_20_8_30
 # resource usage of every kernel in a generated unit: name-template-args VGPR AGPR scratch occupancy
 mkdir -p /tmp/ru
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Rpass-analysis=kernel-resource-usage -c /root/repo/tinympc_amd/csrc/_gen/$1.hip -o /tmp/ru/$1.o 2>&1 | python3 -c "
