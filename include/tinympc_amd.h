@@ -245,7 +245,7 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * resident wavefront at least three tiles -- and the first stage of a split solve -- runs as PERSISTENT waves that draw their tiles
  * from a ticket counter and receive the NEXT tile's warm-start / reference records by LDS-DMA while the current tile iterates: at
  * two waves per SIMD a wave's load phase otherwise hides behind one neighbour only; 0: never; 1: wherever the form exists, any
- * batch size.  Same instructions per iteration, instances independent: bit-identical.  "prefetch_static" (default 75: percent of
+ * batch size.  Same instructions per iteration, instances independent: bit-identical.  "prefetch_static" (default -1 = by rule, 75 for warm launches and 50 for cold ones: percent of
  * a wave's tiles it takes by grid stride before it draws tickets), "prefetch_waves" (default 0 = what is resident; > 0: cap on the
  * persistent grid); read-back "last_prefetch").
  * "step_regroup" (fused launches, "steps_per_launch" > 1, of the register kernel.  The four rows of a wavefront run in lock step: a

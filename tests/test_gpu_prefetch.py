@@ -110,7 +110,7 @@ def test_prefetch_form_on_sweep_shapes_half_rows_and_split_solves(dims):
     base = {"no_tile": 1}
     plain = run_cases_hip(suite, options=dict(base, prefetch=0, repack_after=0))
     assert_match(plain, ref, RTOL, f"plain {dims}")
-    # (prefetch_static: percent of a wave's tiles it takes by grid stride -- 75 by default -- before it draws tickets)
+    # (prefetch_static: percent of a wave's tiles it takes by grid stride -- by rule 75 for warm launches, 50 for cold ones -- before it draws tickets)
     for opts in (dict(prefetch=1, repack_after=0), dict(prefetch=1, repack_after=0, prefetch_waves=2), dict(prefetch=1, repack_after=6, prefetch_waves=2),
                  dict(prefetch=1, repack_after=0, half_rows=0, prefetch_waves=3), dict(prefetch=1, repack_after=0, prefetch_waves=2, prefetch_static=0),
                  dict(prefetch=1, repack_after=0, prefetch_waves=3, prefetch_static=100), dict(prefetch=1, repack_after=0, prefetch_waves=8, prefetch_static=50)):

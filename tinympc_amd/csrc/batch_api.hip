@@ -771,7 +771,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "one_shot_fast")) b->one_shot_fast = value != 0;
     else if (!strcmp(name, "plan")) { b->plan_opt = value != 0 ? 1 : 0; if (!b->plan_opt) b->plan_tried = true; }
     else if (!strcmp(name, "prefetch")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "prefetch: -1 (by rule), 0 (never), 1 (wherever the form exists)"); b->prefetch = (int)value; }
-    else if (!strcmp(name, "prefetch_static")) { if (value < 0 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100"); b->prefetch_static = (int)value; }
+    else if (!strcmp(name, "prefetch_static")) { if (value < -1 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100, or -1 (by rule: 75 warm, 50 cold)"); b->prefetch_static = (int)value; }
     else if (!strcmp(name, "prefetch_waves")) { if (value < 0) return fail(b, TINY_ERR_ARG, "prefetch_waves >= 0"); b->prefetch_waves = (int)value; }
     else if (!strcmp(name, "launch_order")) { if (value < 0 || value > 2) return fail(b, TINY_ERR_ARG, "launch_order: 0 (ascending), 1 (alternating), 2 (descending)"); b->launch_order = (int)value; }
     else if (!strcmp(name, "step_regroup")) { if (value < -1) return fail(b, TINY_ERR_ARG, "step_regroup: K > 0 (stretches of K MPC steps), 0 (never) or -1 (automatic)"); b->step_regroup = (int)value; b->regroup_verdict = 0; b->regroup_since = 0; b->ls_pending = false; }

@@ -135,7 +135,9 @@ struct TinyBatch {
     // of a split solve; 0 never; 1 wherever the form exists (any batch size: tests).  "prefetch_waves": cap on the persistent grid
     // (0: what is resident)
     int prefetch = -1, prefetch_waves = 0;
-    int prefetch_static = 75;            // option "prefetch_static": percent of a wave's tiles it takes by grid stride (the rest by ticket)
+    int prefetch_static = -1;            // option "prefetch_static": percent of a wave's tiles it takes by grid stride (the rest by ticket); -1: by
+                                         // rule -- 75 for warm launches (tiles cost alike: profiles/r06_prefetch_probe.md), 50 for cold ones (a split
+                                         // solve's first stage: tiles differ by what their rows need; config 3 0.762 -> 0.749 ms, tools/experiments/config3_knobs.py)
     unsigned* d_pf_counter = nullptr;    // eight ticket counters (64 bytes apart), never reset: a launch draws a known number from each
     unsigned pf_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // where the next launch's tickets begin, per shard
     bool last_prefetch = false;          // the last one-row launch (a split solve: its first stage) took the form
