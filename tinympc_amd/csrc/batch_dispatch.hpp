@@ -1,4 +1,5 @@
-// batch_dispatch.hpp -- what batch_api.hip (the C ABI) uses of batch_dispatch.hip (kernel selection, tables, launch forms).
+// batch_dispatch.hpp -- what batch_api.hip (the C ABI), batch_dispatch.hip (kernel selection, launch forms), batch_tables.hip (lane
+// tables) and batch_helpers.hip (helper kernels, cost model, on-demand buffers) share.
 #pragma once
 #include "batch_impl.hpp"
 
@@ -24,12 +25,26 @@ bool linear_active(const TinyBatch* b);
 int lin_variant(const TinyBatch* b);
 bool use_tile(const TinyBatch* b);
 bool use_general(const TinyBatch* b);
+bool box_is_uniform(const TinyBatch* b);     // the box is the same at every knot (from the host copies of the bounds)
 // ---- buffers and state the API calls create on demand
 int ensure_kpi(TinyBatch* b, double** p);
 int ensure_repack_buffers(TinyBatch* b);
 int ensure_regroup_buffers(TinyBatch* b, bool second_stream);
 int ensure_adaptive(TinyBatch* b, bool need_tables = true);
 int adaptive_fresh_state(TinyBatch* b);
+// ---- lane tables (batch_tables.hip)
+int lin_kmax(const TinyBatch* b);       // half-spaces per knot and family the LIN variants are built for (4, 8, 16, 32; 0: coverage kernel)
+void build_tables(TinyBatch* b);
+void build_tile_tables(TinyBatch* b);
+void build_general_tables(TinyBatch* b);
+int upload_tables(TinyBatch* b);
+// ---- helper kernels, cost model (batch_helpers.hip)
+constexpr int REGROUP_AUTO_MIN_STEPS = 16, REGROUP_AUTO_MIN_BATCH = 4096;
+double wave_iteration_us(int nx, int nu, int N, int wps);
+int enqueue_iteration_histogram(TinyBatch* b);
+int enqueue_regroup_sort(TinyBatch* b, hipStream_t st, int half, int first, int count);
+int enqueue_repack_sort(TinyBatch* b, const int* list, const int* count);
+int enqueue_lockstep_estimate(TinyBatch* b);
 // ---- launches besides launch_solve (batch_impl.hpp)
 int launch_general(TinyBatch* b, int phase = 0);
 int launch_riccati(TinyBatch* b, const RiccatiArgs& r, size_t lds_bytes, int grid);

@@ -1,4 +1,4 @@
-// batch_impl.hpp -- the opaque TinyBatch behind include/tinympc_amd.h (shared by batch_api.hip, batch_dispatch.hip and
+// batch_impl.hpp -- the opaque TinyBatch behind include/tinympc_amd.h (shared by batch_api.hip, batch_dispatch.hip, batch_tables.hip, batch_helpers.hip and
 // compat_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -152,7 +152,7 @@ struct TinyBatch {
     // form -- LDS-offload set, v|z streamed to d_vz_scratch instead of its record, dynamic slots --, 0 keeps the all-in-registers form
     bool one_shot_fast = true;
     double* d_vz_scratch = nullptr;
-    bool helpers_loaded = false;          // batch_dispatch.hip preload_helper_kernels
+    bool helpers_loaded = false;          // batch_helpers.hip preload_helper_kernels
     const void* loaded_kernel = nullptr;  // the kernel whose code object this handle has asked for last (hipFuncGetAttributes in front of a first launch)
     bool plan_tried = false, plan_shipped = false;
     int last_pf_grid = 0;

@@ -8,7 +8,7 @@
 //                  dot product runs in the same order as the host code (cache.hpp): identical problem data give
 //                  the same Riccati step count and caches equal to ~1e-13 on both paths (tests/test_gpu_hetero.py).
 //                  Its epilogue turns the cache into the per-instance lane tables admm_solve_kernel reads (same
-//                  layout and the same pre-multiplied Quu_inv B', Quu_inv BPf as batch_dispatch.hip:build_tables).
+//                  layout and the same pre-multiplied Quu_inv B', Quu_inv BPf as batch_tables.hip:build_tables).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void riccati_kernel(const RiccatiArgs P) {
         for (int e = lane; e < nu; e += 64) P.BPf[(size_t)b * nu + e] = T2[e];
         if (lane == 0) P.iters[b] = fail ? -1 : iters;
 
-        // ---- lane tables of this instance (layout of admm_kernel.hip.h / tile_kernel.hip.h; see batch_dispatch.hip:build_tables, build_tile_tables_w)
+        // ---- lane tables of this instance (layout of admm_kernel.hip.h / tile_kernel.hip.h; see batch_tables.hip:build_tables, build_tile_tables_w)
         w_mm(nu, nu, nx, Gi, Bt, T1, lane);                                    // Quu_inv B'
         w_mm(nu, nu, 1, Gi, T2, G, lane);                                      // Quu_inv BPf  (BPf is in T2)
         const int cols = P.tab_cols, lw = P.tab_lw, tdoubles = het_tab_doubles(cols, lw);
