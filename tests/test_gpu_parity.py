@@ -749,7 +749,7 @@ def test_api_misuse_is_reported_not_ignored():
     with pytest.raises(tm.TinyMPCError):
         s.get("q")                                            # q/r/p/d need the debug option (or a solve on the coverage kernel)
     # overlapping cones are served (sequential projections, admm.cpp:111-135) -- by the coverage kernel, fused steps included since
-    # round 5 (tests/test_gpu_fused_variants.py); what it cannot take is adaptive rho (and per-instance data)
+    # round 5 (tests/test_gpu_fused_variants.py), per-instance data since round 6 (tests/test_gpu_hetero.py); what it cannot take is adaptive rho
     s.set_cone_constraints([0, 2], [3, 3], [0.5, 0.5], [], [], [])
     s.update_settings(en_state_soc=1)
     assert s.kernel_path() == "cover"

@@ -39,6 +39,11 @@ struct GeneralArgs {
     // offsets into gtab
     int o_mb, o_mf1, o_mf2, o_pt, o_cb, o_cf, o_qr, o_lo, o_hi, o_sc, o_ic, o_ax, o_bx, o_au, o_bu, o_tax, o_tbx,
         o_tau, o_tbu;
+    // per-instance problem data (round 6): the tables tiny_batch_setup_hetero built for a register kernel -- [batch][het_stride]
+    // doubles, matrices [column k][het_lw lanes] in blocks of het_cols columns (MB, MF1, MF2, PT), then the lane vectors (CB, CF, QR,
+    // ... RHO) -- read TRANSPOSED into this kernel's row-major LDS matrices at the top of every instance.  null: one family (gtab)
+    const double* het_tabs;
+    int het_cols, het_lw, het_stride;
 };
 
 // phases of admm_phase_kernel (the batched form of the reference's exported phase functions, admm.hpp:12-17)
@@ -89,7 +94,11 @@ __device__ __forceinline__ void halfspace_inplace(double* z, int n, const double
 // LDS carve-up shared by the solve kernel and the single-phase kernel
 struct GkLds {
     double *sMB, *sMF1, *sMF2, *sPT, *sW, *sU, *sPX, *sX, *sQR, *sPD;
+    const double *CB, *CF, *QR;      // the lane vectors of the instance at hand (the family's, or its own: gk_load_instance)
+    double rho;
 };
+// index of a lane vector in the register kernels' tables (admm_kernel.hip.h VEC_*; riccati_kernel.hip.h VEC_RHO)
+enum : int { GK_VEC_CB = 0, GK_VEC_CF = 1, GK_VEC_QR = 2, GK_VEC_RHO = 8 };
 __device__ __forceinline__ GkLds gk_carve(const GeneralArgs& P, double* lds) {
     const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
     GkLds L;
@@ -106,11 +115,42 @@ __device__ __forceinline__ GkLds gk_carve(const GeneralArgs& P, double* lds) {
     return L;
 }
 
+// the matrices and lane vectors of instance b: the family's tables (loaded once per wave: first = true only) or, with per-instance
+// problem data, the instance's own -- the register kernels' column-major lane tables read transposed.  Ends with a barrier.
+__device__ __forceinline__ void gk_load_instance(const GeneralArgs& P, GkLds& L, const int b, const int lane, const bool first) {
+    const int nz = P.nx + P.nu, ld = nz + 1;
+    if (P.het_tabs) {
+        const double* ht = P.het_tabs + (size_t)b * P.het_stride;
+        const int blk = P.het_cols * P.het_lw, lw = P.het_lw;
+        __syncthreads();                                     // (the instance before is done with the matrices)
+        for (int e = lane; e < nz * ld; e += 64) {
+            const int j = e / ld, k = e % ld;
+            const bool in = k < nz;
+            L.sMB[e] = in ? ht[k * lw + j] : 0.0;
+            L.sMF1[e] = in ? ht[blk + k * lw + j] : 0.0;
+            L.sMF2[e] = in ? ht[2 * blk + k * lw + j] : 0.0;
+            L.sPT[e] = in ? ht[3 * blk + k * lw + j] : 0.0;
+        }
+        const double* vec = ht + 4 * blk;
+        L.CB = vec + GK_VEC_CB * lw; L.CF = vec + GK_VEC_CF * lw; L.QR = vec + GK_VEC_QR * lw;
+        L.rho = vec[GK_VEC_RHO * lw];
+        __syncthreads();
+    } else if (first) {
+        for (int e = lane; e < nz * ld; e += 64) {
+            L.sMB[e] = P.gtab[P.o_mb + e]; L.sMF1[e] = P.gtab[P.o_mf1 + e];
+            L.sMF2[e] = P.gtab[P.o_mf2 + e]; L.sPT[e] = P.gtab[P.o_pt + e];
+        }
+        L.CB = P.gtab + P.o_cb; L.CF = P.gtab + P.o_cf; L.QR = P.gtab + P.o_qr;
+        L.rho = P.rho;
+        __syncthreads();
+    }
+}
+
 // backward_pass_grad (admm.cpp:13-20) on the LDS trajectories: reads q|r and p[:,N-1], writes p and d
 __device__ __forceinline__ void gk_backward(const GeneralArgs& P, const GkLds& L, const int lane) {
     const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
     const bool is_state = lane < nx, is_input = lane >= nx && lane < nz;
-    const double* CB = P.gtab + P.o_cb;
+    const double* CB = L.CB;
     double *sMB = L.sMB, *sW = L.sW, *sQR = L.sQR, *sPD = L.sPD;
     if (is_state) sW[lane] = sPD[(N - 1) * nz + lane];
     for (int i = N - 2; i >= 0; --i) {
@@ -136,7 +176,7 @@ __device__ __forceinline__ void gk_backward(const GeneralArgs& P, const GkLds& L
 __device__ __forceinline__ void gk_forward(const GeneralArgs& P, const GkLds& L, const int lane) {
     const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
     const bool is_state = lane < nx, is_input = lane >= nx && lane < nz;
-    const double* CF = P.gtab + P.o_cf;
+    const double* CF = L.CF;
     double *sMF1 = L.sMF1, *sMF2 = L.sMF2, *sW = L.sW, *sU = L.sU, *sX = L.sX, *sPD = L.sPD;
     if (is_state) sW[lane] = sX[lane];
     for (int i = 0; i < N - 1; ++i) {
@@ -213,21 +253,17 @@ __global__ __launch_bounds__(64) void admm_general_kernel(const GeneralArgs P) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
-    const GkLds L = gk_carve(P, lds);
-    double *sMB = L.sMB, *sMF1 = L.sMF1, *sMF2 = L.sMF2, *sPT = L.sPT, *sPX = L.sPX, *sX = L.sX, *sQR = L.sQR, *sPD = L.sPD;
-    for (int e = lane; e < nz * ld; e += 64) {
-        sMB[e] = P.gtab[P.o_mb + e]; sMF1[e] = P.gtab[P.o_mf1 + e];
-        sMF2[e] = P.gtab[P.o_mf2 + e]; sPT[e] = P.gtab[P.o_pt + e];
-    }
-    const double* QR = P.gtab + P.o_qr;
+    GkLds L = gk_carve(P, lds);
+    double *sPT = L.sPT, *sPX = L.sPX, *sX = L.sX, *sQR = L.sQR, *sPD = L.sPD;
     const double* LO = P.gtab + P.o_lo;
     const double* HI = P.gtab + P.o_hi;
-    const double rho = P.rho;
     const bool is_state = lane < nx;
     const int rec_n = N * nz;
-    __syncthreads();
 
     for (int b = blockIdx.x; b < P.batch; b += gridDim.x) {
+        gk_load_instance(P, L, b, lane, b == (int)blockIdx.x);
+        const double* QR = L.QR;
+        const double rho = L.rho;
         const size_t rec = (size_t)b * rec_n;
         // ---- per-solve setup: x[:,0] = x0, terminal term, slack initialisation (admm.cpp:352-376)
         for (int e = lane; e < rec_n; e += 64) sX[e] = P.prim[rec + e];   // previous solve's x|u (cone / linear slack init)
@@ -371,18 +407,14 @@ __global__ __launch_bounds__(64) void admm_phase_kernel(const GeneralArgs P, con
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int nx = P.nx, nu = P.nu, N = P.N, nz = nx + nu, ld = nz + 1;
-    const GkLds L = gk_carve(P, lds);
-    for (int e = lane; e < nz * ld; e += 64) {
-        L.sMB[e] = P.gtab[P.o_mb + e]; L.sMF1[e] = P.gtab[P.o_mf1 + e];
-        L.sMF2[e] = P.gtab[P.o_mf2 + e]; L.sPT[e] = P.gtab[P.o_pt + e];
-    }
-    const double* QR = P.gtab + P.o_qr;
+    GkLds L = gk_carve(P, lds);
     const double* LO = P.gtab + P.o_lo;
     const double* HI = P.gtab + P.o_hi;
-    const double rho = P.rho;
     const int rec_n = N * nz;
-    __syncthreads();
     for (int b = blockIdx.x; b < P.batch; b += gridDim.x) {
+        gk_load_instance(P, L, b, lane, b == (int)blockIdx.x);
+        const double* QR = L.QR;
+        const double rho = L.rho;
         const size_t rec = (size_t)b * rec_n;
         for (int e = lane; e < rec_n; e += 64) { L.sX[e] = P.prim[rec + e]; L.sQR[e] = P.qr[rec + e]; L.sPD[e] = P.pd[rec + e]; }
         __syncthreads();
