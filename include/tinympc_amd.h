@@ -101,7 +101,9 @@ int tiny_batch_setup(TinyBatch** out, const double* Adyn, const double* Bdyn, co
  * tiny_precompute_and_set_cache (tiny_api.cpp:307-381) runs on the GPU for all instances at once; the solve kernel
  * then streams each instance's own cache.  Bounds, cones and settings stay shared.  Any nx + nu <= 32, nu <= 16 (round 5): shapes the
  * one-row kernel holds run its HET variant, wide and long shapes the tile kernel's per-instance form on the shape's fastest box form
- * (run-time instantiated: needs hipRTC); TINY_ERR_UNSUPPORTED when neither kernel holds the shape. */
+ * (run-time instantiated: needs hipRTC or the prebuilt store); TINY_ERR_UNSUPPORTED when neither kernel holds the shape.  Round 6: cones
+ * that share rows, more half-spaces per knot than the register variants hold, or a variant hipRTC cannot make send a heterogeneous
+ * batch to the coverage kernel, which reads the same per-instance tables (adaptive rho does not combine with per-instance data). */
 int tiny_batch_setup_hetero(TinyBatch** out, const double* Adyn, const double* Bdyn, const double* fdyn,
                             const double* Qdiag, const double* Rdiag, const double* rho,
                             int nx, int nu, int N, int batch, int device, int verbose);
