@@ -123,8 +123,29 @@ def sensitivity(d, b, eps=(1e-15, 1e-14, 1e-13)):
     return amp
 
 
+COVER = False                                           # third argument "cover": see cover_variant
+
+
+def cover_variant(d, seed):
+    """Round 6: the same trial on the COVERAGE kernel -- where the draw has a state cone and nx >= 5 a second cone that shares a row with
+    it (sequential projections, admm.cpp:111-135: only that kernel), otherwise option force_general.  Adaptive rho aside, the coverage
+    kernel takes everything a trial can draw since it reads per-instance tables (one_shot launches rewrite every record there: the
+    trial's comparisons only read what a one-shot launch promises).  From a stream of its own: draw(seed) itself never changes."""
+    r3 = np.random.default_rng(seed + 104729)
+    cfg = d["cfg"]
+    if cfg["state_cone"] is not None and cfg["en_state_soc"] and d["nx"] >= 5 and r3.random() < 0.7:
+        a = int(r3.integers(0, d["nx"] - 4))
+        kw = dict(d["kw"], state_cone=([a, a + 2], [3, 3], [float(r3.uniform(0.3, 1.2)), float(r3.uniform(0.3, 1.2))]))
+        d = dict(d, kw=kw, cfg=sc.default_config(d["fams"][0], **kw), force_general=0)
+    else:
+        d = dict(d, force_general=1)
+    return d
+
+
 def trial(seed):
     d = draw(seed)
+    if COVER:
+        d = cover_variant(d, seed)
     nx, nu, N, B, hetero, fams, slow, T, launches = (d[k] for k in ("nx", "nu", "N", "B", "hetero", "fams", "slow", "T", "launches"))
     use_traj, reset_duals, one_shot, debug, cfg = (d[k] for k in ("use_traj", "reset_duals", "one_shot", "debug", "cfg"))
     x0, Xref, Uref, n_pts, traj, offs = (d[k] for k in ("x0", "Xref", "Uref", "n_pts", "traj", "offs"))
@@ -143,6 +164,8 @@ def trial(seed):
     s.update_settings(cfg["abs_pri_tol"], cfg["abs_dua_tol"], cfg["max_iter"], cfg["check_termination"], 1, 1, cfg["en_state_soc"], cfg["en_input_soc"],
                       cfg["en_state_linear"], cfg["en_input_linear"], cfg["en_tv_state_linear"], cfg["en_tv_input_linear"])
     s.set_option("debug", int(debug))
+    if d.get("force_general"):
+        s.set_option("force_general", 1)
     s.set_x0(x0); s.set_x_ref(Xref); s.set_u_ref(Uref)
     if use_traj:
         s.set_reference_trajectory(traj, offs)
@@ -231,6 +254,7 @@ def trial(seed):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    COVER = len(sys.argv) > 3 and sys.argv[3] == "cover"
     assert build_oracle()
     bad = 0
     for seed in range(s0, s0 + n):

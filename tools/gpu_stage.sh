@@ -107,7 +107,9 @@ for stage in "$@"; do
       timeout 1200 python tools/fuzz_parity.py ${FUZZ_N:-800} ${FUZZ_SEED:-50000} > $O/fuzz_parity.txt 2>&1; tail -2 $O/fuzz_parity.txt
       timeout 1200 python tools/fuzz_closed_loop.py $(( ${FUZZ_N:-800} / 2 )) $(( ${FUZZ_SEED:-50000} + 1000 )) > $O/fuzz_closed_loop.txt 2>&1; tail -2 $O/fuzz_closed_loop.txt
       timeout 600 python tools/fuzz_api_sequence.py 150 $(( ${FUZZ_SEED:-50000} + 2000 )) > $O/fuzz_api_sequence.txt 2>&1; tail -2 $O/fuzz_api_sequence.txt
-      timeout 600 python tools/fuzz_parity.py 200 $(( ${FUZZ_SEED:-50000} + 3000 )) phases > $O/fuzz_phases.txt 2>&1; tail -2 $O/fuzz_phases.txt ;;
+      timeout 600 python tools/fuzz_parity.py 200 $(( ${FUZZ_SEED:-50000} + 3000 )) phases > $O/fuzz_phases.txt 2>&1; tail -2 $O/fuzz_phases.txt
+      # round 6: the closed-loop trials once more on the coverage kernel (overlapping cones where the draw has a state cone, else force_general)
+      timeout 900 python tools/fuzz_closed_loop.py $(( ${FUZZ_N:-800} / 2 )) $(( ${FUZZ_SEED:-50000} + 4000 )) cover > $O/fuzz_closed_loop_cover.txt 2>&1; tail -2 $O/fuzz_closed_loop_cover.txt ;;
     exp)
       bash tools/gpu_experiment.sh $O ;;
     *) echo "unknown stage $stage" ;;
