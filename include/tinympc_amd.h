@@ -215,6 +215,9 @@ int tiny_batch_reduce_stats(TinyBatch* b, double* host_out, void* device_out);
  * warm-start records are left as they were.  Round 5: every shape -- wide and long ones on the tile kernel's EXT forms, as are
  * reference windows, "reset_duals" and per-instance problem data; the coverage kernel (overlapping cones, no hipRTC) runs these launch
  * forms and fused steps too, as a loop of single-step launches, and then writes every record back),
+ * "repack_tail" (default -1 = 0; 1: the open instances of a split solve's capped first stage run to max_iter in ONE launch of the tile
+ * kernel's dynamic slot form instead of the follow-up stages; bit-identical; measured slower than the staged lists under the default
+ * dispatch -- profiles/r06_negative_results.md -- and therefore off; read-back "last_tail_tile"),
  * "one_shot_fast" (default 1, round 6: a one-shot launch of a wide / long shape rides on the shape's fast box form -- LDS-offload set,
  * dynamic slots; a form that streams v|z streams into a scratch array of the record's shape, allocated on first use, so that the
  * record stays untouched -- 1.2-1.9x the rate of the all-in-registers form, which 0 brings back; profiles/r06_one_shot_tile_forms.md),

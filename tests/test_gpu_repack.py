@@ -375,3 +375,28 @@ def test_a_fresh_handle_of_a_baseline_shape_takes_the_shipped_plan():
     small.solve()
     assert small.get_option("plan_shipped") == 0               # (the plan of a batch of another order of magnitude is not taken)
     small.close()
+
+
+@pytest.mark.parametrize("dims", [(12, 4, 10), (4, 2, 30), (8, 4, 10)])
+def test_split_solve_tail_on_the_tile_kernel_is_bit_identical(dims):
+    """Round 6, option "repack_tail" = 1: the open instances a capped first stage leaves behind run to max_iter in ONE launch of the
+    tile kernel's dynamic slot form (an index list and a starting iteration: SolveArgs::index / count / iter_base) instead of the
+    follow-up stages.  Measured slower than the staged lists under the default dispatch (profiles/r06_negative_results.md) and therefore
+    off by default; the records it leaves are those of the plain solve, bit for bit."""
+    suite = sc.sweep_suite(*dims, B=300, max_iter=150)
+    ref = sc.run_cases(OracleSolver, suite)
+    plain = run_cases_hip(suite, options={"repack_after": 0, "no_tile": 0, "plan": 0})
+    fields = ("iter", "sol_solved", "x", "u", "vnew", "znew", "g", "y", "v", "z")
+    for K in (4, 9):
+        s = make_batch(suite)
+        for k, v in {"repack_after": K, "repack_tail": 1, "plan": 0}.items():
+            s.set_option(k, v)
+        c = suite["cases"]
+        s.set_x0(c["x0"]); s.set("Xref", c["Xref"]); s.set("Uref", c["Uref"])
+        s.solve()
+        assert s.get_option("last_tail_tile") == 1, (dims, K)
+        s.close()
+        tail = run_cases_hip(suite, options={"repack_after": K, "repack_tail": 1, "plan": 0})
+        for f in fields:
+            assert np.array_equal(tail[f], plain[f]), (f, dims, K)
+    assert np.array_equal(plain["iter"].astype(int), ref["iter"].astype(int)) and len(np.unique(ref["iter"])) > 3

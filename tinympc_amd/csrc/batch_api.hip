@@ -769,6 +769,7 @@ int tiny_batch_set_option(TinyBatch* b, const char* name, long value) {
     else if (!strcmp(name, "share_ref")) b->share_ref = value != 0;
     else if (!strcmp(name, "half_rows")) b->half_rows = (int)value;
     else if (!strcmp(name, "one_shot_fast")) b->one_shot_fast = value != 0;
+    else if (!strcmp(name, "repack_tail")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "repack_tail: -1 (by rule), 0 (follow-up stages), 1 (the tile kernel's dynamic form)"); b->repack_tail = (int)value; }
     else if (!strcmp(name, "plan")) { b->plan_opt = value != 0 ? 1 : 0; if (!b->plan_opt) b->plan_tried = true; }
     else if (!strcmp(name, "prefetch")) { if (value < -1 || value > 1) return fail(b, TINY_ERR_ARG, "prefetch: -1 (by rule), 0 (never), 1 (wherever the form exists)"); b->prefetch = (int)value; }
     else if (!strcmp(name, "prefetch_static")) { if (value < -1 || value > 100) return fail(b, TINY_ERR_ARG, "prefetch_static: percent, 0 ... 100, or -1 (by rule: 75 warm, 50 cold)"); b->prefetch_static = (int)value; }
@@ -915,6 +916,7 @@ long tiny_batch_get_option(TinyBatch* b, const char* name) {
     if (!strcmp(name, "tile_alt_verdict")) return b->tile_verdict;              // 1: the one-row shape runs on the tile kernel's dynamic form (the clock said so), -1: it does not
     if (!strcmp(name, "last_prefetch_grid")) return b->last_pf_grid;         // ... its persistent grid (waves) and its tile buffer (bytes of dynamic LDS)
     if (!strcmp(name, "last_prefetch_lds")) return (long)b->last_pf_lds;
+    if (!strcmp(name, "last_tail_tile")) return b->last_tail_tile ? 1 : 0;     // the last split solve ran its tail on the tile kernel's dynamic form
     if (!strcmp(name, "plan_shipped")) return b->plan_shipped ? 1 : 0;        // a plan of data/plans.txt was imported at the first solve
     if (!strcmp(name, "last_prefetch")) return b->last_prefetch ? 1 : 0;     // the last one-row launch (a split solve: its first stage) took the PREFETCH form
     if (!strcmp(name, "last_half_rows")) return b->last_half ? 1 : 0;       // the last one-row launch took the HALF form (two instances per DPP row)

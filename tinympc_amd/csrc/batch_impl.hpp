@@ -152,8 +152,18 @@ struct TinyBatch {
     // form -- LDS-offload set, v|z streamed to d_vz_scratch instead of its record, dynamic slots --, 0 keeps the all-in-registers form
     bool one_shot_fast = true;
     double* d_vz_scratch = nullptr;
+    // the split solve's TAIL on the tile kernel (round 6): after the capped first stage the open instances -- listed by that launch -- run
+    // to max_iter in ONE launch of the shape's dynamic slot form (tile_dims.txt: its one-row layout), whose rows refill one by one: no
+    // follow-up stages in lock step.  Option "repack_tail": -1 by the clock (probed like the split itself), 0 never, 1 wherever the form
+    // exists.  launch_tile reads tail_index / tail_count / tail_iter_base while enqueue_split_solve has them set
+    int repack_tail = -1, tail_verdict = 0;
+    double tail_rate = 0.0;
+    const int* tail_index = nullptr;
+    const int* tail_count = nullptr;
+    int tail_iter_base = 0;
+    bool last_tail_tile = false;
+    const void* loaded_kernels[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernels whose first launch this handle has paid for
     bool helpers_loaded = false;          // batch_helpers.hip preload_helper_kernels
-    const void* loaded_kernel = nullptr;  // the kernel whose code object this handle has asked for last (hipFuncGetAttributes in front of a first launch)
     bool plan_tried = false, plan_shipped = false;
     int last_pf_grid = 0;
     size_t last_pf_lds = 0;
