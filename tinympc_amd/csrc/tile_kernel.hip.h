@@ -335,14 +335,20 @@ void admm_tile_kernel(const SolveArgs P) {
     // iter_base: the split solve's tail, batch_dispatch.hip enqueue_split_solve): slot s of the launch is instance index[s], its solve
     // carries on at iteration iter_base from the state the capped launch stored.  For a box variant that IS a warm start whose
     // iteration counter does not begin at zero; the rows of the dynamic form refill one by one, so no row waits for its neighbours.
-    const int ninst = P.index ? *P.count : P.batch;
+    // Only the forms that can be asked to do it carry the code (RSM): the dynamic one-row-layout forms (R = 1, trajectory regenerated, all
+    // arrays in registers: the "<shape> 1 1 4" / "0 1 4" entries of tile_dims.txt) -- one more live register cost the 512-register box
+    // forms of the long shapes scratch ((8,8,50): 36 -> 156 B per lane, 12.1 -> 13.0 ms) when every form had it.
+    constexpr bool RSM = DYN && EXT == 0 && SOC == 0 && LIN == 0 && R == 1 && LM == TILE_LM_REGEN;
+    const int ninst = (RSM && P.index) ? *P.count : P.batch;
     const int ntiles = (ninst + IPW - 1) / IPW;
     // ---- the state of this lane's instance (one instance per SLOT of RPI rows; IPW slots per wave)
     double G[L], VN[L], VP[(VL_ || VG) ? 1 : L], QX[(QL || QR) ? 1 : L], Dn[DL ? 1 : L];
     bool gcz[SOC_PASSES];                                              // SOC: the GC cells of this lane's item of pass p are known to be zero
     bool gc_own_dirty = false;                                         // SOC: this lane's own GC cells outside every item may hold a loaded value
     double ref_last = 0.0, x0v = 0.0, x1v = 0.0, x0_last = 0.0, rp = 0.0, rd = 0.0;   // x1v: slot 1 (x_1 | u_0) of the last sweep; x0_last: the x0 the last solve started from
-    int b = 0, iter = 0, iter0 = 0, solved = 0, checked = 0, countdown = 0, step = 0;   // iter0: where this solve's counter began (SolveArgs::iter_base)
+    int b = 0, iter = 0, solved = 0, checked = 0, countdown = 0, step = 0;
+    [[maybe_unused]] int iter0_ = 0;                                    // RSM: where this solve's counter began (SolveArgs::iter_base); else 0
+    auto iter0 = [&]() -> int { if constexpr (RSM) return iter0_; else return 0; };
     double *vpp = nullptr, *vpp0 = nullptr;                              // VPG: see the load
     const double *rpp = nullptr, *rpp0 = nullptr;                        // QXR: the same column of the reference record
     double qx_term = 0.0;                                               // QXR: -(Xref[:,N-1]' Pinf) of this lane (admm.cpp:292)
@@ -408,7 +414,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 if (need) {
                     const int slot = base + __popcll(m & ((1ull << leader) - 1ull));
                     fresh = slot < ninst;
-                    b = (fresh && P.index) ? P.index[slot] : slot;
+                    b = (RSM && fresh && P.index) ? P.index[slot] : slot;
                 }
                 if (base + n >= ninst) exhausted = true;
             }
@@ -416,7 +422,7 @@ void admm_tile_kernel(const SolveArgs P) {
             if (__ballot(have) == 0ull && next_tile < ntiles) {                          // lock step: the whole wave moves on together
                 const int slot = next_tile * IPW + inst;
                 fresh = slot < ninst;
-                b = (fresh && P.index) ? P.index[slot] : slot;
+                b = slot;                                   // (index lists: dynamic forms only)
                 next_tile += gridDim.x;
             }
         }
@@ -488,9 +494,9 @@ void admm_tile_kernel(const SolveArgs P) {
         bool start = fresh;                                             // a solve begins: this instance's first, or its next fused MPC step
         if (have) {
             if (start) {
-                iter0 = step == 0 ? P.iter_base : 0;             // (a multiple of check_termination: the countdown restarts in phase)
-                iter = iter0; solved = 0; countdown = P.check_termination;
-                if (iter0 > 0 && P.check_termination > 0) checked = 1;
+                if constexpr (RSM) iter0_ = step == 0 ? P.iter_base : 0;      // (a multiple of check_termination: the countdown restarts in phase)
+                iter = iter0(); solved = 0; countdown = P.check_termination;
+                if (iter0() > 0 && P.check_termination > 0) checked = 1;
                 x0_last = x0v;
                 ext_begin_solve();
                 if constexpr (SOC) {
@@ -591,7 +597,7 @@ void admm_tile_kernel(const SolveArgs P) {
                 if constexpr (VG) {
                     // (a cold start -- one_shot -- takes v|z as zero without reading it: vnew|znew were loaded as zeros, and only a
                     // launch's FIRST solve is cold: the later solves of a fused launch read what the stream left)
-                    if (iter == iter0 && !(EXTF && P.cold && step == 0)) {   // a solve's first iteration: v|z of the solve before, from its record, into
+                    if (iter == iter0() && !(EXTF && P.cold && step == 0)) {   // a solve's first iteration: v|z of the solve before, from its record, into
                         __builtin_amdgcn_s_waitcnt(0);                 // the vnew|znew registers (dead behind the backward sweep)
 #pragma unroll
                         for (int l = 0; l < L; ++l) VN[l] = (l == 0 ? vpp0 : vpp)[l * NZ];
@@ -804,12 +810,12 @@ void admm_tile_kernel(const SolveArgs P) {
             if (conv || iter >= P.max_iter) {                            // this solve is over (admm.cpp:431-441 | :448-454)
                 solved = conv ? 1 : 0;
                 if constexpr (VG) {
-                    if (!conv && iter > iter0) {                       // out of iterations: v = vnew was the last thing that happened (:445-446)
+                    if (!conv && iter > iter0()) {                       // out of iterations: v = vnew was the last thing that happened (:445-446)
 #pragma unroll
                         for (int l = 0; l < L; ++l) (l == 0 ? vpp0 : vpp)[l * NZ] = VN[l];
                     }
                 }
-                acc_iter += (unsigned)(iter - iter0);
+                acc_iter += (unsigned)(iter - iter0());
                 acc_solved += (unsigned)solved;
                 if (nsteps > 1) {
                     if (P.iter_log && sub == 0 && j16 == 0) P.iter_log[(size_t)step * P.batch + b] = solved ? iter : -iter;
@@ -820,7 +826,8 @@ void admm_tile_kernel(const SolveArgs P) {
                 step += 1;
                 if (step < nsteps) {
                     // the next fused MPC step of the same instance starts in the next pass
-                    iter0 = 0; iter = 0; solved = 0; countdown = P.check_termination;
+                    if constexpr (RSM) iter0_ = 0;
+                    iter = 0; solved = 0; countdown = P.check_termination;
                     x0_last = x0v;
                     ext_begin_solve();
                     if constexpr (SOC) {
