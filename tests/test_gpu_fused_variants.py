@@ -217,3 +217,28 @@ def test_closed_loop_launch_forms_on_the_coverage_kernel(name, force):
         if mode == 1:
             assert np.array_equal(q.get("vnew"), ref["vnew"])
         q.close()
+
+
+def test_step_log_of_a_zero_iteration_step_is_the_same_on_every_kernel():
+    """with max_iter = 0 a fused launch's steps run no iteration.  The one-row kernel logs the u_0 its record holds for such a
+    step; the coverage kernel wrote the slot only when an iteration had run and left uninitialised memory otherwise."""
+    suite = sc.random_state_suite("quadrotor_20hz", B=6, seed=91, soc=False)
+    c = suite["cases"]
+
+    def run(force):
+        s = make_batch(suite)
+        s.update_settings(max_iter=0)
+        s.set_option("force_general", force)
+        s.set_x0(c["x0"]); s.set("Xref", c["Xref"]); s.set("Uref", c["Uref"]); s.set("u", c["u"]); s.set("x", c["x"])
+        s.set_option("steps_per_launch", 3)
+        s.set_option("step_log", 1)
+        s.solve()
+        it, u0 = s.step_log(3)
+        path = s.kernel_path()
+        s.close()
+        return it, u0, path
+    it_r, u0_r, p_r = run(0)
+    it_c, u0_c, p_c = run(1)
+    assert p_r == "regs" and p_c == "cover"
+    assert np.array_equal(it_r, it_c) and np.all(np.abs(it_r) == 0)
+    assert np.all(np.isfinite(u0_c)) and np.array_equal(u0_c[0], c["u"][:, :, 0])       # the u_0 the caller put into the record

@@ -400,3 +400,58 @@ def test_split_solve_tail_on_the_tile_kernel_is_bit_identical(dims):
         for f in fields:
             assert np.array_equal(tail[f], plain[f]), (f, dims, K)
     assert np.array_equal(plain["iter"].astype(int), ref["iter"].astype(int)) and len(np.unique(ref["iter"])) > 3
+
+
+def test_a_plan_with_fields_out_of_range_is_refused_and_foreign_settings_open_its_verdicts():
+    """a TinyBatchPlan is a POD read from a file.  Every verdict must lie in {-1, 0, 1}, every clock reading must be finite
+    and non-negative, counts non-negative; a plan made under other settings (max_iter / check_termination) or for a batch of another
+    order of magnitude is taken as a HINT whose verdicts count as open -- the handle probes again."""
+    import struct
+    suite = sc.tracking_random_suite(B=1024, seed=77)
+    rep = 16
+    cases = {k: np.concatenate([v] * rep, axis=0) for k, v in suite["cases"].items()}
+    big = dict(suite, cases=cases)
+
+    def fresh():
+        s = make_batch(big)
+        s.set_option("plan", 0)
+        s.set_x0(cases["x0"]); s.set_x_ref(cases["Xref"]); s.set_u_ref(cases["Uref"])
+        return s
+    a = fresh()
+    for _ in range(10):
+        a.reset(); a.solve()
+    plan = a.get_plan()
+    f = tm.TinyBatchSolver.plan_fields(plan)
+    a.close()
+    names = ("magic version bytes nx nu N batch max_iter check_termination open_questions auto_verdict auto_cap auto_cap_max_iter "
+             "auto_growth growth_verdict auto_probes tile_verdict regroup_verdict hist_valid").split()
+    doubles = ("auto_plain_rate", "auto_split_rate", "auto_gain", "tile_rate", "lockstep_ratio")
+    doff = (4 * len(names) + 7) // 8 * 8
+    bad = []
+    for name, value in (("auto_verdict", 2), ("tile_verdict", -2), ("regroup_verdict", 3), ("growth_verdict", 7), ("auto_cap", -1), ("auto_cap", 4000),
+                        ("auto_growth", 3), ("auto_probes", -5), ("auto_cap_max_iter", -1), ("batch", 0), ("hist_valid", 2)):
+        p = bytearray(plan)
+        struct.pack_into("<i", p, 4 * names.index(name), value)
+        bad.append((name, value, bytes(p)))
+    for name, value in (("auto_plain_rate", float("nan")), ("auto_split_rate", -1.0), ("auto_gain", float("inf")), ("tile_rate", float("nan")), ("lockstep_ratio", -0.5)):
+        p = bytearray(plan)
+        struct.pack_into("<d", p, doff + 8 * doubles.index(name), value)
+        bad.append((name, value, bytes(p)))
+    b = fresh()
+    for name, value, p in bad:
+        with pytest.raises(tm.TinyMPCError, match="out of range"):
+            b.set_plan(p)
+    b.set_plan(plan)                                              # the genuine one is taken with its verdicts
+    assert b.get_option("auto_split_verdict") == f["auto_verdict"]
+    b.close()
+    # other settings than the plan's: verdicts open
+    c = fresh()
+    c.update_settings(**dict(abs_pri_tol=big["config"]["abs_pri_tol"], abs_dua_tol=big["config"]["abs_dua_tol"], max_iter=big["config"]["max_iter"] - 1))
+    c.set_plan(plan)
+    assert c.get_option("auto_split_verdict") == 0
+    c.close()
+    # a batch of another order of magnitude: verdicts open
+    d = make_batch(suite)                                         # 1 024 instances against the plan's 16 384
+    d.set_plan(plan)
+    assert d.get_option("auto_split_verdict") == 0
+    d.close()
