@@ -130,3 +130,35 @@ def test_automatic_regroup_follows_the_lock_step_estimate():
     h.solve_async()
     assert h.get_option("step_regroup_stretches") == 1
     h.close()
+
+
+def test_shipped_plans_of_config_4_follow_the_cone_setting():
+    """Round 6: tinympc_amd/data/plans.txt holds one entry per cone setting of BASELINE config 4 (`plan_soc <mask>`): the fused rocket
+    episode runs in stretches of MPC steps with the thrust cone alone (rows of a wave disagree: lock-step estimate 1.13) and as ONE launch
+    with the state cone on (1.02) -- on the FIRST episode of a fresh handle."""
+    import tinympc_amd as tm
+    prob, extra = tm.load_problem("rocket_landing_20hz")
+    m = extra["mpc"]
+    nx, nu, N = prob["nx"], prob["nu"], prob["N"]
+    B = 65536
+    rng = np.random.default_rng(3)
+    x0 = 1.1 * np.array(m["xinit"]) * (1 + 0.05 * rng.uniform(-1, 1, (B, nx)))
+    xinit, xg = np.array(m["xinit"], dtype=float), np.array(m["xg"], dtype=float)
+    trj = np.stack([xinit + (xg - xinit) * float(i) / (m["NTOTAL"] - 1) for i in range(m["NTOTAL"])])
+    got = {}
+    for ss, si in ((0, 1), (1, 0)):
+        s = tm.TinyBatchSolver.from_problem(prob, B)
+        s.set_bound_constraints(np.array(m["x_min"]), np.array(m["x_max"]), np.full((nu, 1), m["u_min"]), np.full((nu, 1), m["u_max"]))
+        s.set_cone_constraints(m["state_cone"]["A"], m["state_cone"]["q"], m["state_cone"]["c"], m["input_cone"]["A"], m["input_cone"]["q"], m["input_cone"]["c"])
+        s.update_settings(abs_pri_tol=m["abs_pri_tol"], max_iter=m["max_iter"], en_state_soc=ss, en_input_soc=si)
+        uref = np.zeros((nu, N - 1)); uref[2, :] = m["uref_z"]
+        s.set_u_ref(uref, broadcast=True)
+        s.set_reference_trajectory(trj)
+        s.set_x0(x0)
+        s.set_option("advance_x0", 1)
+        s.set_option("steps_per_launch", 24)
+        s.solve()
+        got[(ss, si)] = (s.get_option("plan_shipped"), s.get_option("step_regroup_stretches"), s.get_option("step_regroup_verdict"))
+        s.close()
+    assert got[(0, 1)][0] == 1 and got[(0, 1)][2] == 1 and got[(0, 1)][1] > 1, got
+    assert got[(1, 0)][0] == 1 and got[(1, 0)][2] == -1 and got[(1, 0)][1] == 1, got

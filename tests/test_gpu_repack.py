@@ -340,8 +340,10 @@ def test_a_fresh_handle_of_a_baseline_shape_takes_the_shipped_plan():
     FIRST solve (read-back "plan_shipped"); option "plan" = 0, other settings or a batch of another order of magnitude: the handle
     probes as before.  Results never depend on it."""
     plans = os.path.join(os.path.dirname(HERE), "tinympc_amd", "data", "plans.txt")
-    entries = [ln.split() for ln in open(plans) if ln.startswith("plan ")]
+    # (`plan ...` or `plan_soc <mask> ...`: an entry that only serves handles whose active cone families are that mask)
+    entries = [ln.split()[1:] if ln.startswith("plan_soc ") else ln.split() for ln in open(plans) if ln.startswith(("plan ", "plan_soc "))]
     assert len(entries) >= 10 and all(len(e) >= 21 and int(e[20]) == len(e) - 21 for e in entries)
+    assert sum(1 for ln in open(plans) if ln.startswith("plan_soc ")) == 3      # BASELINE config 4's three cone settings
     key = [e for e in entries if e[1:5] == ["12", "4", "10", "262144"]]
     assert key and int(key[0][5]) == 100 and int(key[0][7]) in (1, -1)        # config 3's entry: max_iter 100, a settled verdict
     base = sc.tracking_random_suite(B=2048, seed=99)

@@ -1006,8 +1006,12 @@ int tiny_batch_set_plan(TinyBatch* b, const TinyBatchPlan* in) {
 namespace tinympc_amd {
 // ---- shipped plans: tinympc_amd/data/plans.txt next to the library (or TINYMPC_AMD_PLANS=<file>; "0": none) ---------------------------
 // one plan per line, written by tools/make_plans.py from tiny_batch_get_plan of settled handles:
-//   plan nx nu N batch max_iter check_termination auto_verdict auto_cap auto_cap_max_iter auto_growth growth_verdict auto_probes
+//   plan | plan_soc <mask>   nx nu N batch max_iter check_termination auto_verdict auto_cap auto_cap_max_iter auto_growth growth_verdict auto_probes
 //        tile_verdict regroup_verdict auto_plain_rate auto_split_rate auto_gain tile_rate lockstep_ratio nhist i:count ...
+// a line may begin with `plan_soc <mask>` instead of `plan`: the entry then only serves handles whose ACTIVE cone families are that mask
+// (bit 0 inputs, bit 1 states; BASELINE config 4: the three cone settings of one shape settle on different launch forms -- stretches of
+// MPC steps pay with the thrust cone alone, not with the state cone, whose rows already iterate alike)
+static std::vector<int> g_plan_soc;                    // parallel to shipped_plans(): -1 = any
 static const std::vector<TinyBatchPlan>& shipped_plans() {
     static std::vector<TinyBatchPlan> plans;
     static std::once_flag once;
@@ -1027,7 +1031,9 @@ static const std::vector<TinyBatchPlan>& shipped_plans() {
         if (!f) return;
         char word[16];
         while (fscanf(f, "%15s", word) == 1) {
-            if (strcmp(word, "plan") != 0) { int c; while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }      // comments, unknown lines
+            int soc_mask = -1;
+            if (!strcmp(word, "plan_soc")) { if (fscanf(f, "%d", &soc_mask) != 1) break; }
+            else if (strcmp(word, "plan") != 0) { int c; while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }      // comments, unknown lines
             TinyBatchPlan p;
             memset(&p, 0, sizeof(p));
             p.magic = TINY_PLAN_MAGIC; p.version = TINY_PLAN_VERSION; p.bytes = (int)sizeof(TinyBatchPlan);
@@ -1044,6 +1050,7 @@ static const std::vector<TinyBatchPlan>& shipped_plans() {
             if (!ok) break;
             p.hist_valid = nh > 0 ? 1 : 0;
             plans.push_back(p);
+            g_plan_soc.push_back(soc_mask);
         }
         fclose(f);
     });
@@ -1052,7 +1059,11 @@ static const std::vector<TinyBatchPlan>& shipped_plans() {
 bool apply_shipped_plan(TinyBatch* b) {
     const TinyBatchPlan* best = nullptr;
     double best_d = 1e300;
-    for (const TinyBatchPlan& p : shipped_plans()) {
+    const std::vector<TinyBatchPlan>& all = shipped_plans();
+    const int soc_now = ((b->set.en_input_soc && !b->Acu.empty()) ? 1 : 0) | ((b->set.en_state_soc && !b->Acx.empty()) ? 2 : 0);
+    for (size_t i = 0; i < all.size(); ++i) {
+        const TinyBatchPlan& p = all[i];
+        if (g_plan_soc[i] >= 0 && g_plan_soc[i] != soc_now) continue;
         if (p.nx != b->nx || p.nu != b->nu || p.N != b->N || p.max_iter != b->set.max_iter || p.check_termination != b->set.check_termination) continue;
         if (p.batch > 2L * b->batch || b->batch > 2L * p.batch) continue;                 // the batch bucket: within a factor of two
         const double d = std::fabs(std::log((double)p.batch / (double)b->batch));

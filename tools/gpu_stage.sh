@@ -74,7 +74,7 @@ for stage in "$@"; do
     cfgtraffic)
       # HBM-side bytes per solve of every `configs` entry: FETCH_SIZE / WRITE_SIZE passes (kernel trace only) of one entry per run
       cd /tmp
-      for e in ${CFG_ENTRIES:-config3 config4 config4_state_cone config4_both_cones sweep_4_2_10 sweep_12_4_30 sweep_4_2_50 sweep_12_8_30 sweep_20_8_10 sweep_20_8_50}; do
+      for e in ${CFG_ENTRIES:-config3 config4 config4_state_cone config4_both_cones sweep_4_2_10 sweep_12_4_30 sweep_4_2_50 sweep_12_8_30 sweep_20_8_10 sweep_20_8_50 hetero_20_8_10 tracking_12_8_30}; do
         timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/${e}_fetch -o c -- python $R/tools/bench_configs.py $e > $R/$O/${e}_fetch.json 2> $R/$O/${e}_fetch.err
         timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/${e}_write -o c -- python $R/tools/bench_configs.py $e > $R/$O/${e}_write.json 2> $R/$O/${e}_write.err
       done

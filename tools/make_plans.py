@@ -21,12 +21,12 @@ os.environ["TINYMPC_AMD_PLANS"] = "0"                  # the handles below settl
 import tinympc_amd as tm  # noqa: E402
 
 
-def line(plan: bytes, note: str) -> str:
+def line(plan: bytes, note: str, soc=None) -> str:
     f = tm.TinyBatchSolver.plan_fields(plan)
     import struct
     hist = struct.unpack_from("<1024I", plan, len(plan) - 4096)
     nz = [(i, c) for i, c in enumerate(hist) if c] if f["hist_valid"] else []
-    head = "plan %d %d %d %d %d %d %d %d %d %d %d %d %d %d %.9g %.9g %.9g %.9g %.9g %d" % (
+    head = ("plan" if soc is None else "plan_soc %d" % soc) + " %d %d %d %d %d %d %d %d %d %d %d %d %d %d %.9g %.9g %.9g %.9g %.9g %d" % (
         f["nx"], f["nu"], f["N"], f["batch"], f["max_iter"], f["check_termination"], f["auto_verdict"], f["auto_cap"], f["auto_cap_max_iter"],
         f["auto_growth"], f["growth_verdict"], f["auto_probes"], f["tile_verdict"], f["regroup_verdict"], f["auto_plain_rate"], f["auto_split_rate"],
         f["auto_gain"], f["tile_rate"], f["lockstep_ratio"], len(nz))
@@ -95,8 +95,9 @@ def main():
             s.set_x0(x0)
             s.solve_async()
             s.synchronize()
-        if ss == 0:                                    # (one entry per shape / settings / batch: the input-cone episode is BASELINE's config 4)
-            out.append(line(s.get_plan(), "BASELINE config 4: rocket landing x 65 536, input cone, 90 fused steps (the stretch verdict)"))
+        # (one entry per cone setting -- `plan_soc <mask>`, bit 0 inputs, bit 1 states: stretches pay with the thrust cone alone)
+        out.append(line(s.get_plan(), "BASELINE config 4: rocket landing x 65 536, %s, 90 fused steps (the stretch verdict)" %
+                        {(0, 1): "input cone", (1, 0): "state cone", (1, 1): "both cones"}[(ss, si)], soc=(1 if si else 0) | (2 if ss else 0)))
         s.close()
     flush()
     # the config-5 cells the one-row kernel holds
